@@ -1,0 +1,152 @@
+/*
+ * hipk.h -- C ABI of libhipk.so: MI355X (gfx950) kernels for the Module-A
+ * iterative-solver hot path (CSR SpMV, deterministic dots, fused CG / BiCGStab /
+ * GMRES updates, device-resident solve loops).
+ *
+ * The reference (Litianyu141/Pytorch-Sparse-Linalg-torch-amgx.cg.bicg.gmres) has
+ * NO native boundary: its hot path is Python calling ATen.  Every entry point
+ * below therefore names the reference Python construct it replaces
+ * (TSL = src/pytorch_sparse_solver/module_a/torch_sparse_linalg.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer named *_dev / x / y / b / work is a DEVICE pointer
+ *     (tensor.data_ptr()); vectors must be 16-byte aligned.
+ *   - every function returns HIPK_OK (0) or a negative hipk_status;
+ *     hipk_last_error() gives the thread-local message of the last failure.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - the library never allocates inside a solve: the caller supplies `work`
+ *     (size from hipk_*_work_bytes), so solves are graph/stream friendly.
+ *   - all reductions are atomic-free with a fixed summation tree
+ *     (DESIGN.md "reduction spec"): results are bitwise run-to-run reproducible
+ *     and bitwise equal to oracle/krylov_oracle.c.
+ */
+#ifndef HIPK_H
+#define HIPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPK_VERSION 100
+
+typedef struct hipk_csr_s *hipk_csr_t;
+typedef void *hipk_stream_t; /* hipStream_t */
+
+enum hipk_dtype { HIPK_F32 = 0, HIPK_F64 = 1 };
+
+enum hipk_status {
+    HIPK_OK = 0,
+    HIPK_ERR_ARG = -1,         /* bad argument (null pointer, negative size, ...) */
+    HIPK_ERR_HIP = -2,         /* a HIP runtime call failed                       */
+    HIPK_ERR_ALIGN = -3,       /* vector pointer not 16-byte aligned              */
+    HIPK_ERR_UNSUPPORTED = -4, /* dtype / option not built                        */
+    HIPK_ERR_WORKSPACE = -5,   /* work buffer too small                           */
+    HIPK_ERR_NO_DEVICE = -6    /* no gfx950 device visible                        */
+};
+
+/* GMRES least-squares variants, TSL:755-760 (`solve_method`). */
+enum hipk_gmres_method { HIPK_GMRES_BATCHED = 0, HIPK_GMRES_INCREMENTAL = 1 };
+
+/* Solver parameters: the keyword arguments of cg/bicgstab/gmres
+ * (TSL:1019-1021, 1091-1093, 641-644). */
+typedef struct {
+    double tol;            /* relative tolerance (python float, rounded through fp32 as the reference does) */
+    double atol;           /* absolute tolerance                                                           */
+    int64_t maxiter;       /* CG/BiCGStab: iterations; GMRES: restart cycles. <0 => 10*n (TSL:982-984)      */
+    int32_t restart;       /* GMRES Krylov dimension (TSL:642)                                             */
+    int32_t gmres_method;  /* hipk_gmres_method                                                            */
+    int32_t check_every;   /* host polls the device stop word every this many iterations (<=0: default)    */
+    int32_t gpu_tolerances;/* 1: GMRES uses the `device.type=='cuda'` tolerance branch (TSL:737-740)       */
+    int32_t profile;       /* 1: bracket every SpMV launch with events and report stats.spmv_ms_avg        */
+    int32_t reserved;
+} hipk_params;
+
+/* Side channel the reference does not have: filled on return. */
+typedef struct {
+    int64_t iterations;     /* CG/BiCGStab loop iterations; GMRES restart cycles                    */
+    int64_t matvecs;        /* SpMV launches that did work                                          */
+    int32_t info;           /* 0 converged / -1 not, decided exactly as TSL:1007-1016 / TSL:766-773 */
+    int32_t breakdown;      /* BiCGStab: 0, -10 (rho), -11 (alpha/omega) as TSL:902-936; GMRES: 1 on happy breakdown */
+    double b_norm;          /* ||b||                                                                */
+    double residual_norm;   /* true ||b - A x|| recomputed after the loop                           */
+    double x_norm;          /* ||x|| (NaN check)                                                    */
+    double threshold;       /* the value residual_norm was compared against                         */
+    double recurrence_rs;   /* last recurrence <r,r> (CG: gamma)                                    */
+    double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
+    double spmv_ms_avg;     /* average SpMV kernel time when params.profile=1, else 0               */
+    int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
+} hipk_stats;
+
+int hipk_version(void);
+const char *hipk_last_error(void);
+
+/* Number of visible HIP devices whose arch is gfx950 (0 => nothing can run). */
+int hipk_device_count(void);
+
+/* ---- CSR handle --------------------------------------------------------------
+ * Replaces the tensor `A` captured by `_normalize_matvec` (TSL:176-208).
+ * crow/col are device arrays of idx_bytes (4 or 8) wide integers as torch stores
+ * them (int64); they are narrowed once to int32 (SURVEY 7.2 "index width").
+ * `val` is BORROWED: it must stay alive and unchanged until hipk_csr_destroy.
+ * Column indices must be sorted within each row (torch CSR invariant) only for
+ * bitwise parity with the oracle, not for correctness. */
+int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                    const void *crow_dev, const void *col_dev, int idx_bytes,
+                    const void *val_dev, int dtype, hipk_stream_t stream);
+int hipk_csr_destroy(hipk_csr_t h);
+int64_t hipk_csr_rows(hipk_csr_t h);
+int64_t hipk_csr_nnz(hipk_csr_t h);
+/* Algorithmic bytes of one SpMV: nnz*(sizeof(val)+4)+(n+1)*4+2*n*sizeof(val). */
+int64_t hipk_csr_spmv_bytes(hipk_csr_t h);
+
+/* ---- reduction geometry ------------------------------------------------------
+ * Every dot/norm is a two-level fixed tree: the vector is cut in `count` chunks
+ * of `chunk` elements (chunk = 2048 * 2^k, count <= 2048); see DESIGN.md. */
+int hipk_chunk_size(int64_t n);
+int hipk_chunk_count(int64_t n);
+
+/* ---- primitives --------------------------------------------------------------
+ * scratch_dev: device buffer of hipk_scratch_bytes() bytes (partial sums).      */
+size_t hipk_scratch_bytes(void);
+
+/* y = A x  (torch.matmul(A, v), TSL:191). */
+int hipk_spmv(hipk_csr_t h, const void *x, void *y, hipk_stream_t stream);
+/* y = A x and out_dev[0] = <w, y>  (TSL:845-846 fused). */
+int hipk_spmv_dot(hipk_csr_t h, const void *x, void *y, const void *w,
+                  double *out_dev, void *scratch_dev, hipk_stream_t stream);
+/* out_dev[0] = <x, y>  (`_vdot_real_tree`, TSL:130-139). Accumulates in fp64. */
+int hipk_dot(int64_t n, const void *x, const void *y, int dtype, double *out_dev,
+             void *scratch_dev, hipk_stream_t stream);
+/* y = a*x + y with mul-then-add rounding (`_add(y, _mul(a, x))`, TSL:847). */
+int hipk_axpy(int64_t n, double a, const void *x, void *y, int dtype, hipk_stream_t stream);
+/* y = x + b*y  (`_add(z, _mul(beta, p))`, TSL:852). */
+int hipk_xpby(int64_t n, const void *x, double b, void *y, int dtype, hipk_stream_t stream);
+
+/* ---- whole solves (device-resident loops) ------------------------------------
+ * x: in = x0, out = solution.  b is not modified.  `work` >= *_work_bytes.
+ * The loop stops at exactly the iteration the reference stops at (device-side
+ * stop word; the host only polls it every check_every iterations).            */
+size_t hipk_cg_work_bytes(int64_t n, int dtype);
+/* `_isolve(_cg_solve)`: TSL:806-856 + 968-1016. */
+int hipk_cg_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                  const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+
+size_t hipk_bicgstab_work_bytes(int64_t n, int dtype);
+/* `_isolve(_bicgstab_solve)`: TSL:859-964 + 968-1016. */
+int hipk_bicgstab_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                        const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+
+size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype);
+/* `gmres`: TSL:641-803 with `_gmres_batched` (TSL:431-493) or
+ * `_gmres_incremental` (TSL:557-638). */
+int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                     const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPK_H */

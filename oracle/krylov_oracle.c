@@ -1,0 +1,589 @@
+/*
+ * krylov_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, fp64) of the reference's Module-A hot path:
+ *   cg / bicgstab / gmres of
+ *   /root/reference/src/pytorch_sparse_solver/module_a/torch_sparse_linalg.py  (= TSL)
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (libhipk.so + the Python package) never does.
+ *
+ * Parity pinning: the reference ships no golden vectors (its tests are residual
+ * thresholds only), so this restatement is pinned against outputs of the reference
+ * itself, generated in the build container by oracle/gen_golden.py and committed
+ * under tests/golden/ (inputs + x, info, matvec counts, residuals).
+ * tests/test_oracle_golden.py checks every fixture.
+ *
+ * The arithmetic ORDER is part of the contract with the HIP kernels (DESIGN.md
+ * "reduction spec"): they reproduce this file bit-for-bit.
+ *   - dot: chunks of CH = 2048*2^k elements (<= 2048 chunks); in a chunk "virtual
+ *     thread" t of 256 owns elements {2t,2t+1} + 512 j and accumulates with fma in
+ *     ascending order; 256 accumulators are folded by v[t] += v[t+s], s = 128..1;
+ *     chunk partials are folded the same way (thread t takes partials t, t+256, ..).
+ *   - SpMV row: products rounded, then added in CSR order (rows <= 32 entries);
+ *     longer rows: 64 strided lane sums folded by v[l] += v[l+s], s = 32..1.
+ *   - element-wise updates: multiply, round, add, round (as `_add(x, _mul(a, p))`).
+ * Build with -ffp-contract=off (oracle/Makefile) so nothing is fused implicitly.
+ *
+ * Threading (orc_set_threads) only parallelises over chunks / rows, which are
+ * independent in the spec, so results are bitwise identical for any thread count.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_THREADS 256
+#define ORC_MAX_PARTS 2048
+#define ORC_BASE_CHUNK 2048
+#define ORC_LONG_ROW 32
+#define ORC_EPS 2.220446049250313e-16 /* torch.finfo(torch.float64).eps */
+#define ORC_INV_SQRT2 0.7071067811865476 /* TSL:63 */
+
+static int g_threads = 1;
+
+void orc_set_threads(int t) {
+    g_threads = t < 1 ? 1 : t;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#endif
+}
+int orc_get_threads(void) { return g_threads; }
+
+typedef struct {
+    int64_t iterations; /* cg/bicgstab iterations, gmres restart cycles */
+    int64_t matvecs;
+    int32_t info;
+    int32_t breakdown;
+    double b_norm;
+    double residual_norm;
+    double x_norm;
+    double threshold;
+    double recurrence_rs;
+} orc_stats;
+
+/* ------------------------------------------------------------------ geometry */
+void orc_chunk_geom(int64_t n, int *ch, int *g) {
+    const int64_t full = (int64_t)ORC_BASE_CHUNK * ORC_MAX_PARTS;
+    int64_t q = (n + full - 1) / full;
+    if (q < 1) q = 1;
+    int64_t p = 1;
+    while (p < q) p <<= 1;
+    *ch = (int)(ORC_BASE_CHUNK * p);
+    *g = (int)((n + *ch - 1) / *ch);
+    if (*g < 1) *g = 1;
+}
+
+static double tree256(double *v) {
+    for (int s = 128; s >= 1; s >>= 1)
+        for (int t = 0; t < s; ++t) v[t] = v[t] + v[t + s];
+    return v[0];
+}
+
+static double reduce_parts(const double *part, int g) {
+    double v[ORC_THREADS];
+    for (int t = 0; t < ORC_THREADS; ++t) {
+        double acc = 0.0;
+        for (int k = 0; k < ORC_MAX_PARTS / ORC_THREADS; ++k) {
+            const int i = t + k * ORC_THREADS;
+            if (i < g) acc = acc + part[i];
+        }
+        v[t] = acc;
+    }
+    return tree256(v);
+}
+
+static double chunk_dot(const double *a, const double *b, int64_t base, int64_t end) {
+    double v[ORC_THREADS];
+    for (int t = 0; t < ORC_THREADS; ++t) v[t] = 0.0;
+    /* element e of the chunk belongs to virtual thread (e mod 512)/2; ascending e is
+       ascending order inside every thread */
+    for (int64_t i = base; i < end; ++i) {
+        const int t = (int)(((i - base) & 511) >> 1);
+        v[t] = fma(a[i], b[i], v[t]);
+    }
+    return tree256(v);
+}
+
+/* G chunk partials of <a,b> (also what a rank of the row-partitioned solver owns) */
+void orc_dot_parts(int64_t n, const double *a, const double *b, double *parts) {
+    int ch, g;
+    orc_chunk_geom(n, &ch, &g);
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int c = 0; c < g; ++c) {
+        const int64_t base = (int64_t)c * ch;
+        const int64_t end = base + ch < n ? base + ch : n;
+        parts[c] = (base < end) ? chunk_dot(a, b, base, end) : 0.0;
+    }
+}
+
+double orc_reduce_parts(const double *parts, int g) { return reduce_parts(parts, g); }
+
+/* `_vdot_real_tree` (TSL:130-139) */
+double orc_dot(int64_t n, const double *a, const double *b) {
+    int ch, g;
+    orc_chunk_geom(n, &ch, &g);
+    double *parts = (double *)malloc(sizeof(double) * (size_t)g);
+    orc_dot_parts(n, a, b, parts);
+    const double r = reduce_parts(parts, g);
+    free(parts);
+    return r;
+}
+
+/* ------------------------------------------------------------------ SpMV */
+static double row_sum(const int32_t *col, const double *val, const double *x, int lo, int hi) {
+    const int len = hi - lo;
+    if (len <= ORC_LONG_ROW) {
+        double s = 0.0;
+        for (int j = lo; j < hi; ++j) {
+            const double p = val[j] * x[col[j]];
+            s = s + p;
+        }
+        return s;
+    }
+    double v[64];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int j = lo + l; j < hi; j += 64) {
+            const double p = val[j] * x[col[j]];
+            s = s + p;
+        }
+        v[l] = s;
+    }
+    for (int s = 32; s >= 1; s >>= 1)
+        for (int l = 0; l < s; ++l) v[l] = v[l] + v[l + s];
+    return v[0];
+}
+
+/* y = A x  (`torch.matmul(A, v)`, TSL:191); bsub != NULL: y = bsub - A x (TSL:820) */
+void orc_spmv(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *x,
+              const double *bsub, double *y) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int64_t r = 0; r < n; ++r) {
+        const double s = row_sum(col, val, x, crow[r], crow[r + 1]);
+        y[r] = bsub ? bsub[r] - s : s;
+    }
+}
+
+/* ------------------------------------------------------------------ helpers */
+static double tmax(double a, double b) { /* torch.maximum: NaN wins */
+    if (isnan(a) || isnan(b)) return NAN;
+    return a > b ? a : b;
+}
+static double tmin(double a, double b) {
+    if (isnan(a) || isnan(b)) return NAN;
+    return a < b ? a : b;
+}
+static double norm_from_sq(double v) { return sqrt(v < 0.0 ? 0.0 : v); } /* `_norm`, TSL:154-162 */
+
+typedef struct {
+    int64_t n;
+    const int32_t *crow, *col;
+    const double *val;
+} csr_t;
+
+static void isolve_epilogue(const csr_t *A, const double *b, const double *x, double tol, double atol,
+                            double bs, double *tmp, orc_stats *st) {
+    /* TSL:1007-1016 */
+    orc_spmv(A->n, A->crow, A->col, A->val, x, b, tmp);
+    st->residual_norm = norm_from_sq(orc_dot(A->n, tmp, tmp));
+    st->b_norm = norm_from_sq(bs);
+    st->x_norm = norm_from_sq(orc_dot(A->n, x, x));
+    st->threshold = tmax((double)(float)tol * st->b_norm, (double)(float)atol);
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------ CG: TSL:806-856 via _isolve TSL:968-1016 */
+int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
+           double *x /* in: x0, out: x */, double tol, double atol, int64_t maxiter, orc_stats *st) {
+    csr_t A = {n, crow, col, val};
+    memset(st, 0, sizeof(*st));
+    if (maxiter < 0) maxiter = 10 * n;
+    double *r = (double *)malloc(sizeof(double) * (size_t)n);
+    double *p = (double *)malloc(sizeof(double) * (size_t)n);
+    double *Ap = (double *)malloc(sizeof(double) * (size_t)n);
+    const double bs = orc_dot(n, b, b);
+    const float tolf = (float)tol, atolf = (float)atol; /* torch.tensor(python float) is fp32 */
+    const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
+    const double atol2 = a2 > a3 ? a2 : a3;
+    orc_spmv(n, crow, col, val, x, b, r);
+    int64_t matvecs = 1;
+    double gamma = orc_dot(n, r, r);
+    memcpy(p, r, sizeof(double) * (size_t)n);
+    int64_t k = 0;
+    while (!(k >= maxiter || gamma <= atol2)) {
+        orc_spmv(n, crow, col, val, p, NULL, Ap);
+        ++matvecs;
+        const double pAp = orc_dot(n, p, Ap);
+        const double alpha = gamma / pAp;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const double m0 = alpha * p[i];
+            x[i] = x[i] + m0;
+            const double m1 = alpha * Ap[i];
+            r[i] = r[i] - m1;
+        }
+        const double rr = orc_dot(n, r, r);
+        const double beta = rr / gamma;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const double m = beta * p[i];
+            p[i] = r[i] + m;
+        }
+        gamma = rr;
+        ++k;
+    }
+    isolve_epilogue(&A, b, x, tol, atol, bs, Ap, st);
+    st->iterations = k;
+    st->matvecs = matvecs + 1;
+    st->recurrence_rs = gamma;
+    free(r);
+    free(p);
+    free(Ap);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ BiCGStab: TSL:859-964 */
+int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
+                 double *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
+    csr_t A = {n, crow, col, val};
+    memset(st, 0, sizeof(*st));
+    if (maxiter < 0) maxiter = 10 * n;
+    const size_t nb = sizeof(double) * (size_t)n;
+    double *r = (double *)malloc(nb), *rhat = (double *)malloc(nb), *p = (double *)malloc(nb);
+    double *q = (double *)malloc(nb), *s = (double *)malloc(nb), *t = (double *)malloc(nb);
+    const double bs = orc_dot(n, b, b);
+    const float tolf = (float)tol, atolf = (float)atol;
+    const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
+    const double atol2 = a2 > a3 ? a2 : a3;
+    orc_spmv(n, crow, col, val, x, b, r);
+    int64_t matvecs = 1;
+    memcpy(rhat, r, nb);
+    memcpy(p, r, nb);
+    memcpy(q, r, nb);
+    double alpha = 1.0, omega = 1.0, rho = 1.0, rs = 0.0;
+    int64_t k = 0;
+    int code = 0;
+    while (k < maxiter) {
+        rs = orc_dot(n, r, r);
+        if (rs <= atol2) break;
+        const double rho_new = orc_dot(n, rhat, r);
+        if (fabs(rho_new) < ORC_EPS * fabs(rho)) {
+            code = -10;
+            break;
+        }
+        const double beta = rho_new / rho * alpha / omega; /* left to right, TSL:906 */
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const double t1 = omega * q[i];
+            const double t2 = p[i] - t1;
+            const double t3 = beta * t2;
+            p[i] = r[i] + t3;
+        }
+        orc_spmv(n, crow, col, val, p, NULL, q);
+        ++matvecs;
+        const double alpha_new = rho_new / orc_dot(n, rhat, q);
+        if (fabs(alpha_new) < ORC_EPS) {
+            code = -11;
+            break;
+        }
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const double m = alpha_new * q[i];
+            s[i] = r[i] - m;
+        }
+        const int exit_early = orc_dot(n, s, s) < atol2;
+        orc_spmv(n, crow, col, val, s, NULL, t);
+        ++matvecs;
+        const double tt = orc_dot(n, t, t);
+        double omega_new;
+        if (fabs(tt) < ORC_EPS)
+            omega_new = 0.0;
+        else
+            omega_new = orc_dot(n, t, s) / tt;
+        if (fabs(omega_new) < ORC_EPS && !exit_early) {
+            code = -11;
+            break;
+        }
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const double m0 = alpha_new * p[i];
+            if (exit_early) {
+                x[i] = x[i] + m0;
+                r[i] = s[i];
+            } else {
+                const double m1 = omega_new * s[i];
+                const double m2 = m0 + m1;
+                x[i] = x[i] + m2;
+                const double m3 = omega_new * t[i];
+                r[i] = s[i] - m3;
+            }
+        }
+        rho = rho_new;
+        alpha = alpha_new;
+        omega = omega_new;
+        ++k;
+        if (exit_early) break;
+    }
+    isolve_epilogue(&A, b, x, tol, atol, bs, t, st);
+    st->iterations = k;
+    st->matvecs = matvecs + 1;
+    st->breakdown = code;
+    st->recurrence_rs = rs;
+    free(r);
+    free(rhat);
+    free(p);
+    free(q);
+    free(s);
+    free(t);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ GMRES: TSL:641-803, 431-493, 557-638 */
+/* `_lstsq` normal equations + Cholesky, fallback general solve (TSL:391-428).
+   H is (m+1) x m row-major with leading dimension ldh; uses rows 0..k, cols 0..k-1. */
+static void lstsq_normal(const double *H, int ldh, int k, double beta0, double *y) {
+    double a2[32 * 32], b2[32], L[32 * 32];
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int p = 0; p <= k; ++p) s = fma(H[p * ldh + i], H[p * ldh + j], s);
+            a2[i * 32 + j] = s;
+        }
+        b2[i] = H[0 * ldh + i] * beta0; /* beta_vec = [beta0, 0, ...] */
+    }
+    int ok = 1;
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < k && ok; ++j) {
+        double d = a2[j * 32 + j];
+        for (int p = 0; p < j; ++p) d = fma(-L[j * 32 + p], L[j * 32 + p], d);
+        if (!(d > 0.0)) {
+            ok = 0;
+            break;
+        }
+        const double ljj = sqrt(d);
+        L[j * 32 + j] = ljj;
+        for (int i = j + 1; i < k; ++i) {
+            double s = a2[i * 32 + j];
+            for (int p = 0; p < j; ++p) s = fma(-L[i * 32 + p], L[j * 32 + p], s);
+            L[i * 32 + j] = s / ljj;
+        }
+    }
+    if (ok) {
+        double z[32];
+        for (int i = 0; i < k; ++i) {
+            double s = b2[i];
+            for (int p = 0; p < i; ++p) s = fma(-L[i * 32 + p], z[p], s);
+            z[i] = s / L[i * 32 + i];
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            double s = z[i];
+            for (int p = i + 1; p < k; ++p) s = fma(-L[p * 32 + i], y[p], s);
+            y[i] = s / L[i * 32 + i];
+        }
+        return;
+    }
+    /* torch.linalg.solve fallback: Gaussian elimination with partial pivoting */
+    double M[32 * 33];
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) M[i * 33 + j] = a2[i * 32 + j];
+        M[i * 33 + k] = b2[i];
+    }
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < k; ++i)
+            if (fabs(M[i * 33 + c]) > fabs(M[piv * 33 + c])) piv = i;
+        if (piv != c)
+            for (int j = 0; j <= k; ++j) {
+                const double tmp = M[c * 33 + j];
+                M[c * 33 + j] = M[piv * 33 + j];
+                M[piv * 33 + j] = tmp;
+            }
+        for (int i = c + 1; i < k; ++i) {
+            const double f = M[i * 33 + c] / M[c * 33 + c];
+            for (int j = c; j <= k; ++j) M[i * 33 + j] = fma(-f, M[c * 33 + j], M[i * 33 + j]);
+        }
+    }
+    for (int i = k - 1; i >= 0; --i) {
+        double s = M[i * 33 + k];
+        for (int p = i + 1; p < k; ++p) s = fma(-M[i * 33 + p], y[p], s);
+        y[i] = s / M[i * 33 + i];
+    }
+}
+
+/* `_givens_rotation` (TSL:508-518) */
+static void givens(double a, double b, double *cs, double *sn) {
+    if (fabs(b) == 0.0) {
+        *cs = 1.0;
+        *sn = 0.0;
+        return;
+    }
+    if (fabs(a) < fabs(b)) {
+        const double t = -(a / b);
+        const double r = 1.0 / sqrt(1.0 + fabs(t) * fabs(t)); /* torch.rsqrt */
+        *cs = r * t;
+        *sn = r;
+    } else {
+        const double t = -(b / a);
+        const double r = 1.0 / sqrt(1.0 + fabs(t) * fabs(t));
+        *cs = r;
+        *sn = r * t;
+    }
+}
+
+/* gpu_tolerances: 1 = the `device.type == 'cuda'` branch of TSL:737-744 */
+int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
+              double *x, double tol, double atol, int restart, int64_t maxiter, int method /*0 batched,1 incremental*/,
+              int gpu_tolerances, orc_stats *st) {
+    memset(st, 0, sizeof(*st));
+    if (restart < 1 || restart > 31) return -1;
+    if (maxiter < 0) maxiter = 10 * n;
+    const int m = restart;
+    const size_t nb = sizeof(double) * (size_t)n;
+    double *V = (double *)malloc(nb * (size_t)(m + 1)); /* column j at V + j*n */
+    double *tmp = (double *)malloc(nb);
+    double H[32 * 32], R[32 * 32], gv[32][2], beta_vec[33], rvec[32], hvec[32], y[32];
+    const int ldh = 32;
+
+    const double bs = orc_dot(n, b, b);
+    const double b_norm = norm_from_sq(bs);
+    /* TSL:735-748 */
+    const double sq = sqrt((double)n);
+    const double cand = (gpu_tolerances ? 1e-12 : 1e-14) * sq;
+    const double adaptive = (cand > tol) ? cand : (double)(float)tol; /* python max(): float stays a float -> fp32 tensor */
+    const double base_atol = (double)(float)(ORC_EPS * (gpu_tolerances ? 1000 : 100) * (double)n);
+    const double atol_eff = tmax(adaptive * b_norm, tmax((double)(float)atol, base_atol));
+    const double ptol = b_norm * tmin(1.0, atol_eff / b_norm); /* TSL:750-753, M = identity */
+
+    /* TSL:791-792 */
+    double *res = V; /* residual lives in column 0 */
+    orc_spmv(n, crow, col, val, x, b, res);
+    int64_t matvecs = 1;
+    double res_norm = norm_from_sq(orc_dot(n, res, res));
+    {
+        const int use = res_norm > ORC_EPS;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / res_norm : 0.0;
+        if (!use) res_norm = 0.0;
+    }
+    int64_t cycles = 0;
+    int happy = 0;
+    while (cycles < maxiter && res_norm > atol_eff) {
+        memset(H, 0, sizeof(H));
+        memset(R, 0, sizeof(R));
+        for (int i = 0; i < 32; ++i) R[i * 32 + i] = 1.0; /* TSL:581 */
+        memset(gv, 0, sizeof(gv));
+        memset(beta_vec, 0, sizeof(beta_vec));
+        beta_vec[0] = res_norm;
+        int k = 0, breakdown = 0;
+        double err = res_norm;
+        while (k < m && !breakdown && (method == 0 || err > ptol)) {
+            /* ---- `_kth_arnoldi_iteration` (TSL:331-388) */
+            double *w = V + (size_t)(k + 1) * n;
+            orc_spmv(n, crow, col, val, V + (size_t)k * n, NULL, w);
+            ++matvecs;
+            double norm0 = norm_from_sq(orc_dot(n, w, w));
+            if (!(norm0 > ORC_EPS)) norm0 = 0.0;
+            /* CGS, <= 2 passes (TSL:284-328) */
+            for (int j = 0; j <= k; ++j) rvec[j] = 0.0;
+            double qnorm = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {
+                    double rr = 0.0;
+                    for (int j = 0; j <= k; ++j) rr = fma(rvec[j], rvec[j], rr);
+                    double rnorm = norm_from_sq(rr);
+                    if (!(rnorm > ORC_EPS)) rnorm = 0.0;
+                    if (!(rnorm < qnorm * ORC_INV_SQRT2)) break;
+                }
+                for (int j = 0; j <= k; ++j) hvec[j] = orc_dot(n, V + (size_t)j * n, w);
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+                for (int64_t i = 0; i < n; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j <= k; ++j) s = fma(V[(size_t)j * n + i], hvec[j], s);
+                    w[i] = w[i] - s;
+                }
+                for (int j = 0; j <= k; ++j) rvec[j] = rvec[j] + hvec[j];
+                qnorm = norm_from_sq(orc_dot(n, w, w));
+                if (!(qnorm > ORC_EPS)) qnorm = 0.0; /* `_safe_normalize(q)` default thresh */
+            }
+            /* TSL:358-359: thresh = eps * ||A v_k||; the norm is recomputed from q */
+            double norm1 = norm_from_sq(orc_dot(n, w, w));
+            const double thr = ORC_EPS * norm0;
+            const int use = norm1 > thr;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+            for (int64_t i = 0; i < n; ++i) w[i] = use ? w[i] / norm1 : 0.0;
+            if (!use) norm1 = 0.0;
+            for (int j = 0; j <= k; ++j) H[j * ldh + k] = rvec[j];
+            H[(k + 1) * ldh + k] = norm1;
+            breakdown = (norm1 == 0.0);
+            if (method == 1) {
+                /* TSL:595-623 */
+                double hc[33];
+                for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * ldh + k];
+                for (int i = 0; i < k; ++i) {
+                    const double cs = gv[i][0], sn = gv[i][1];
+                    const double t0 = cs * hc[i] - sn * hc[i + 1];
+                    hc[i + 1] = sn * hc[i] + cs * hc[i + 1];
+                    hc[i] = t0;
+                }
+                double cs, sn;
+                givens(hc[k], hc[k + 1], &cs, &sn);
+                gv[k][0] = cs;
+                gv[k][1] = sn;
+                hc[k] = cs * hc[k] - sn * hc[k + 1];
+                hc[k + 1] = 0.0;
+                for (int j = 0; j <= k; ++j) R[j * 32 + k] = hc[j];
+                const double t0 = cs * beta_vec[k] - sn * beta_vec[k + 1];
+                beta_vec[k + 1] = sn * beta_vec[k] + cs * beta_vec[k + 1];
+                beta_vec[k] = t0;
+                err = fabs(beta_vec[k + 1]);
+            }
+            ++k;
+        }
+        if (breakdown) happy = 1;
+        if (k > 0) {
+            if (method == 0) {
+                lstsq_normal(H, ldh, k, res_norm, y);
+            } else {
+                for (int i = k - 1; i >= 0; --i) { /* solve_triangular, TSL:630 */
+                    double s = beta_vec[i];
+                    for (int p = i + 1; p < k; ++p) s = fma(-R[i * 32 + p], y[p], s);
+                    y[i] = s / R[i * 32 + i];
+                }
+            }
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+            for (int64_t i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < k; ++j) s = fma(V[(size_t)j * n + i], y[j], s);
+                x[i] = x[i] + s;
+            }
+        }
+        orc_spmv(n, crow, col, val, x, b, res);
+        ++matvecs;
+        res_norm = norm_from_sq(orc_dot(n, res, res));
+        {
+            const int use = res_norm > ORC_EPS;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+            for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / res_norm : 0.0;
+            if (!use) res_norm = 0.0;
+        }
+        ++cycles;
+    }
+    /* TSL:766-773 */
+    orc_spmv(n, crow, col, val, x, b, tmp);
+    ++matvecs;
+    st->residual_norm = norm_from_sq(orc_dot(n, tmp, tmp));
+    st->x_norm = norm_from_sq(orc_dot(n, x, x));
+    st->b_norm = b_norm;
+    st->threshold = atol_eff * 10;
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+    st->iterations = cycles;
+    st->matvecs = matvecs;
+    st->breakdown = happy;
+    st->recurrence_rs = res_norm;
+    free(V);
+    free(tmp);
+    return 0;
+}

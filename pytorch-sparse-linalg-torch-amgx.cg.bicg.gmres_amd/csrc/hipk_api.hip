@@ -1,0 +1,193 @@
+// hipk_api.hip -- handle management, error plumbing and the SpMV entry points.
+#include <stdarg.h>
+
+#include "hipk_blas1.h"
+#include "hipk_common.h"
+#include "hipk_spmv.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void hipk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *hipk_last_error(void) { return g_err; }
+extern "C" int hipk_version(void) { return HIPK_VERSION; }
+
+extern "C" int hipk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+extern "C" int hipk_chunk_size(int64_t n) { return hipk_make_geom(n).ch; }
+extern "C" int hipk_chunk_count(int64_t n) { return hipk_make_geom(n).g; }
+extern "C" size_t hipk_scratch_bytes(void) {
+    return (size_t)HIPK_SCRATCH_SLOTS * HIPK_MAX_PARTS * sizeof(double);
+}
+
+// ------------------------------------------------------------------ CSR handle
+// Narrow torch's int64 indices to int32 and validate the structure on the way, so a
+// malformed matrix is rejected here instead of faulting inside the SpMV gather.
+template <typename I>
+__global__ void hipk_narrow_check_kernel(const I *__restrict__ crow_in, const I *__restrict__ col_in,
+                                         int *__restrict__ crow, int *__restrict__ col, int64_t n_rows,
+                                         int64_t n_cols, int64_t nnz, int *__restrict__ bad) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i <= n_rows; i += stride) {
+        const int64_t v = (int64_t)crow_in[i];
+        if (v < 0 || v > nnz) atomicOr(bad, 1);
+        if (i == 0 && v != 0) atomicOr(bad, 2);
+        if (i == n_rows && v != nnz) atomicOr(bad, 4);
+        if (i < n_rows && (int64_t)crow_in[i + 1] < v) atomicOr(bad, 8);
+        crow[i] = (int)v;
+    }
+    for (int64_t j = i0; j < nnz; j += stride) {
+        const int64_t v = (int64_t)col_in[j];
+        if (v < 0 || v >= n_cols) atomicOr(bad, 16);
+        col[j] = (int)v;
+    }
+}
+
+extern "C" int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                               const void *crow_dev, const void *col_dev, int idx_bytes,
+                               const void *val_dev, int dtype, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(out != nullptr, HIPK_ERR_ARG, "out is null");
+    *out = nullptr;
+    HIPK_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, HIPK_ERR_ARG, "negative size");
+    HIPK_REQUIRE(n_rows < INT32_MAX && n_cols < INT32_MAX && nnz < INT32_MAX, HIPK_ERR_UNSUPPORTED,
+                 "rows/cols/nnz must fit int32 (indices are narrowed to 32 bit)");
+    HIPK_REQUIRE(idx_bytes == 4 || idx_bytes == 8, HIPK_ERR_ARG, "idx_bytes must be 4 or 8");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype must be f32/f64");
+    HIPK_REQUIRE(crow_dev != nullptr, HIPK_ERR_ARG, "crow is null");
+    HIPK_REQUIRE(nnz == 0 || (col_dev != nullptr && val_dev != nullptr), HIPK_ERR_ARG, "col/val is null");
+    HIPK_REQUIRE(hipk_aligned16(val_dev), HIPK_ERR_ALIGN, "val must be 16-byte aligned");
+
+    hipk_csr_s *h = new hipk_csr_s();
+    memset(h, 0, sizeof(*h));
+    h->n_rows = n_rows;
+    h->n_cols = n_cols;
+    h->nnz = nnz;
+    h->dtype = dtype;
+    h->val = val_dev;
+    h->geom = hipk_make_geom(n_rows);
+    int *bad = nullptr;
+    int bad_h = 0;
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->crow, sizeof(int) * (size_t)(n_rows + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&bad, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_poll, 16 * sizeof(int64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+        const int64_t work = (nnz > n_rows + 1) ? nnz : n_rows + 1;
+        int grid = (int)((work + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        if (grid < 1) grid = 1;
+        if (idx_bytes == 8)
+            hipk_narrow_check_kernel<int64_t><<<grid, 256, 0, stream>>>((const int64_t *)crow_dev,
+                                                                       (const int64_t *)col_dev, h->crow,
+                                                                       h->col, n_rows, n_cols, nnz, bad);
+        else
+            hipk_narrow_check_kernel<int><<<grid, 256, 0, stream>>>((const int *)crow_dev, (const int *)col_dev,
+                                                                   h->crow, h->col, n_rows, n_cols, nnz, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad_h, bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (bad) (void)hipFree(bad);
+    if (e != hipSuccess || bad_h != 0) {
+        if (e != hipSuccess)
+            hipk_set_error("hipk_csr_create: %s", hipGetErrorString(e));
+        else
+            hipk_set_error("hipk_csr_create: malformed CSR structure (flags 0x%x: 1 crow range, 2 crow[0]!=0, "
+                           "4 crow[n]!=nnz, 8 crow not monotone, 16 column out of range)", bad_h);
+        hipk_csr_destroy(h);
+        return e != hipSuccess ? HIPK_ERR_HIP : HIPK_ERR_ARG;
+    }
+    *out = h;
+    return HIPK_OK;
+}
+
+extern "C" int hipk_csr_destroy(hipk_csr_t h) {
+    if (!h) return HIPK_OK;
+    if (h->crow) (void)hipFree(h->crow);
+    if (h->col) (void)hipFree(h->col);
+    if (h->host_poll) (void)hipHostFree(h->host_poll);
+    delete h;
+    return HIPK_OK;
+}
+
+extern "C" int64_t hipk_csr_rows(hipk_csr_t h) { return h ? h->n_rows : -1; }
+extern "C" int64_t hipk_csr_nnz(hipk_csr_t h) { return h ? h->nnz : -1; }
+extern "C" int64_t hipk_csr_spmv_bytes(hipk_csr_t h) {
+    if (!h) return -1;
+    const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
+    return h->nnz * (sv + 4) + (h->n_rows + 1) * 4 + 2 * h->n_rows * sv;
+}
+
+// ------------------------------------------------------------------ SpMV launch
+// CAP (LDS product slots per group): 1280 = 256 rows x 5 nnz, the 5-point stencil's
+// natural group, and it keeps the workgroup at 16 KB LDS => 8 workgroups per CU.
+int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a, hipStream_t stream) {
+    const int grid = hipk_xcd_grid(a.g);
+    if (h->dtype == HIPK_F64)
+        hipk_spmv_kernel<double, 1280><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    else
+        hipk_spmv_kernel<float, 2048><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+static void hipk_fill_spmv_args(const hipk_csr_s *h, hipk_spmv_args &a, const void *x, void *y) {
+    memset(&a, 0, sizeof(a));
+    a.crow = h->crow;
+    a.col = h->col;
+    a.val = h->val;
+    a.x = x;
+    a.y = y;
+    a.n = h->n_rows;
+    a.ch = h->geom.ch;
+    a.g = h->geom.g;
+}
+
+extern "C" int hipk_spmv(hipk_csr_t h, const void *x, void *y, hipk_stream_t stream) {
+    HIPK_REQUIRE(h && x && y, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y), HIPK_ERR_ALIGN, "x/y must be 16-byte aligned");
+    HIPK_REQUIRE(x != y, HIPK_ERR_ARG, "x and y must not alias");
+    if (h->n_rows == 0) return HIPK_OK;
+    hipk_spmv_args a;
+    hipk_fill_spmv_args(h, a, x, y);
+    return hipk_launch_spmv(h, a, (hipStream_t)stream);
+}
+
+extern "C" int hipk_spmv_dot(hipk_csr_t h, const void *x, void *y, const void *w, double *out_dev,
+                             void *scratch_dev, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(h && x && y && w && out_dev && scratch_dev, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y) && hipk_aligned16(w), HIPK_ERR_ALIGN,
+                 "x/y/w must be 16-byte aligned");
+    HIPK_REQUIRE(x != y && w != y, HIPK_ERR_ARG, "y must not alias x or w");
+    hipk_spmv_args a;
+    hipk_fill_spmv_args(h, a, x, y);
+    a.mode = HIPK_SPMV_DOT_W;
+    a.w = w;
+    a.part0 = (double *)scratch_dev;
+    a.part1 = (double *)scratch_dev + HIPK_MAX_PARTS;
+    if (h->n_rows > 0) {
+        int rc = hipk_launch_spmv(h, a, stream);
+        if (rc != HIPK_OK) return rc;
+    }
+    return hipk_launch_finish1(a.part0, h->n_rows > 0 ? a.g : 0, out_dev, stream);
+}

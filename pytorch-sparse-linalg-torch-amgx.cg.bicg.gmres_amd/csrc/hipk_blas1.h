@@ -1,0 +1,57 @@
+// hipk_blas1.h -- chunked element access helpers + BLAS-1 style launchers.
+#pragma once
+#include "hipk_common.h"
+
+#ifdef __HIPCC__
+// 16-byte vector access to VEC consecutive elements starting at element i (i % VEC == 0,
+// base pointer 16-byte aligned); falls back to scalars for the ragged tail (nv < VEC).
+template <typename T>
+__device__ __forceinline__ void hipk_ld(const T *__restrict__ p, int64_t i, int nv,
+                                        T (&out)[hipk_vec<T>::VEC]) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (nv == VEC) {
+        const typename hipk_vec<T>::type v = *(const typename hipk_vec<T>::type *)(p + i);
+        const T *vp = (const T *)&v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = vp[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = (k < nv) ? p[i + k] : (T)0;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void hipk_st(T *__restrict__ p, int64_t i, int nv,
+                                        const T (&in)[hipk_vec<T>::VEC]) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (nv == VEC) {
+        typename hipk_vec<T>::type v;
+        T *vp = (T *)&v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) vp[k] = in[k];
+        *(typename hipk_vec<T>::type *)(p + i) = v;
+    } else {
+        for (int k = 0; k < nv; ++k) p[i + k] = in[k];
+    }
+}
+
+// Iterate the calling thread's elements of chunk c in reduction-spec order.
+// f(int64_t i, int nv): i = first element, nv = valid elements (1..VEC).
+template <typename T, typename F>
+__device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    const int64_t base = (int64_t)c * ch;
+    const int64_t end = (base + ch < n) ? base + ch : n;
+#pragma unroll 4
+    for (int64_t i = base + (int64_t)VEC * threadIdx.x; i < end; i += (int64_t)VEC * HIPK_THREADS) {
+        const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
+        f(i, nv);
+    }
+}
+#endif
+
+// out_dev[0] = fixed-order sum of part[0..g)   (single workgroup)
+int hipk_launch_finish1(const double *part, int g, double *out_dev, hipStream_t stream);
+// part[c] = chunk partial of <x,y>
+int hipk_launch_dot_parts(int64_t n, const void *x, const void *y, int dtype, double *part,
+                          hipStream_t stream);

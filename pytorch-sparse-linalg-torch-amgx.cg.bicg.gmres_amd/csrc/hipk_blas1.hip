@@ -1,0 +1,113 @@
+// hipk_blas1.hip -- deterministic dot and the two-kernel axpy replacements.
+//   hipk_dot   <- `_vdot_real_tree`  (TSL:130-139)
+//   hipk_axpy  <- `_add(y, _mul(a, x))` (TSL:847): mul then add, two roundings
+//   hipk_xpby  <- `_add(x, _mul(b, y))` (TSL:852)
+#include "hipk_blas1.h"
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_dot_kernel(int64_t n, int ch, const T *__restrict__ x,
+                                                                const T *__restrict__ y,
+                                                                double *__restrict__ part) {
+    __shared__ double sbuf[HIPK_THREADS];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        T xv[hipk_vec<T>::VEC], yv[hipk_vec<T>::VEC];
+        hipk_ld<T>(x, i, nv, xv);
+        hipk_ld<T>(y, i, nv, yv);
+#pragma unroll
+        for (int k = 0; k < hipk_vec<T>::VEC; ++k)
+            if (k < nv) acc = fma((double)xv[k], (double)yv[k], acc);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) part[c] = acc;
+}
+
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_finish1_kernel(const double *__restrict__ part, int g,
+                                                                    double *__restrict__ out) {
+    __shared__ double sbuf[HIPK_THREADS];
+    const double r = hipk_reduce_parts(part, g, sbuf);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_axpy_kernel(int64_t n, int ch, double a_,
+                                                                 const T *__restrict__ x, T *__restrict__ y) {
+    const int c = blockIdx.x;
+    const T a = (T)a_;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        T xv[hipk_vec<T>::VEC], yv[hipk_vec<T>::VEC];
+        hipk_ld<T>(x, i, nv, xv);
+        hipk_ld<T>((const T *)y, i, nv, yv);
+#pragma unroll
+        for (int k = 0; k < hipk_vec<T>::VEC; ++k) {
+            if (OP == 0) {
+                const T m = a * xv[k];  // y = y + a*x
+                yv[k] = yv[k] + m;
+            } else {
+                const T m = a * yv[k];  // y = x + a*y
+                yv[k] = xv[k] + m;
+            }
+        }
+        hipk_st<T>(y, i, nv, yv);
+    });
+}
+
+int hipk_launch_finish1(const double *part, int g, double *out_dev, hipStream_t stream) {
+    hipk_finish1_kernel<<<1, HIPK_THREADS, 0, stream>>>(part, g, out_dev);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+int hipk_launch_dot_parts(int64_t n, const void *x, const void *y, int dtype, double *part,
+                          hipStream_t stream) {
+    const hipk_geom gm = hipk_make_geom(n);
+    if (n <= 0) return HIPK_OK;
+    if (dtype == HIPK_F64)
+        hipk_dot_kernel<double><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, (const double *)x,
+                                                                   (const double *)y, part);
+    else
+        hipk_dot_kernel<float><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, (const float *)x,
+                                                                  (const float *)y, part);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_dot(int64_t n, const void *x, const void *y, int dtype, double *out_dev,
+                        void *scratch_dev, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(n >= 0 && x && y && out_dev && scratch_dev, HIPK_ERR_ARG, "bad argument");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y), HIPK_ERR_ALIGN, "x/y must be 16-byte aligned");
+    int rc = hipk_launch_dot_parts(n, x, y, dtype, (double *)scratch_dev, stream);
+    if (rc != HIPK_OK) return rc;
+    return hipk_launch_finish1((const double *)scratch_dev, n > 0 ? hipk_make_geom(n).g : 0, out_dev, stream);
+}
+
+static int hipk_axpy_like(int op, int64_t n, double a, const void *x, void *y, int dtype, hipStream_t stream) {
+    HIPK_REQUIRE(n >= 0 && x && y, HIPK_ERR_ARG, "bad argument");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y), HIPK_ERR_ALIGN, "x/y must be 16-byte aligned");
+    if (n == 0) return HIPK_OK;
+    const hipk_geom gm = hipk_make_geom(n);
+    if (dtype == HIPK_F64) {
+        if (op == 0)
+            hipk_axpy_kernel<double, 0><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, a, (const double *)x, (double *)y);
+        else
+            hipk_axpy_kernel<double, 1><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, a, (const double *)x, (double *)y);
+    } else {
+        if (op == 0)
+            hipk_axpy_kernel<float, 0><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, a, (const float *)x, (float *)y);
+        else
+            hipk_axpy_kernel<float, 1><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, a, (const float *)x, (float *)y);
+    }
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_axpy(int64_t n, double a, const void *x, void *y, int dtype, hipk_stream_t stream) {
+    return hipk_axpy_like(0, n, a, x, y, dtype, (hipStream_t)stream);
+}
+extern "C" int hipk_xpby(int64_t n, const void *x, double b, void *y, int dtype, hipk_stream_t stream) {
+    return hipk_axpy_like(1, n, b, x, y, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,275 @@
+// hipk_cg.hip -- device-resident conjugate gradient.
+//
+// Restates `_isolve(_cg_solve)` (TSL:806-856, 968-1016) for M = identity as three
+// kernels per iteration, all scalars living in device memory:
+//   K1 spmv+dot   Ap = A p, partials of <p,Ap>            (TSL:845-846)   B_spmv
+//   K2 update     alpha = gamma/<p,Ap>; x += alpha p; r -= alpha Ap; partials of <r,r>
+//                                                          (TSL:846-850)   48 n bytes
+//   K3 direction  beta = <r,r>/gamma; p = r + beta p; gamma <- <r,r>; stop test
+//                                                          (TSL:851-853, 841) 24 n bytes
+// = B_spmv + 72 n bytes per iteration, the compulsory traffic between the two global
+// reductions.  Every workgroup re-derives alpha/beta from the chunk
+// partials of the previous kernel with the fixed tree, so no grid barrier, no atomics
+// and no host round trip are needed; the host only polls `stop_it` every check_every
+// iterations and the kernels of iterations >= stop_it return immediately, so the
+// solve stops at exactly the iteration the reference stops at.
+#include <math.h>
+
+#include <vector>
+
+#include "hipk_blas1.h"
+#include "hipk_solve.h"
+#include "hipk_spmv.h"
+
+struct hipk_cg_scal {
+    double gamma[2];   // <r,r> ping-pong by iteration parity
+    double atol2;      // max(tol^2 <b,b>, atol^2)            (TSL:815-817)
+    double bs;         // <b,b>
+    double res2;       // true ||b - A x||^2 after the loop  (TSL:1008)
+    double xx;         // <x,x>                               (TSL:1013)
+    int64_t stop_it;   // iterations >= stop_it are no-ops
+    int64_t pad;
+};
+
+// gamma0 = <r0,r0>, bs = <b,b>, atol2; p = r0.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
+    int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, const double *__restrict__ part_rr,
+    const double *__restrict__ part_bb, const T *__restrict__ r, T *__restrict__ p, double tol2, double atol_sq,
+    int64_t maxiter) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double gamma0, bs;
+    hipk_reduce_parts2(part_rr, part_bb, g, gamma0, bs, sbuf);
+    const int c = blockIdx.x;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        T rv[hipk_vec<T>::VEC];
+        hipk_ld<T>(r, i, nv, rv);
+        hipk_st<T>(p, i, nv, rv);
+    });
+    if (c == 0 && threadIdx.x == 0) {
+        const double a2 = tol2 * bs;
+        const double atol2 = (a2 > atol_sq) ? a2 : atol_sq;  // torch.maximum: NaN-propagation irrelevant here
+        scal->gamma[0] = gamma0;
+        scal->gamma[1] = 0.0;
+        scal->atol2 = atol2;
+        scal->bs = bs;
+        // TSL:841: `if k >= maxiter or rs <= atol2: break` evaluated before the first SpMV
+        scal->stop_it = (maxiter <= 0 || gamma0 <= atol2) ? 0 : INT64_MAX;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
+    int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
+    const double *__restrict__ part_pAp, const T *__restrict__ p, const T *__restrict__ Ap, T *__restrict__ x,
+    T *__restrict__ r, double *__restrict__ part_rr) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const double pAp = hipk_reduce_parts(part_pAp, g, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T alpha = (T)(gamma / pAp);  // TSL:846
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T pv[VEC], av[VEC], xv[VEC], rv[VEC];
+        hipk_ld<T>(p, i, nv, pv);
+        hipk_ld<T>(Ap, i, nv, av);
+        hipk_ld<T>((const T *)x, i, nv, xv);
+        hipk_ld<T>((const T *)r, i, nv, rv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * pv[k];
+            xv[k] = xv[k] + m0;  // TSL:847
+            const T m1 = alpha * av[k];
+            rv[k] = rv[k] - m1;  // TSL:848
+            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);  // TSL:850
+        }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(r, i, nv, rv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) part_rr[c] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
+    int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
+    const double *__restrict__ part_rr, const T *__restrict__ r, T *__restrict__ p) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const double rr = hipk_reduce_parts(part_rr, g, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T beta = (T)(rr / gamma);  // TSL:851
+    const int c = blockIdx.x;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC], pv[VEC];
+        hipk_ld<T>(r, i, nv, rv);
+        hipk_ld<T>((const T *)p, i, nv, pv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m = beta * pv[k];
+            pv[k] = rv[k] + m;  // TSL:852
+        }
+        hipk_st<T>(p, i, nv, pv);
+    });
+    if (c == 0 && threadIdx.x == 0) {
+        scal->gamma[(it + 1) & 1] = rr;  // TSL:853
+        // TSL:841 for the NEXT pass: stop when k+1 >= maxiter or rs <= atol2.
+        // Workgroups of THIS launch compare against `it`, so they are unaffected.
+        if (it + 1 >= maxiter || rr <= scal->atol2) scal->stop_it = it + 1;
+    }
+}
+
+// res2 = sum parts0, xx = sum parts1 -> scal
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_scal *__restrict__ scal, int g,
+                                                                     const double *__restrict__ part_res,
+                                                                     const double *__restrict__ part_xx) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double res2, xx;
+    hipk_reduce_parts2(part_res, part_xx, g, res2, xx, sbuf);
+    if (threadIdx.x == 0) {
+        scal->res2 = res2;
+        scal->xx = xx;
+    }
+}
+
+static inline size_t hipk_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
+    const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
+    const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
+    return 256 + hipk_scratch_bytes() + 3 * vec;
+}
+
+template <typename T>
+static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hipk_params *prm, hipk_stats *st,
+                           hipStream_t stream) {
+    const int64_t n = A->n_rows;
+    const hipk_geom gm = A->geom;
+    const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sizeof(T), 256);
+    hipk_cg_scal *scal = (hipk_cg_scal *)work;
+    double *parts = (double *)(work + 256);
+    double *part_a = parts;                       // <p,Ap> / <b,b> / <x,x>
+    double *part_b = parts + HIPK_MAX_PARTS;      // <r,r>
+    double *part_c = parts + 2 * HIPK_MAX_PARTS;  // spare dot slot of the spmv kernel
+    T *r = (T *)(work + 256 + hipk_scratch_bytes());
+    T *p = (T *)((char *)r + vec);
+    T *Ap = (T *)((char *)p + vec);
+
+    const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;  // TSL:982-984
+    // torch.square(torch.tensor(tol)): python floats become fp32 tensors (TSL:816-817)
+    const float tolf = (float)prm->tol, atolf = (float)prm->atol;
+    const double tol2 = (double)(tolf * tolf), atol_sq = (double)(atolf * atolf);
+    int64_t check = prm->check_every > 0 ? prm->check_every : 64;
+
+    hipk_event_pair whole;
+    HIPK_CHECK_HIP(whole.create());
+    hipk_spmv_profiler prof(prm->profile != 0);
+    HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
+
+    hipk_spmv_args sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.crow = A->crow;
+    sa.col = A->col;
+    sa.val = A->val;
+    sa.n = n;
+    sa.ch = gm.ch;
+    sa.g = gm.g;
+    int rc;
+    int64_t matvecs = 0;
+
+    // r0 = b - A x0 with <r0,r0> partials (TSL:820, 826); <b,b> partials (TSL:815)
+    sa.x = x;
+    sa.y = r;
+    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sa.bsub = b;
+    sa.part0 = part_c;
+    sa.part1 = part_b;
+    if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+    ++matvecs;
+    if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_a, stream)) != HIPK_OK) return rc;
+    hipk_cg_start_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, part_b, part_a, r, p, tol2,
+                                                                atol_sq, maxiter);
+    HIPK_CHECK_HIP(hipGetLastError());
+
+    // ---- iteration loop: enqueue `check` iterations, then an async read of stop_it;
+    // two batches stay in flight so the GPU never waits for the host.
+    sa.x = p;
+    sa.y = Ap;
+    sa.mode = HIPK_SPMV_DOT_W;
+    sa.w = p;
+    sa.bsub = nullptr;
+    sa.part0 = part_a;
+    sa.part1 = part_c;
+    sa.stop_it = &scal->stop_it;
+
+    hipk_poller poll(A->host_poll);
+    HIPK_CHECK_HIP(poll.create());
+    int64_t it = 0, stop = INT64_MAX;
+    HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+    while (it < maxiter) {
+        HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
+        if (stop <= it) break;
+        const int64_t end = (it + check < maxiter) ? it + check : maxiter;
+        for (; it < end; ++it) {
+            sa.it = it;
+            prof.before(stream);
+            if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+            prof.after(stream);
+            hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, p, Ap, x, r,
+                                                                         part_b);
+            hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_b,
+                                                                            r, p);
+        }
+        HIPK_CHECK_HIP(hipGetLastError());
+        HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+    }
+    HIPK_CHECK_HIP(poll.drain(&stop));
+    const int64_t iterations = (stop < it) ? stop : it;
+    matvecs += iterations;
+
+    // ---- TSL:1007-1014: true residual, ||x||
+    sa.x = x;
+    sa.y = Ap;
+    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sa.w = nullptr;
+    sa.bsub = b;
+    sa.part0 = part_c;
+    sa.part1 = part_b;
+    sa.stop_it = nullptr;
+    if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+    ++matvecs;
+    if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_a, stream)) != HIPK_OK) return rc;
+    hipk_cg_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, gm.g, part_b, part_a);
+    HIPK_CHECK_HIP(hipGetLastError());
+    hipk_cg_scal hs;
+    HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
+    HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+
+    hipk_finish_isolve_stats(st, prm, hs.bs, hs.res2, hs.xx, iterations, matvecs);
+    st->recurrence_rs = hs.gamma[iterations & 1];
+    st->breakdown = 0;
+    float ms = 0.f;
+    HIPK_CHECK_HIP(hipEventElapsedTime(&ms, whole.a, whole.b));
+    st->solve_ms = ms;
+    HIPK_CHECK_HIP(prof.collect(st, iterations));
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cg_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                             const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
+                 "b/x must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_cg_work_bytes(A->n_rows, A->dtype), HIPK_ERR_WORKSPACE, "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_cg_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st, (hipStream_t)stream);
+    return hipk_cg_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+}

@@ -1,0 +1,199 @@
+// hipk_common.h -- shared host/device definitions of libhipk (gfx950 only).
+//
+// Reduction spec (mirrored bit-for-bit by oracle/krylov_oracle.c):
+//   * a vector of n elements is cut in G = ceil(n/CH) chunks, CH = 2048 * 2^k with
+//     the smallest k such that G <= 2048;
+//   * inside a chunk, "virtual thread" t (0..255) owns elements
+//     {VEC*t .. VEC*t+VEC-1} + 256*VEC*j, j = 0,1,..  (VEC = 16 B / sizeof(T)) and
+//     accumulates acc = fma(a_i, b_i, acc) over them in ascending i, in fp64;
+//   * the 256 accumulators are summed by the tree  v[t] += v[t+s], s = 128,64,..,1;
+//   * the G chunk partials are summed by thread t taking partials t, t+256, ..
+//     in ascending order, then the same tree.
+// Element-wise updates use mul-then-add (two roundings) exactly like the
+// reference's `_add(x, _mul(alpha, p))`; the library is built with
+// -ffp-contract=off so nothing is fused unless `fma` is spelled out.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hipk.h"
+
+#define HIPK_THREADS 256
+#define HIPK_MAX_PARTS 2048
+#define HIPK_BASE_CHUNK 2048
+// number of partial-sum slots (of HIPK_MAX_PARTS doubles each) in a scratch buffer
+#define HIPK_SCRATCH_SLOTS 4
+
+// ---------------------------------------------------------------- error plumbing
+void hipk_set_error(const char *fmt, ...);
+
+#define HIPK_CHECK_HIP(expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            hipk_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,              \
+                           hipGetErrorString(_e));                                    \
+            return HIPK_ERR_HIP;                                                      \
+        }                                                                             \
+    } while (0)
+
+#define HIPK_REQUIRE(cond, code, msg)                                                 \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            hipk_set_error("%s:%d: %s", __FILE__, __LINE__, msg);                     \
+            return (code);                                                            \
+        }                                                                             \
+    } while (0)
+
+static inline bool hipk_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---------------------------------------------------------------- chunk geometry
+struct hipk_geom {
+    int64_t n;
+    int ch;  // chunk size (elements)
+    int g;   // chunk count (<= HIPK_MAX_PARTS)
+};
+
+static inline hipk_geom hipk_make_geom(int64_t n) {
+    hipk_geom gm;
+    gm.n = n;
+    const int64_t full = (int64_t)HIPK_BASE_CHUNK * HIPK_MAX_PARTS;
+    int64_t q = (n + full - 1) / full;
+    if (q < 1) q = 1;
+    int64_t p = 1;
+    while (p < q) p <<= 1;
+    gm.ch = (int)(HIPK_BASE_CHUNK * p);
+    gm.g = (int)((n + gm.ch - 1) / gm.ch);
+    if (gm.g < 1) gm.g = 1;
+    return gm;
+}
+
+// ---------------------------------------------------------------- CSR handle
+struct hipk_csr_s {
+    int64_t n_rows, n_cols, nnz;
+    int dtype;        // hipk_dtype
+    int *crow;        // device, n_rows+1, owned
+    int *col;         // device, nnz, owned
+    const void *val;  // device, nnz, borrowed
+    hipk_geom geom;   // chunking of the row space
+    int device;
+    // pinned host word block used by solves to poll the device stop word
+    int64_t *host_poll;  // hipHostMalloc, 16 x int64
+};
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device helpers
+template <typename T>
+struct hipk_vec;
+template <>
+struct hipk_vec<double> {
+    typedef double2 type;
+    static constexpr int VEC = 2;
+};
+template <>
+struct hipk_vec<float> {
+    typedef float4 type;
+    static constexpr int VEC = 4;
+};
+
+// XCD-aware placement: workgroups b and b+8 share an XCD (round-robin dispatch), so
+// give XCD k the k-th contiguous eighth of the chunks: the x-vector lines a 5-point
+// stencil re-reads (+-1 grid line) then hit in that XCD's own L2.
+// Speed only -- correctness never depends on it.  Returns -1 for padding blocks.
+__device__ __forceinline__ int hipk_xcd_chunk(int b, int g) {
+    const int per = (g + 7) >> 3;
+    const int c = (b & 7) * per + (b >> 3);
+    return (c < g && (b >> 3) < per) ? c : -1;
+}
+static inline int hipk_xcd_grid(int g) { return ((g + 7) >> 3) << 3; }
+
+// Sum of the 256 per-thread values with the spec's tree. Result valid in ALL threads.
+// sbuf: 256 doubles of LDS. Leaves sbuf reusable (trailing barrier).
+__device__ __forceinline__ double hipk_block_sum(double v, double *sbuf) {
+    const int t = threadIdx.x;
+    sbuf[t] = v;
+    __syncthreads();
+    if (t < 128) sbuf[t] = sbuf[t] + sbuf[t + 128];
+    __syncthreads();
+    if (t < 64) {
+        double a = sbuf[t] + sbuf[t + 64];
+        a = a + __shfl_down(a, 32);
+        a = a + __shfl_down(a, 16);
+        a = a + __shfl_down(a, 8);
+        a = a + __shfl_down(a, 4);
+        a = a + __shfl_down(a, 2);
+        a = a + __shfl_down(a, 1);
+        if (t == 0) sbuf[0] = a;
+    }
+    __syncthreads();
+    const double r = sbuf[0];
+    __syncthreads();
+    return r;
+}
+
+// Two sums at once (sbuf: 512 doubles).
+__device__ __forceinline__ void hipk_block_sum2(double &v0, double &v1, double *sbuf) {
+    const int t = threadIdx.x;
+    sbuf[t] = v0;
+    sbuf[256 + t] = v1;
+    __syncthreads();
+    if (t < 128) {
+        sbuf[t] = sbuf[t] + sbuf[t + 128];
+        sbuf[256 + t] = sbuf[256 + t] + sbuf[256 + t + 128];
+    }
+    __syncthreads();
+    if (t < 64) {
+        double a = sbuf[t] + sbuf[t + 64];
+        double b = sbuf[256 + t] + sbuf[256 + t + 64];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            a = a + __shfl_down(a, s);
+            b = b + __shfl_down(b, s);
+        }
+        if (t == 0) {
+            sbuf[0] = a;
+            sbuf[256] = b;
+        }
+    }
+    __syncthreads();
+    v0 = sbuf[0];
+    v1 = sbuf[256];
+    __syncthreads();
+}
+
+// Final reduction of g (<= 2048) chunk partials, redundantly in every workgroup:
+// all workgroups obtain the same bits without any inter-workgroup hand-off inside a
+// launch (the partials were written by the PREVIOUS kernel on the stream).
+__device__ __forceinline__ double hipk_reduce_parts(const double *__restrict__ part, int g,
+                                                    double *sbuf) {
+    const int t = threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < HIPK_MAX_PARTS / HIPK_THREADS; ++k) {
+        const int i = t + k * HIPK_THREADS;
+        if (i < g) acc = acc + part[i];
+    }
+    return hipk_block_sum(acc, sbuf);
+}
+
+__device__ __forceinline__ void hipk_reduce_parts2(const double *__restrict__ p0,
+                                                   const double *__restrict__ p1, int g,
+                                                   double &r0, double &r1, double *sbuf) {
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < HIPK_MAX_PARTS / HIPK_THREADS; ++k) {
+        const int i = t + k * HIPK_THREADS;
+        if (i < g) {
+            a = a + p0[i];
+            b = b + p1[i];
+        }
+    }
+    hipk_block_sum2(a, b, sbuf);
+    r0 = a;
+    r1 = b;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,152 @@
+// hipk_solve.h -- host-side helpers shared by the device-resident solve loops.
+#pragma once
+#include <math.h>
+
+#include <vector>
+
+#include "hipk_common.h"
+
+struct hipk_event_pair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&a);
+        if (e != hipSuccess) return e;
+        return hipEventCreate(&b);
+    }
+    ~hipk_event_pair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+// Brackets SpMV launches with HIP events on the launch stream (params.profile = 1) so
+// bench.py can quote the kernel's duration in its real cache context.
+struct hipk_spmv_profiler {
+    static constexpr int kMax = 256;
+    bool on;
+    std::vector<hipEvent_t> ev;
+    int used = 0;
+    explicit hipk_spmv_profiler(bool enable) : on(enable) {
+        if (!on) return;
+        ev.resize(2 * kMax, nullptr);
+        for (auto &e : ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                on = false;
+                break;
+            }
+    }
+    ~hipk_spmv_profiler() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    void before(hipStream_t s) {
+        if (on && used < kMax) (void)hipEventRecord(ev[2 * used], s);
+    }
+    void after(hipStream_t s) {
+        if (on && used < kMax) {
+            (void)hipEventRecord(ev[2 * used + 1], s);
+            ++used;
+        }
+    }
+    // valid: number of leading bracketed launches that did real work
+    hipError_t collect(hipk_stats *st, int64_t valid = INT64_MAX) {
+        st->spmv_ms_avg = 0.0;
+        st->spmv_profiled = 0;
+        if (!on) return hipSuccess;
+        const int cnt = (int)((valid < used) ? valid : used);
+        double sum = 0.0;
+        for (int k = 0; k < cnt; ++k) {
+            float ms = 0.f;
+            hipError_t e = hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
+            if (e != hipSuccess) return e;
+            sum += ms;
+        }
+        if (cnt > 0) st->spmv_ms_avg = sum / cnt;
+        st->spmv_profiled = cnt;
+        return hipSuccess;
+    }
+};
+
+// Asynchronous reads of one device word (the stop word) into pinned host memory, at most
+// two in flight: the host learns "the loop has stopped" one batch late and never stalls
+// the GPU queue.
+struct hipk_poller {
+    int64_t *host;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int head = 0, count = 0;
+    explicit hipk_poller(int64_t *pinned) : host(pinned) {}
+    hipError_t create() {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    ~hipk_poller() {
+        for (int i = 0; i < 2; ++i)
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    hipError_t post(const int64_t *dev_word, int64_t, hipStream_t s) {
+        const int slot = (head + count) & 1;
+        hipError_t e = hipMemcpyAsync(&host[slot], dev_word, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ev[slot], s);
+        if (e != hipSuccess) return e;
+        ++count;
+        return hipSuccess;
+    }
+    void harvest(int64_t *stop) {
+        const int64_t v = host[head];
+        if (v < *stop) *stop = v;
+        head = (head + 1) & 1;
+        --count;
+    }
+    hipError_t wait_oldest_if_full(int64_t *stop) {
+        while (count > 0) {
+            hipError_t q = hipEventQuery(ev[head]);
+            if (q == hipSuccess) {
+                harvest(stop);
+            } else if (q == hipErrorNotReady) {
+                break;
+            } else {
+                return q;
+            }
+        }
+        if (count == 2) {
+            hipError_t e = hipEventSynchronize(ev[head]);
+            if (e != hipSuccess) return e;
+            harvest(stop);
+        }
+        return hipSuccess;
+    }
+    hipError_t drain(int64_t *stop) {
+        while (count > 0) {
+            hipError_t e = hipEventSynchronize(ev[head]);
+            if (e != hipSuccess) return e;
+            harvest(stop);
+        }
+        return hipSuccess;
+    }
+};
+
+// torch.maximum semantics (NaN wins).
+static inline double hipk_tmax(double a, double b) {
+    if (isnan(a) || isnan(b)) return NAN;
+    return a > b ? a : b;
+}
+// sqrt(torch.clamp(v, min=0)) as `_norm` does (TSL:154-162); NaN stays NaN.
+static inline double hipk_norm_from_sq(double v) { return sqrt(v < 0.0 ? 0.0 : v); }
+
+// `_isolve` epilogue (TSL:1007-1016): info from the TRUE residual.
+static inline void hipk_finish_isolve_stats(hipk_stats *st, const hipk_params *prm, double bs, double res2,
+                                            double xx, int64_t iterations, int64_t matvecs) {
+    st->iterations = iterations;
+    st->matvecs = matvecs;
+    st->b_norm = hipk_norm_from_sq(bs);
+    st->residual_norm = hipk_norm_from_sq(res2);
+    st->x_norm = hipk_norm_from_sq(xx);
+    // torch.tensor(tol) is an fp32 tensor (TSL:1010-1011)
+    st->threshold = hipk_tmax((double)(float)prm->tol * st->b_norm, (double)(float)prm->atol);
+    const bool failed = isnan(st->x_norm) || (st->residual_norm > st->threshold);
+    st->info = failed ? -1 : 0;
+}

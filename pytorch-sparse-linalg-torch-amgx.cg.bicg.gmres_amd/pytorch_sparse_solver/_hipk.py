@@ -1,0 +1,345 @@
+"""ctypes binding of libhipk.so (include/hipk.h) -- the MI355X kernels behind Module A.
+
+There is NO CPU fallback in here: every function raises if the HIP library is missing
+or no gfx950 device is visible.  `import torch` must come before the library is loaded
+(torch's bundled libamdhip64.so.7 is then the HIP runtime the library binds to).
+"""
+from __future__ import annotations
+
+import collections
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libhipk.so")
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+
+HIPK_F32, HIPK_F64 = 0, 1
+GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
+
+# every symbol include/hipk.h declares (tests/test_abi.py checks the export list)
+SYMBOLS = [
+    "hipk_version", "hipk_last_error", "hipk_device_count",
+    "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
+    "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
+    "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
+    "hipk_cg_work_bytes", "hipk_cg_solve",
+    "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
+    "hipk_gmres_work_bytes", "hipk_gmres_solve",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [
+        ("tol", ctypes.c_double),
+        ("atol", ctypes.c_double),
+        ("maxiter", ctypes.c_int64),
+        ("restart", ctypes.c_int32),
+        ("gmres_method", ctypes.c_int32),
+        ("check_every", ctypes.c_int32),
+        ("gpu_tolerances", ctypes.c_int32),
+        ("profile", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("iterations", ctypes.c_int64),
+        ("matvecs", ctypes.c_int64),
+        ("info", ctypes.c_int32),
+        ("breakdown", ctypes.c_int32),
+        ("b_norm", ctypes.c_double),
+        ("residual_norm", ctypes.c_double),
+        ("x_norm", ctypes.c_double),
+        ("threshold", ctypes.c_double),
+        ("recurrence_rs", ctypes.c_double),
+        ("solve_ms", ctypes.c_double),
+        ("spmv_ms_avg", ctypes.c_double),
+        ("spmv_profiled", ctypes.c_int64),
+    ]
+
+
+@dataclass
+class SolveStats:
+    """Side channel for what the reference never returns."""
+    method: str
+    iterations: int
+    matvecs: int
+    info: int
+    breakdown: int
+    b_norm: float
+    residual_norm: float
+    x_norm: float
+    threshold: float
+    recurrence_rs: float
+    solve_ms: float
+    spmv_ms_avg: float
+    spmv_profiled: int
+
+
+class HipkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libhipk.so for gfx950 with hipcc (csrc/Makefile). Works without a GPU."""
+    import subprocess
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """Load libhipk.so; raise loudly when it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipkError(
+            f"libhipk.so not found at {LIB_PATH}: the MI355X HIP extension is required for CUDA/ROCm tensors "
+            f"(build it with `python __graft_entry__.py` or `make -C {CSRC_DIR}`); there is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    L.hipk_version.restype = i32
+    L.hipk_last_error.restype = ctypes.c_char_p
+    L.hipk_device_count.restype = i32
+    L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]
+    L.hipk_csr_destroy.argtypes = [vp]
+    for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes):
+        f.argtypes = [vp]
+        f.restype = i64
+    L.hipk_chunk_size.argtypes = [i64]
+    L.hipk_chunk_count.argtypes = [i64]
+    L.hipk_scratch_bytes.restype = ctypes.c_size_t
+    L.hipk_spmv.argtypes = [vp, vp, vp, vp]
+    L.hipk_spmv_dot.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.hipk_dot.argtypes = [i64, vp, vp, i32, vp, vp, vp]
+    L.hipk_axpy.argtypes = [i64, dbl, vp, vp, i32, vp]
+    L.hipk_xpby.argtypes = [i64, vp, dbl, vp, i32, vp]
+    for name in ("cg", "bicgstab"):
+        wb = getattr(L, f"hipk_{name}_work_bytes")
+        wb.argtypes = [i64, i32]
+        wb.restype = ctypes.c_size_t
+        getattr(L, f"hipk_{name}_solve").argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params),
+                                                     ctypes.POINTER(Stats), vp]
+    L.hipk_gmres_work_bytes.argtypes = [i64, i32, i32]
+    L.hipk_gmres_work_bytes.restype = ctypes.c_size_t
+    L.hipk_gmres_solve.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().hipk_last_error().decode("utf-8", "replace")
+        raise HipkError(f"{what} failed (status {rc}): {msg}")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float64:
+        return HIPK_F64
+    if dt == torch.float32:
+        return HIPK_F32
+    raise HipkError(f"unsupported dtype {dt}")
+
+
+class CsrHandle:
+    """Owns a hipk_csr_t and keeps the tensors it borrows alive."""
+
+    def __init__(self, crow: torch.Tensor, col: torch.Tensor, val: torch.Tensor, shape):
+        if not val.is_cuda:
+            raise HipkError("CsrHandle needs CUDA/ROCm tensors")
+        self.crow = crow.contiguous()
+        self.col = col.contiguous()
+        self.val = val.contiguous()
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.device = val.device
+        self.dtype = val.dtype
+        if self.crow.dtype != self.col.dtype or self.crow.dtype not in (torch.int32, torch.int64):
+            raise HipkError("CSR indices must both be int32 or both int64")
+        if self.crow.numel() != self.shape[0] + 1 or self.col.numel() != self.val.numel():
+            raise HipkError("inconsistent CSR component sizes")
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib().hipk_csr_create(ctypes.byref(self._h), self.shape[0], self.shape[1], self.val.numel(),
+                                       self.crow.data_ptr(), self.col.data_ptr(), self.crow.element_size(),
+                                       self.val.data_ptr(), _dtype_code(self.dtype), _stream(self.device))
+        _check(rc, "hipk_csr_create")
+
+    @property
+    def ptr(self):
+        return self._h
+
+    @property
+    def n(self) -> int:
+        return self.shape[0]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.val.numel())
+
+    def spmv_bytes(self) -> int:
+        return int(lib().hipk_csr_spmv_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            try:
+                lib().hipk_csr_destroy(self._h)
+            finally:
+                self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# -------------------------------------------------------------------- handle cache
+# Repeated solves with the same matrix (the LDC stepper: one matrix, thousands of RHS)
+# reuse the analysed handle.  Keyed on storage identity + version counters.
+_CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_CACHE_MAX = 4
+
+
+def _cache_key(A: torch.Tensor):
+    if A.layout == torch.sparse_csr:
+        parts = (A.crow_indices(), A.col_indices(), A.values())
+    elif A.layout == torch.sparse_coo:
+        parts = (A._indices(), A._values())
+    else:
+        parts = (A,)
+    return (str(A.layout), tuple(A.shape), str(A.device), A.dtype) + tuple(
+        (p.data_ptr(), p._version, p.numel()) for p in parts)
+
+
+def handle_for(A: torch.Tensor) -> CsrHandle:
+    """CSR handle of a CUDA tensor in any layout (dense / COO / CSR), converted once and cached."""
+    key = _cache_key(A)
+    hit = _CACHE.get(key)
+    if hit is not None:
+        _CACHE.move_to_end(key)
+        return hit[0]
+    src = A.detach()
+    if src.layout == torch.sparse_csr:
+        csr = src
+    elif src.layout == torch.sparse_coo:
+        csr = src.coalesce().to_sparse_csr()
+    elif src.layout == torch.strided:
+        csr = src.to_sparse_csr()
+    else:
+        csr = src.to_sparse_csr()
+    h = CsrHandle(csr.crow_indices(), csr.col_indices(), csr.values(), csr.shape)
+    _CACHE[key] = (h, src)  # keep the source alive so its pointers cannot be recycled
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
+    return h
+
+
+def clear_cache() -> None:
+    _CACHE.clear()
+
+
+# -------------------------------------------------------------------- primitives
+def scratch(device) -> torch.Tensor:
+    return torch.empty(int(lib().hipk_scratch_bytes()), dtype=torch.uint8, device=device)
+
+
+def spmv(h: CsrHandle, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.is_contiguous() and x.dtype == h.dtype and x.numel() == h.shape[1]
+    y = torch.empty(h.shape[0], dtype=h.dtype, device=h.device) if out is None else out
+    with torch.cuda.device(h.device):
+        _check(lib().hipk_spmv(h.ptr, x.data_ptr(), y.data_ptr(), _stream(h.device)), "hipk_spmv")
+    return y
+
+
+def spmv_dot(h: CsrHandle, x: torch.Tensor, w: torch.Tensor):
+    """(A x, <w, A x>) with the dot fused into the SpMV epilogue."""
+    y = torch.empty(h.shape[0], dtype=h.dtype, device=h.device)
+    out = torch.empty(1, dtype=torch.float64, device=h.device)
+    sc = scratch(h.device)
+    with torch.cuda.device(h.device):
+        _check(lib().hipk_spmv_dot(h.ptr, x.data_ptr(), y.data_ptr(), w.data_ptr(), out.data_ptr(), sc.data_ptr(),
+                                   _stream(h.device)), "hipk_spmv_dot")
+    return y, out
+
+
+def dot(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    assert x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype and x.numel() == y.numel()
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    sc = scratch(x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().hipk_dot(x.numel(), x.data_ptr(), y.data_ptr(), _dtype_code(x.dtype), out.data_ptr(),
+                              sc.data_ptr(), _stream(x.device)), "hipk_dot")
+    return out
+
+
+def axpy(a: float, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """y <- y + a*x in place."""
+    with torch.cuda.device(x.device):
+        _check(lib().hipk_axpy(x.numel(), float(a), x.data_ptr(), y.data_ptr(), _dtype_code(x.dtype),
+                               _stream(x.device)), "hipk_axpy")
+    return y
+
+
+def xpby(x: torch.Tensor, b: float, y: torch.Tensor) -> torch.Tensor:
+    """y <- x + b*y in place."""
+    with torch.cuda.device(x.device):
+        _check(lib().hipk_xpby(x.numel(), x.data_ptr(), float(b), y.data_ptr(), _dtype_code(x.dtype),
+                               _stream(x.device)), "hipk_xpby")
+    return y
+
+
+# -------------------------------------------------------------------- whole solves
+def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Params, work_bytes: int) -> SolveStats:
+    L = lib()
+    work = torch.empty(work_bytes, dtype=torch.uint8, device=h.device)
+    st = Stats()
+    fn = getattr(L, f"hipk_{method}_solve")
+    with torch.cuda.device(h.device):
+        rc = fn(h.ptr, b.data_ptr(), x.data_ptr(), work.data_ptr(), work_bytes, ctypes.byref(prm), ctypes.byref(st),
+                _stream(h.device))
+    _check(rc, f"hipk_{method}_solve")
+    return SolveStats(method=method, iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+                      breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
+                      threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
+                      spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled)
+
+
+def solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+          maxiter: Optional[int], restart: int = 20, solve_method: str = "batched", check_every: int = 0,
+          profile: bool = False) -> SolveStats:
+    """Run hipk_{cg,bicgstab,gmres}_solve. `x` holds x0 on entry and the solution on return."""
+    if h.shape[0] != h.shape[1]:
+        raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
+    assert b.is_contiguous() and x.is_contiguous() and b.dtype == h.dtype and x.dtype == h.dtype
+    assert b.numel() == h.n and x.numel() == h.n and b.device == h.device and x.device == h.device
+    prm = Params()
+    prm.tol, prm.atol = float(tol), float(atol)
+    prm.maxiter = -1 if maxiter is None else int(maxiter)
+    prm.restart = int(restart)
+    prm.gmres_method = {"batched": GMRES_BATCHED, "incremental": GMRES_INCREMENTAL}[solve_method]
+    prm.check_every = int(check_every)
+    prm.gpu_tolerances = 1  # device.type == 'cuda' on ROCm as well (TSL:737)
+    prm.profile = 1 if profile else 0
+    L = lib()
+    code = _dtype_code(h.dtype)
+    if method == "gmres":
+        wb = L.hipk_gmres_work_bytes(h.n, int(restart), code)
+    else:
+        wb = getattr(L, f"hipk_{method}_work_bytes")(h.n, code)
+    return _solve(method, h, b, x, prm, int(wb))

@@ -1,0 +1,22 @@
+"""Module A: JAX-style iterative solvers (cg, bicgstab, gmres), MI355X-native.
+
+Same exports as the reference's `module_a/__init__.py:47-63`; CUDA/ROCm tensor inputs run
+on hand-written gfx950 kernels (libhipk.so), everything else on the generic torch path.
+`get_last_stats()` is the one addition: iteration counts the reference never returns.
+"""
+from .torch_sparse_linalg import (
+    cg, bicgstab, gmres,
+    cg_differentiable, bicgstab_differentiable, gmres_differentiable,
+    LinearSolveFunction, ImplicitAdjointFunction, get_last_stats,
+)
+from .torch_tree_util import tree_leaves, tree_map, tree_flatten, tree_unflatten, Partial
+
+__all__ = [
+    'cg', 'bicgstab', 'gmres',
+    'cg_differentiable', 'bicgstab_differentiable', 'gmres_differentiable',
+    'LinearSolveFunction',
+    'tree_leaves', 'tree_map', 'tree_flatten', 'tree_unflatten', 'Partial',
+    'get_last_stats',
+]
+
+__version__ = '1.0.0'

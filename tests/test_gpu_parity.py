@@ -1,0 +1,148 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes, _hipk), against
+the CPU oracle on the same inputs -- BIT-EXACT for SpMV, dots and whole CG/BiCGStab solves
+(the oracle restates the kernels' summation order) -- and against the committed reference
+fixtures (iteration counts, info, x within summation-order rounding)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BICGSTAB_MATVEC_BAND, golden_runs, load_case, run_id
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev_csr(d):
+    n = int(d["n"])
+    return torch.sparse_csr_tensor(torch.from_numpy(d["crow"]).long(), torch.from_numpy(d["col"]).long(),
+                                   torch.from_numpy(d["val"]), size=(n, n)).to(DEV)
+
+
+def random_csr(n, row_lens, seed):
+    rng = np.random.default_rng(seed)
+    crow = np.zeros(n + 1, dtype=np.int64)
+    crow[1:] = np.cumsum(row_lens)
+    col = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in row_lens]) if crow[-1] else np.zeros(0, np.int64)
+    val = rng.standard_normal(int(crow[-1]))
+    return crow, col.astype(np.int64), val
+
+
+CASES = sorted({r["case"] for r in golden_runs()})
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_spmv_bit_exact_on_fixture_matrices(hipk, oracle, case):
+    d = load_case(case)
+    A = dev_csr(d)
+    h = hipk.handle_for(A)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(int(d["n"]))
+    y = hipk.spmv(h, torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert np.array_equal(y, oracle.spmv(d["crow"], d["col"], d["val"], x))
+
+
+@pytest.mark.parametrize("name,n,lens", [
+    ("empty_rows", 700, lambda rng, n: rng.integers(0, 4, n) * (rng.random(n) < 0.5)),
+    ("ragged", 3000, lambda rng, n: rng.integers(0, 40, n)),                  # crosses the long-row threshold (32)
+    ("long_rows", 1500, lambda rng, n: rng.integers(33, 400, n)),
+    ("one_huge_row", 2600, lambda rng, n: np.where(np.arange(n) == 1111, 2500, rng.integers(1, 8, n))),  # > CAP
+    ("dense_as_csr", 1000, lambda rng, n: np.full(n, n)),                     # BASELINE config 1 shape
+    ("single", 1, lambda rng, n: np.array([1])),
+    ("all_empty", 513, lambda rng, n: np.zeros(n, dtype=np.int64)),
+])
+def test_spmv_bit_exact_edge_shapes(hipk, oracle, name, n, lens):
+    rng = np.random.default_rng(11)
+    crow, col, val = random_csr(n, np.asarray(lens(rng, n), dtype=np.int64), seed=3)
+    x = rng.standard_normal(n)
+    h = hipk.CsrHandle(torch.from_numpy(crow).to(DEV), torch.from_numpy(col).to(DEV), torch.from_numpy(val).to(DEV), (n, n))
+    y = hipk.spmv(h, torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert np.array_equal(y, oracle.spmv(crow, col, val, x))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 511, 512, 513, 2047, 2048, 2049, 100_003, 4_000_000, 4_194_305])
+def test_dot_bit_exact(hipk, oracle, n):
+    rng = np.random.default_rng(n)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    got = hipk.dot(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).item()
+    assert got == oracle.dot(a, b)
+
+
+def test_fused_spmv_dot_equals_separate(hipk, oracle):
+    d = load_case("poisson_nx64")
+    h = hipk.handle_for(dev_csr(d))
+    rng = np.random.default_rng(2)
+    x, w = rng.standard_normal(4096), rng.standard_normal(4096)
+    y, dt = hipk.spmv_dot(h, torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV))
+    y_ref = oracle.spmv(d["crow"], d["col"], d["val"], x)
+    assert np.array_equal(y.cpu().numpy(), y_ref) and dt.item() == oracle.dot(w, y_ref)
+
+
+def test_axpy_xpby_rounding(hipk):
+    rng = np.random.default_rng(9)
+    x, y = rng.standard_normal(10_001), rng.standard_normal(10_001)
+    a = 0.3718281828
+    yt = torch.from_numpy(y.copy()).to(DEV)
+    hipk.axpy(a, torch.from_numpy(x).to(DEV), yt)
+    assert np.array_equal(yt.cpu().numpy(), y + a * x)          # numpy: multiply, round, add, round
+    yt = torch.from_numpy(y.copy()).to(DEV)
+    hipk.xpby(torch.from_numpy(x).to(DEV), a, yt)
+    assert np.array_equal(yt.cpu().numpy(), x + a * y)
+
+
+def test_create_rejects_malformed_csr(hipk):
+    crow = torch.tensor([0, 2, 4], device=DEV)
+    val = torch.ones(4, dtype=torch.float64, device=DEV)
+    with pytest.raises(hipk.HipkError, match="malformed"):
+        hipk.CsrHandle(crow, torch.tensor([0, 1, 0, 7], device=DEV), val, (2, 2))       # column out of range
+    with pytest.raises(hipk.HipkError, match="malformed"):
+        hipk.CsrHandle(torch.tensor([0, 3, 2], device=DEV), torch.tensor([0, 1, 0, 1], device=DEV), val, (2, 2))
+
+
+def _solve_gpu(solver, d, r):
+    from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats, gmres
+    kw = dict(r["kwargs"])
+    if r["has_x0"]:
+        kw["x0"] = torch.from_numpy(d["x0"]).to(DEV)
+    x, info = {"cg": cg, "bicgstab": bicgstab, "gmres": gmres}[solver](dev_csr(d), torch.from_numpy(d["b"]).to(DEV), **kw)
+    return x.cpu().numpy(), info, get_last_stats()
+
+
+@pytest.mark.parametrize("r", golden_runs("cg"), ids=run_id)
+def test_cg_bit_exact_vs_oracle_and_reference_counts(hipk, oracle, r):
+    d = load_case(r["case"])
+    x, info, st = _solve_gpu("cg", d, r)
+    ref = oracle.cg(d["crow"], d["col"], d["val"], d["b"], x0=d["x0"] if r["has_x0"] else None, **r["kwargs"])
+    assert np.array_equal(x, ref.x)                                   # bit-exact vs the oracle
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert st.residual_norm == ref.residual_norm and st.recurrence_rs == ref.recurrence_rs
+    assert info == r["info"] and st.matvecs == r["matvecs"]           # same counts as the reference itself
+    x_ref = d[r["tag"] + "_x"]
+    assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+
+
+def test_cg_n4m_headline_properties(hipk):
+    """BASELINE config 2 at full size: size-independent properties (the oracle run is in bench.py)."""
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    nx = 2000
+    A = create_poisson_2d_csr(nx, nx, device=DEV)
+    b = torch.ones(nx * nx, dtype=torch.float64, device=DEV)
+    x1, info1 = cg(A, b, tol=1e-6)
+    st1 = get_last_stats()
+    x2, info2 = cg(A, b, tol=1e-6)
+    st2 = get_last_stats()
+    assert info1 == 0 and info2 == 0
+    assert torch.equal(x1, x2) and st1.iterations == st2.iterations           # run-to-run bitwise reproducible
+    assert abs(st1.iterations - 1.62 * nx) < 0.05 * 1.62 * nx                 # oracle trend: 51/101/204/411/829 at nx=32..512
+    h = hipk.handle_for(A)
+    r = b - hipk.spmv(h, x1)
+    assert (r.norm() / b.norm()).item() <= 1e-6                               # fp64 tolerance of north_star
+    # SpMV linearity at full size
+    g = torch.Generator(device=DEV).manual_seed(0)
+    u = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=g)
+    v = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=g)
+    lhs = hipk.spmv(h, 2.0 * u + v)
+    rhs = 2.0 * hipk.spmv(h, u) + hipk.spmv(h, v)
+    assert torch.allclose(lhs, rhs, rtol=1e-12, atol=1e-12)
+    # and against torch's own CSR matmul (the reference's SpMV, TSL:191)
+    assert torch.allclose(hipk.spmv(h, u), torch.matmul(A, u), rtol=1e-12, atol=1e-12)

@@ -1,0 +1,63 @@
+"""The CPU oracle (oracle/krylov_oracle.c) against fixtures produced by the reference itself
+(oracle/gen_golden.py): this is what pins the oracle (no GPU needed)."""
+import numpy as np
+import pytest
+
+from conftest import BICGSTAB_MATVEC_BAND, golden_runs, load_case, run_id
+
+
+@pytest.mark.parametrize("r", golden_runs(), ids=run_id)
+def test_oracle_reproduces_reference(oracle, r):
+    d = load_case(r["case"])
+    kw = dict(r["kwargs"])
+    x0 = d["x0"] if r["has_x0"] else None
+    res = getattr(oracle, r["solver"])(d["crow"], d["col"], d["val"], d["b"], x0=x0, **kw)
+    x_ref = d[r["tag"] + "_x"]
+    rel = np.linalg.norm(res.x - x_ref) / max(np.linalg.norm(x_ref), 1e-300)
+    tol = kw.get("tol", 1e-5)
+    if r["solver"] == "bicgstab":
+        assert abs(res.matvecs - r["matvecs"]) <= max(2, BICGSTAB_MATVEC_BAND * r["matvecs"])
+        # same verdict, or (chaotic tridiagonal case) a true residual within 50x of the tolerance
+        assert res.info == r["info"] or res.residual_norm <= 50 * max(tol, 1e-300) * res.b_norm
+        assert rel < 1e-4
+    else:
+        assert res.info == r["info"]
+        assert res.matvecs == r["matvecs"]          # same iteration / cycle count as the reference
+        assert rel < 1e-8                             # same iterate up to summation-order rounding
+        assert abs(res.residual_norm - r["residual_norm"]) <= 0.5 * max(res.residual_norm, r["residual_norm"]) \
+            + 1e-12 * r["b_norm"]
+
+
+def test_reduction_spec_geometry(oracle):
+    assert oracle.chunk_geom(1) == (2048, 1)
+    assert oracle.chunk_geom(4_000_000) == (2048, 1954)
+    assert oracle.chunk_geom(2048 * 2048) == (2048, 2048)
+    assert oracle.chunk_geom(2048 * 2048 + 1) == (4096, 1025)
+    assert oracle.chunk_geom(64_000_000) == (32768, 1954)
+
+
+def test_dot_matches_numpy_and_is_thread_independent(oracle):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 511, 512, 513, 2048, 2049, 100_003):
+        a, b = rng.standard_normal(n), rng.standard_normal(n)
+        oracle.set_threads(1)
+        d1 = oracle.dot(a, b)
+        oracle.set_threads(4)
+        d4 = oracle.dot(a, b)
+        oracle.set_threads(1)
+        assert d1 == d4
+        assert abs(d1 - float(np.dot(a, b))) <= 1e-12 * max(1.0, np.abs(a * b).sum())
+    parts = oracle.dot_parts(np.ones(5000), np.ones(5000))
+    assert parts.tolist() == [2048.0, 2048.0, 904.0] and oracle.reduce_parts(parts) == 5000.0
+
+
+def test_spmv_matches_scipy(oracle):
+    sp = pytest.importorskip("scipy.sparse")
+    rng = np.random.default_rng(1)
+    A = sp.random(300, 300, density=0.2, random_state=2, format="csr")   # rows ~60 nnz: long-row tree path
+    A.sort_indices()
+    x = rng.standard_normal(300)
+    y = oracle.spmv(A.indptr, A.indices, A.data, x)
+    assert np.allclose(y, A @ x, rtol=1e-13, atol=1e-13)
+    b = rng.standard_normal(300)
+    assert np.array_equal(oracle.spmv(A.indptr, A.indices, A.data, x, bsub=b), b - y)
