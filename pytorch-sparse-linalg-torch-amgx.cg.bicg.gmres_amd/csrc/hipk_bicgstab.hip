@@ -1,0 +1,396 @@
+// hipk_bicgstab.hip -- device-resident BiCGStab.
+//
+// Restates `_isolve(_bicgstab_solve)` (TSL:859-964, 968-1016) for M = identity as five
+// kernels per iteration; every scalar test of the reference (convergence TSL:894-896,
+// rho breakdown :902-904, alpha breakdown :913-915, early exit :920, omega guard
+// :926-930, omega breakdown :934-936) is evaluated on the device, redundantly and
+// identically by every workgroup, from the chunk partials of the previous kernel:
+//   K1 direction  rs, rho' -> tests; beta; p = r + beta (p - omega q)          32 n bytes
+//   K2 spmv+dot   q = A p, <rhat,q>                                           B_spmv + 8 n
+//   K3 s-update   alpha' = rho'/<rhat,q> -> test; s = r - alpha' q; <s,s>      24 n
+//   K4 spmv+dots  t = A s, <t,s>, <t,t>                                        B_spmv
+//   K5 x/r-update omega' -> tests; x += alpha' p (+ omega' s); r = s (- omega' t);
+//                 <r,r>, <rhat,r> for the next iteration                       56 n
+// = 2 B_spmv + 120 n bytes per iteration.  The full-vector `torch.where` selects of the
+// reference (TSL:944, 950) become a wave-uniform branch.
+#include <math.h>
+
+#include "hipk_blas1.h"
+#include "hipk_solve.h"
+#include "hipk_spmv.h"
+
+#define HIPK_EPS64 2.220446049250313e-16
+#define HIPK_EPS32 1.1920928955078125e-07
+
+struct hipk_bi_scal {
+    double rho, alpha, omega;  // committed by K5 of the last completed iteration
+    double rho_new, alpha_new; // handed from K3 to K5 of the same iteration
+    double atol2, bs;
+    double rs_last;
+    double res2, xx;
+    int64_t stop_it;
+    int64_t iters;
+    int32_t code;      // 0 / -10 / -11  (TSL:903, 914, 935)
+    int32_t extra_mv;  // SpMVs run by an iteration that then broke down
+};
+
+template <typename T>
+struct hipk_eps;
+template <>
+struct hipk_eps<double> {
+    static constexpr double v = HIPK_EPS64;
+};
+template <>
+struct hipk_eps<float> {
+    static constexpr double v = HIPK_EPS32;
+};
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
+    int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, const double *__restrict__ part_rr,
+    const double *__restrict__ part_bb, double *__restrict__ part_rhr, const T *__restrict__ r, T *__restrict__ rhat,
+    T *__restrict__ p, T *__restrict__ q, double tol2, double atol_sq, int64_t maxiter) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double rr, bs;
+    hipk_reduce_parts2(part_rr, part_bb, g, rr, bs, sbuf);
+    const int c = blockIdx.x;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        T rv[hipk_vec<T>::VEC];
+        hipk_ld<T>(r, i, nv, rv);
+        hipk_st<T>(rhat, i, nv, rv);  // TSL:876
+        hipk_st<T>(p, i, nv, rv);     // TSL:890
+        hipk_st<T>(q, i, nv, rv);
+    });
+    if (threadIdx.x == 0) {
+        part_rhr[c] = part_rr[c];  // <rhat, r0> = <r0, r0>
+        if (c == 0) {
+            const double a2 = tol2 * bs;
+            scal->rho = 1.0;
+            scal->alpha = 1.0;
+            scal->omega = 1.0;
+            scal->atol2 = (a2 > atol_sq) ? a2 : atol_sq;
+            scal->bs = bs;
+            scal->rs_last = 0.0;
+            scal->stop_it = (maxiter <= 0) ? 0 : INT64_MAX;
+            scal->iters = 0;
+            scal->code = 0;
+            scal->extra_mv = 0;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
+    int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rr,
+    const double *__restrict__ part_rhr, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ p) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double rs, rho_new;
+    hipk_reduce_parts2(part_rr, part_rhr, g, rs, rho_new, sbuf);
+    const double rho = scal->rho, alpha = scal->alpha, omega = scal->omega;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (lead) scal->rs_last = rs;
+    if (rs <= scal->atol2) {  // TSL:894-896
+        if (lead) scal->stop_it = it;
+        return;
+    }
+    if (fabs(rho_new) < hipk_eps<T>::v * fabs(rho)) {  // TSL:902-904
+        if (lead) {
+            scal->stop_it = it;
+            scal->code = -10;
+        }
+        return;
+    }
+    const T beta = (T)(rho_new / rho * alpha / omega);  // TSL:906, left to right
+    const T om = (T)omega;
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC], qv[VEC], pv[VEC];
+        hipk_ld<T>(r, i, nv, rv);
+        hipk_ld<T>(q, i, nv, qv);
+        hipk_ld<T>((const T *)p, i, nv, pv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {  // TSL:907
+            const T t1 = om * qv[k];
+            const T t2 = pv[k] - t1;
+            const T t3 = beta * t2;
+            pv[k] = rv[k] + t3;
+        }
+        hipk_st<T>(p, i, nv, pv);
+    });
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
+    int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
+    const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
+    double *__restrict__ part_ss) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double rho_new, rq;
+    hipk_reduce_parts2(part_rhr, part_rq, g, rho_new, rq, sbuf);
+    const double alpha_new = rho_new / rq;  // TSL:910
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (fabs(alpha_new) < hipk_eps<T>::v) {  // TSL:913-915
+        if (lead) {
+            scal->stop_it = it;
+            scal->code = -11;
+            scal->extra_mv = 1;
+        }
+        return;
+    }
+    if (lead) {
+        scal->rho_new = rho_new;
+        scal->alpha_new = alpha_new;
+    }
+    const T al = (T)alpha_new;
+    double acc = 0.0;
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC], qv[VEC];
+        hipk_ld<T>(r, i, nv, rv);
+        hipk_ld<T>(q, i, nv, qv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m = al * qv[k];
+            rv[k] = rv[k] - m;  // TSL:917
+            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);
+        }
+        hipk_st<T>(s, i, nv, rv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) part_ss[blockIdx.x] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
+    int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, int64_t maxiter,
+    const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
+    const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ rhat,
+    T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    const double ss = hipk_reduce_parts(part_ss, g, sbuf);
+    double ts, tt;
+    hipk_reduce_parts2(part_ts, part_tt, g, ts, tt, sbuf);
+    const double atol2 = scal->atol2;
+    const double alpha_new = scal->alpha_new, rho_new = scal->rho_new;
+    const bool exit_early = ss < atol2;                                      // TSL:920 (strict)
+    const double omega_new = (fabs(tt) < hipk_eps<T>::v) ? 0.0 : ts / tt;    // TSL:926-930
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (fabs(omega_new) < hipk_eps<T>::v && !exit_early) {                   // TSL:934-936
+        if (lead) {
+            scal->stop_it = it;
+            scal->code = -11;
+            scal->extra_mv = 2;
+        }
+        return;
+    }
+    const T al = (T)alpha_new, om = (T)omega_new;
+    double acc0 = 0.0, acc1 = 0.0;
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T pv[VEC], sv[VEC], xv[VEC], hv[VEC], rv[VEC];
+        hipk_ld<T>(p, i, nv, pv);
+        hipk_ld<T>(s, i, nv, sv);
+        hipk_ld<T>((const T *)x, i, nv, xv);
+        hipk_ld<T>(rhat, i, nv, hv);
+        if (exit_early) {  // TSL:942-950 with exit_early true
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const T m0 = al * pv[k];
+                xv[k] = xv[k] + m0;
+                rv[k] = sv[k];
+            }
+        } else {
+            T tv[VEC];
+            hipk_ld<T>(t, i, nv, tv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const T m0 = al * pv[k];
+                const T m1 = om * sv[k];
+                const T m2 = m0 + m1;
+                xv[k] = xv[k] + m2;
+                const T m3 = om * tv[k];
+                rv[k] = sv[k] - m3;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            if (k < nv) {
+                acc0 = fma((double)rv[k], (double)rv[k], acc0);
+                acc1 = fma((double)hv[k], (double)rv[k], acc1);
+            }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(r, i, nv, rv);
+    });
+    hipk_block_sum2(acc0, acc1, sbuf);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = acc0;
+        part_rhr[blockIdx.x] = acc1;
+    }
+    if (lead) {
+        scal->rho = rho_new;
+        scal->alpha = alpha_new;
+        scal->omega = omega_new;
+        scal->iters = it + 1;
+        if (exit_early || it + 1 >= maxiter) scal->stop_it = it + 1;  // TSL:961, loop bound :892
+    }
+}
+
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_final_kernel(hipk_bi_scal *__restrict__ scal, int g,
+                                                                     const double *__restrict__ part_res,
+                                                                     const double *__restrict__ part_xx) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double res2, xx;
+    hipk_reduce_parts2(part_res, part_xx, g, res2, xx, sbuf);
+    if (threadIdx.x == 0) {
+        scal->res2 = res2;
+        scal->xx = xx;
+    }
+}
+
+static constexpr int kBiSlots = 8;
+
+extern "C" size_t hipk_bicgstab_work_bytes(int64_t n, int dtype) {
+    const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
+    const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
+    return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec;
+}
+
+template <typename T>
+static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hipk_params *prm, hipk_stats *st,
+                                 hipStream_t stream) {
+    const int64_t n = A->n_rows;
+    const hipk_geom gm = A->geom;
+    const size_t vec = hipk_align_up((size_t)n * sizeof(T), 256);
+    hipk_bi_scal *scal = (hipk_bi_scal *)work;
+    double *parts = (double *)(work + 256);
+    double *part_rr = parts, *part_rhr = parts + HIPK_MAX_PARTS, *part_rq = parts + 2 * HIPK_MAX_PARTS;
+    double *part_ss = parts + 3 * HIPK_MAX_PARTS, *part_ts = parts + 4 * HIPK_MAX_PARTS;
+    double *part_tt = parts + 5 * HIPK_MAX_PARTS, *part_bb = parts + 6 * HIPK_MAX_PARTS;
+    double *part_spare = parts + 7 * HIPK_MAX_PARTS;
+    char *vbase = work + 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double);
+    T *r = (T *)vbase, *rhat = (T *)(vbase + vec), *p = (T *)(vbase + 2 * vec), *q = (T *)(vbase + 3 * vec);
+    T *s = (T *)(vbase + 4 * vec), *t = (T *)(vbase + 5 * vec);
+
+    const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;
+    const float tolf = (float)prm->tol, atolf = (float)prm->atol;
+    const double tol2 = (double)(tolf * tolf), atol_sq = (double)(atolf * atolf);
+    const int64_t check = prm->check_every > 0 ? prm->check_every : 32;
+
+    hipk_event_pair whole;
+    HIPK_CHECK_HIP(whole.create());
+    hipk_spmv_profiler prof(prm->profile != 0);
+    HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
+
+    hipk_spmv_args sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.crow = A->crow;
+    sa.col = A->col;
+    sa.val = A->val;
+    sa.n = n;
+    sa.ch = gm.ch;
+    sa.g = gm.g;
+    int rc;
+
+    sa.x = x;
+    sa.y = r;
+    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sa.bsub = b;
+    sa.part0 = part_spare;
+    sa.part1 = part_rr;
+    if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+    if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
+    hipk_bi_start_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, part_rr, part_bb, part_rhr, r,
+                                                                rhat, p, q, tol2, atol_sq, maxiter);
+    HIPK_CHECK_HIP(hipGetLastError());
+
+    hipk_spmv_args sq = sa, stt = sa;
+    sq.x = p;
+    sq.y = q;
+    sq.mode = HIPK_SPMV_DOT_W;
+    sq.w = rhat;
+    sq.bsub = nullptr;
+    sq.part0 = part_rq;
+    sq.part1 = part_spare;
+    sq.stop_it = &scal->stop_it;
+    stt.x = s;
+    stt.y = t;
+    stt.mode = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
+    stt.w = s;
+    stt.bsub = nullptr;
+    stt.part0 = part_ts;
+    stt.part1 = part_tt;
+    stt.stop_it = &scal->stop_it;
+
+    hipk_poller poll(A->host_poll);
+    HIPK_CHECK_HIP(poll.create());
+    int64_t it = 0, stop = INT64_MAX;
+    HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+    while (it < maxiter) {
+        HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
+        if (stop <= it) break;
+        const int64_t end = (it + check < maxiter) ? it + check : maxiter;
+        for (; it < end; ++it) {
+            hipk_bi_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr, part_rhr,
+                                                                            r, q, p);
+            sq.it = it;
+            prof.before(stream);
+            if ((rc = hipk_launch_spmv(A, sq, stream)) != HIPK_OK) return rc;
+            prof.after(stream);
+            hipk_bi_supdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq, r,
+                                                                          q, s, part_ss);
+            stt.it = it;
+            if ((rc = hipk_launch_spmv(A, stt, stream)) != HIPK_OK) return rc;
+            hipk_bi_xupdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_ss,
+                                                                          part_ts, part_tt, p, s, t, rhat, x, r,
+                                                                          part_rr, part_rhr);
+        }
+        HIPK_CHECK_HIP(hipGetLastError());
+        HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+    }
+    HIPK_CHECK_HIP(poll.drain(&stop));
+
+    // TSL:1007-1014
+    sa.x = x;
+    sa.y = t;
+    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sa.bsub = b;
+    sa.part0 = part_spare;
+    sa.part1 = part_ss;
+    sa.stop_it = nullptr;
+    if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+    if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
+    hipk_bi_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, gm.g, part_ss, part_bb);
+    HIPK_CHECK_HIP(hipGetLastError());
+    hipk_bi_scal hs;
+    HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
+    HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+
+    hipk_finish_isolve_stats(st, prm, hs.bs, hs.res2, hs.xx, hs.iters, 1 + 2 * hs.iters + hs.extra_mv + 1);
+    st->recurrence_rs = hs.rs_last;
+    st->breakdown = hs.code;
+    float ms = 0.f;
+    HIPK_CHECK_HIP(hipEventElapsedTime(&ms, whole.a, whole.b));
+    st->solve_ms = ms;
+    HIPK_CHECK_HIP(prof.collect(st, hs.iters));
+    return HIPK_OK;
+}
+
+extern "C" int hipk_bicgstab_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                                   const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
+                 "b/x must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_bicgstab_work_bytes(A->n_rows, A->dtype), HIPK_ERR_WORKSPACE, "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_bicgstab_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st,
+                                             (hipStream_t)stream);
+    return hipk_bicgstab_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+}

@@ -135,7 +135,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_sca
     }
 }
 
-static inline size_t hipk_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;

@@ -1,0 +1,643 @@
+// hipk_gmres.hip -- restarted GMRES with the Krylov basis resident in HBM.
+//
+// Restates `gmres` (TSL:641-803) with `_gmres_batched` (TSL:431-493) and
+// `_gmres_incremental` (TSL:557-638) for M = identity.  What changes against the
+// reference's data layout and launch pattern:
+//   * the basis is COLUMN-CONTIGUOUS (column j = one aligned n-vector); the reference keeps
+//     the basis index fastest (TSL:448-452) and CLONES the whole n x (m+1) basis every
+//     Arnoldi step (TSL:363-368) -- here A v_k is written straight into column k+1 and
+//     orthogonalised / normalised in place;
+//   * one Arnoldi step = SpMV (+||w||^2) | multi-dot h = V^H w over the k+1 LIVE columns
+//     (one pass over w, k+1 accumulators per thread) | tiny reduce | fused q = w - V h
+//     (+||q||^2) | CGS2 decision on the device (TSL:322-326) | optional second pass |
+//     guarded normalise + Hessenberg column (+ Givens update for 'incremental');
+//   * no host synchronisation inside a restart cycle: breakdown (TSL:387) and the
+//     incremental early exit (TSL:591, 622) set a device stop word that turns the
+//     remaining steps into no-ops; the host reads H once per cycle and solves the
+//     <= 31 x 30 least-squares problem (normal equations + Cholesky, TSL:407-421, or the
+//     triangular solve TSL:630) in the same arithmetic order as the oracle.
+// Traffic of step k (fp64): B_spmv + 8n(k+2) [multi-dot] + 8n(k+3) [update] + 16n [normalise].
+#include <math.h>
+
+#include "hipk_blas1.h"
+#include "hipk_solve.h"
+#include "hipk_spmv.h"
+
+#define HIPK_GM_MAXM 31
+#define HIPK_GM_LDH 32
+#define HIPK_EPS64 2.220446049250313e-16
+#define HIPK_INV_SQRT2 0.7071067811865476
+
+struct hipk_gm_scal {
+    double res_norm;  // ||r|| after `_safe_normalize` (0 when <= eps)
+    double bs;        // <b,b>
+    double res2, xx;  // final true residual^2 and <x,x>
+    double qnorm;     // step-local ||q|| after CGS pass 1 (thresholded)
+    double err;       // incremental: |beta_vec[k+1]|
+    double ptol;
+    int64_t stop_step;  // Arnoldi steps >= stop_step of the current cycle are no-ops
+    int64_t steps_done;
+    int32_t pass2;      // second CGS pass wanted for the current step
+    int32_t breakdown;
+    int32_t incremental;
+    int32_t pad;
+    double H[(HIPK_GM_MAXM + 2) * HIPK_GM_LDH];  // (m+1) x m, row-major, ld 32
+    double R[HIPK_GM_LDH * HIPK_GM_LDH];
+    double gv[HIPK_GM_LDH * 2];
+    double beta_vec[HIPK_GM_LDH + 1];
+    double hvec[HIPK_GM_LDH];
+    double rvec[HIPK_GM_LDH];
+};
+static constexpr size_t kGmHeader = 32768;
+static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
+static constexpr int kGmSlots = 8;  // ww, qq, res, bb, xx, spare x3
+
+struct hipk_gm_y {
+    double y[HIPK_GM_LDH];
+};
+
+// ---- reduce 8 per-thread values at once with the spec tree (sbuf: 8*256 doubles)
+__device__ __forceinline__ void hipk_block_sum8(double (&v)[8], int nb, double *sbuf) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) sbuf[b * HIPK_THREADS + t] = v[b];
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            sbuf[b * HIPK_THREADS + t] = sbuf[b * HIPK_THREADS + t] + sbuf[b * HIPK_THREADS + t + 128];
+    }
+    __syncthreads();
+    if (t < 64) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            double a = sbuf[b * HIPK_THREADS + t] + sbuf[b * HIPK_THREADS + t + 64];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) a = a + __shfl_down(a, s);
+            v[b] = a;  // valid in lane 0
+        }
+    }
+    __syncthreads();
+    (void)nb;
+}
+
+// part[j*MAXP + c] = chunk partial of <V_j, w>, j = 0..k  (`_project_on_columns`, TSL:276-281)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_kernel(
+    int64_t n, int ch, const hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    const T *__restrict__ w, double *__restrict__ part) {
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    __shared__ double sbuf[8 * HIPK_THREADS];
+    const int c = blockIdx.x;
+    double acc[HIPK_GM_LDH];
+#pragma unroll
+    for (int j = 0; j < HIPK_GM_LDH; ++j) acc[j] = 0.0;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+        hipk_ld<T>(w, i, nv, wv);
+#pragma unroll
+        for (int j = 0; j < HIPK_GM_LDH; ++j) {
+            if (j <= k) {
+                T vv[VEC];
+                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (e < nv) acc[j] = fma((double)vv[e], (double)wv[e], acc[j]);
+            }
+        }
+    });
+#pragma unroll
+    for (int b0 = 0; b0 < HIPK_GM_LDH; b0 += 8) {
+        if (b0 <= k) {
+            double v8[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v8[b] = acc[b0 + b];
+            hipk_block_sum8(v8, 8, sbuf);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b0 + b <= k) part[(size_t)(b0 + b) * HIPK_MAX_PARTS + c] = v8[b];
+            }
+        }
+    }
+}
+
+// hvec[j] = fixed-order sum of part[j][0..g)   (one workgroup per j)
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_hreduce_kernel(hipk_gm_scal *__restrict__ scal, int k, int pass,
+                                                                       int g, const double *__restrict__ part) {
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const int j = blockIdx.x;
+    const double h = hipk_reduce_parts(part + (size_t)j * HIPK_MAX_PARTS, g, sbuf);
+    if (threadIdx.x == 0) scal->hvec[j] = h;
+}
+
+// q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
+    int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    T *__restrict__ w, double *__restrict__ part_qq) {
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    __shared__ double hs[HIPK_GM_LDH];
+    if (threadIdx.x < HIPK_GM_LDH) hs[threadIdx.x] = (threadIdx.x <= k) ? scal->hvec[threadIdx.x] : 0.0;
+    __syncthreads();
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+        hipk_ld<T>((const T *)w, i, nv, wv);
+        double s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < HIPK_GM_LDH; ++j) {
+            if (j <= k) {
+                T vv[VEC];
+                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
+                const double hj = hs[j];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], hj, s[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            wv[e] = (T)((double)wv[e] - s[e]);
+            if (e < nv) acc = fma((double)wv[e], (double)wv[e], acc);
+        }
+        hipk_st<T>(w, i, nv, wv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) {
+        part_qq[c] = acc;
+        if (c == 0) {
+            for (int j = 0; j <= k; ++j) scal->rvec[j] = ((pass == 0) ? 0.0 : scal->rvec[j]) + hs[j];
+        }
+    }
+}
+
+// second CGS pass iff ||r|| < ||q|| / sqrt(2)  (TSL:313-326), norms guarded as `_safe_normalize`
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_scal *__restrict__ scal, int k, int g,
+                                                                      const double *__restrict__ part_qq) {
+    if (k >= scal->stop_step) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const double qq = hipk_reduce_parts(part_qq, g, sbuf);
+    if (threadIdx.x == 0) {
+        double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+        if (!(qnorm > HIPK_EPS64)) qnorm = 0.0;
+        double rr = 0.0;
+        for (int j = 0; j <= k; ++j) rr = fma(scal->rvec[j], scal->rvec[j], rr);
+        double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+        if (!(rnorm > HIPK_EPS64)) rnorm = 0.0;
+        scal->qnorm = qnorm;
+        scal->pass2 = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ void hipk_givens(double a, double b, double &cs, double &sn) {  // TSL:508-518
+    if (fabs(b) == 0.0) {
+        cs = 1.0;
+        sn = 0.0;
+        return;
+    }
+    if (fabs(a) < fabs(b)) {
+        const double t = -(a / b);
+        const double r = 1.0 / sqrt(1.0 + fabs(t) * fabs(t));
+        cs = r * t;
+        sn = r;
+    } else {
+        const double t = -(b / a);
+        const double r = 1.0 / sqrt(1.0 + fabs(t) * fabs(t));
+        cs = r;
+        sn = r * t;
+    }
+}
+
+// v_{k+1} = q/||q|| (zero when ||q|| <= eps ||A v_k||), column k of H, breakdown,
+// and for 'incremental' the Givens update + early-exit test  (TSL:358-387, 595-623)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
+    int64_t n, int ch, int g, hipk_gm_scal *__restrict__ scal, int k, T *__restrict__ w,
+    const double *__restrict__ part_qq, const double *__restrict__ part_ww) {
+    if (k >= scal->stop_step) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double qq, ww;
+    hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
+    double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
+    double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
+    if (!(norm0 > HIPK_EPS64)) norm0 = 0.0;
+    const double thr = HIPK_EPS64 * norm0;
+    const bool use = norm1 > thr;
+    const T nrm = (T)norm1;
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+        hipk_ld<T>((const T *)w, i, nv, wv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wv[e] = use ? wv[e] / nrm : (T)0;
+        hipk_st<T>(w, i, nv, wv);
+    });
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!use) norm1 = 0.0;
+        double *H = scal->H;
+        for (int j = 0; j <= k; ++j) H[j * HIPK_GM_LDH + k] = scal->rvec[j];
+        H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+        scal->steps_done = k + 1;
+        bool stop = false;
+        if (norm1 == 0.0) {  // TSL:387
+            scal->breakdown = 1;
+            stop = true;
+        }
+        if (scal->incremental) {
+            double hc[HIPK_GM_LDH + 1];
+            for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * HIPK_GM_LDH + k];
+            for (int i = 0; i < k; ++i) {
+                const double cs = scal->gv[2 * i], sn = scal->gv[2 * i + 1];
+                const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+                const double t0 = p0 - p1;
+                const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
+                hc[i + 1] = p2 + p3;
+                hc[i] = t0;
+            }
+            double cs, sn;
+            hipk_givens(hc[k], hc[k + 1], cs, sn);
+            scal->gv[2 * k] = cs;
+            scal->gv[2 * k + 1] = sn;
+            {
+                const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
+                hc[k] = p0 - p1;
+            }
+            hc[k + 1] = 0.0;
+            for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
+            double *bv = scal->beta_vec;
+            const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
+            const double t0 = p0 - p1;
+            const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
+            bv[k + 1] = p2 + p3;
+            bv[k] = t0;
+            const double err = fabs(bv[k + 1]);
+            scal->err = err;
+            if (!(err > scal->ptol)) stop = true;  // TSL:591
+        }
+        if (stop) scal->stop_step = k + 1;
+    }
+}
+
+__global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int incremental, double ptol) {
+    const int t = threadIdx.x;
+    for (int i = t; i < (HIPK_GM_MAXM + 2) * HIPK_GM_LDH; i += blockDim.x) scal->H[i] = 0.0;
+    for (int i = t; i < HIPK_GM_LDH * HIPK_GM_LDH; i += blockDim.x)
+        scal->R[i] = ((i / HIPK_GM_LDH) == (i % HIPK_GM_LDH)) ? 1.0 : 0.0;  // TSL:581
+    for (int i = t; i < HIPK_GM_LDH * 2; i += blockDim.x) scal->gv[i] = 0.0;
+    for (int i = t; i <= HIPK_GM_LDH; i += blockDim.x) scal->beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
+    if (t == 0) {
+        scal->stop_step = INT64_MAX;
+        scal->steps_done = 0;
+        scal->pass2 = 0;
+        scal->breakdown = 0;
+        scal->incremental = incremental;
+        scal->ptol = ptol;
+        scal->err = scal->res_norm;
+    }
+}
+
+// x += V[:, :k] y   (TSL:488-490)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_xupdate_kernel(int64_t n, int ch, int k,
+                                                                       const T *__restrict__ V, int64_t ldv,
+                                                                       T *__restrict__ x, hipk_gm_y yy) {
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T xv[VEC];
+        hipk_ld<T>((const T *)x, i, nv, xv);
+        double s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < HIPK_GM_LDH; ++j) {
+            if (j < k) {
+                T vv[VEC];
+                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], yy.y[j], s[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) xv[e] = (T)((double)xv[e] + s[e]);
+        hipk_st<T>(x, i, nv, xv);
+    });
+}
+
+// residual (already in column 0) -> unit residual + norm  (`_safe_normalize`, TSL:217-273); also <b,b>
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_resnorm_kernel(int64_t n, int ch, int g,
+                                                                       hipk_gm_scal *__restrict__ scal,
+                                                                       T *__restrict__ v0,
+                                                                       const double *__restrict__ part_res,
+                                                                       const double *__restrict__ part_bb) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double res2, bs;
+    hipk_reduce_parts2(part_res, part_bb, g, res2, bs, sbuf);
+    const double norm = sqrt(res2 < 0.0 ? 0.0 : res2);
+    const bool use = norm > HIPK_EPS64;
+    const T nrm = (T)norm;
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC];
+        hipk_ld<T>((const T *)v0, i, nv, rv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) rv[e] = use ? rv[e] / nrm : (T)0;
+        hipk_st<T>(v0, i, nv, rv);
+    });
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->res_norm = use ? norm : 0.0;
+        scal->bs = bs;
+    }
+}
+
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_final_kernel(hipk_gm_scal *__restrict__ scal, int g,
+                                                                     const double *__restrict__ part_res,
+                                                                     const double *__restrict__ part_xx) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double res2, xx;
+    hipk_reduce_parts2(part_res, part_xx, g, res2, xx, sbuf);
+    if (threadIdx.x == 0) {
+        scal->res2 = res2;
+        scal->xx = xx;
+    }
+}
+
+// ---------------------------------------------------------------- host-side small dense solves
+// `_lstsq` (TSL:391-428): normal equations + Cholesky, general solve when Cholesky fails.
+// Same operation order as oracle/krylov_oracle.c::lstsq_normal.
+static void hipk_lstsq_normal(const double *H, int ldh, int k, double beta0, double *y) {
+    double a2[32 * 32], b2[32], L[32 * 32];
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int p = 0; p <= k; ++p) s = fma(H[p * ldh + i], H[p * ldh + j], s);
+            a2[i * 32 + j] = s;
+        }
+        b2[i] = H[0 * ldh + i] * beta0;
+    }
+    bool ok = true;
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < k && ok; ++j) {
+        double d = a2[j * 32 + j];
+        for (int p = 0; p < j; ++p) d = fma(-L[j * 32 + p], L[j * 32 + p], d);
+        if (!(d > 0.0)) {
+            ok = false;
+            break;
+        }
+        const double ljj = sqrt(d);
+        L[j * 32 + j] = ljj;
+        for (int i = j + 1; i < k; ++i) {
+            double s = a2[i * 32 + j];
+            for (int p = 0; p < j; ++p) s = fma(-L[i * 32 + p], L[j * 32 + p], s);
+            L[i * 32 + j] = s / ljj;
+        }
+    }
+    if (ok) {
+        double z[32];
+        for (int i = 0; i < k; ++i) {
+            double s = b2[i];
+            for (int p = 0; p < i; ++p) s = fma(-L[i * 32 + p], z[p], s);
+            z[i] = s / L[i * 32 + i];
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            double s = z[i];
+            for (int p = i + 1; p < k; ++p) s = fma(-L[p * 32 + i], y[p], s);
+            y[i] = s / L[i * 32 + i];
+        }
+        return;
+    }
+    double M[32 * 33];
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) M[i * 33 + j] = a2[i * 32 + j];
+        M[i * 33 + k] = b2[i];
+    }
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < k; ++i)
+            if (fabs(M[i * 33 + c]) > fabs(M[piv * 33 + c])) piv = i;
+        if (piv != c)
+            for (int j = 0; j <= k; ++j) {
+                const double tmp = M[c * 33 + j];
+                M[c * 33 + j] = M[piv * 33 + j];
+                M[piv * 33 + j] = tmp;
+            }
+        for (int i = c + 1; i < k; ++i) {
+            const double f = M[i * 33 + c] / M[c * 33 + c];
+            for (int j = c; j <= k; ++j) M[i * 33 + j] = fma(-f, M[c * 33 + j], M[i * 33 + j]);
+        }
+    }
+    for (int i = k - 1; i >= 0; --i) {
+        double s = M[i * 33 + k];
+        for (int p = i + 1; p < k; ++p) s = fma(-M[i * 33 + p], y[p], s);
+        y[i] = s / M[i * 33 + i];
+    }
+}
+
+static inline double hipk_tmin(double a, double b) {
+    if (isnan(a) || isnan(b)) return NAN;
+    return a < b ? a : b;
+}
+
+extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
+    const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
+    const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
+    const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM ? HIPK_GM_MAXM : restart);
+    return kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) + (size_t)(m + 2) * vec;
+}
+
+template <typename T>
+static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hipk_params *prm, hipk_stats *st,
+                              hipStream_t stream) {
+    const int64_t n = A->n_rows;
+    const hipk_geom gm = A->geom;
+    const int m = prm->restart;
+    const size_t vec = hipk_align_up((size_t)n * sizeof(T), 256);
+    const int64_t ldv = (int64_t)(vec / sizeof(T));
+    hipk_gm_scal *scal = (hipk_gm_scal *)work;
+    double *parts = (double *)(work + kGmHeader);
+    double *part_ww = parts, *part_qq = parts + HIPK_MAX_PARTS, *part_res = parts + 2 * HIPK_MAX_PARTS;
+    double *part_bb = parts + 3 * HIPK_MAX_PARTS, *part_xx = parts + 4 * HIPK_MAX_PARTS;
+    double *part_spare = parts + 5 * HIPK_MAX_PARTS;
+    double *part_md = parts + (size_t)kGmSlots * HIPK_MAX_PARTS;
+    char *vbase = work + kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double);
+    T *V = (T *)vbase;
+    T *tmp = (T *)(vbase + (size_t)(m + 1) * vec);
+    const int incremental = (prm->gmres_method == HIPK_GMRES_INCREMENTAL) ? 1 : 0;
+    const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;  // TSL:719-721
+
+    hipk_event_pair whole;
+    HIPK_CHECK_HIP(whole.create());
+    hipk_spmv_profiler prof(prm->profile != 0);
+    HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
+
+    hipk_spmv_args sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.crow = A->crow;
+    sa.col = A->col;
+    sa.val = A->val;
+    sa.n = n;
+    sa.ch = gm.ch;
+    sa.g = gm.g;
+    int rc;
+    int64_t matvecs = 0;
+
+    // residual = b - A x0 into column 0, unit residual + norm (TSL:791-792); <b,b>
+    hipk_spmv_args sr = sa;
+    sr.x = x;
+    sr.y = V;
+    sr.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sr.bsub = b;
+    sr.part0 = part_spare;
+    sr.part1 = part_res;
+    if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
+    if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) return rc;
+    ++matvecs;
+    hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb);
+    HIPK_CHECK_HIP(hipGetLastError());
+    double head[2];
+    HIPK_CHECK_HIP(hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+    double res_norm = head[0];
+    const double bs = head[1];
+    const double b_norm = hipk_norm_from_sq(bs);
+
+    // TSL:735-753 (python floats become fp32 tensors; python max() keeps a float a float)
+    const double eps = (A->dtype == HIPK_F64) ? HIPK_EPS64 : HIPK_EPS64;  // fp32 extension keeps the fp64 floor
+    const double sq = sqrt((double)n);
+    const double cand = (prm->gpu_tolerances ? 1e-12 : 1e-14) * sq;
+    const double adaptive = (cand > prm->tol) ? cand : (double)(float)prm->tol;
+    const double base_atol = (double)(float)(eps * (prm->gpu_tolerances ? 1000 : 100) * (double)n);
+    const double atol_eff = hipk_tmax(adaptive * b_norm, hipk_tmax((double)(float)prm->atol, base_atol));
+    const double ptol = b_norm * hipk_tmin(1.0, atol_eff / b_norm);
+
+    hipk_gm_scal *hs = (hipk_gm_scal *)malloc(sizeof(hipk_gm_scal));
+    if (!hs) {
+        hipk_set_error("out of host memory");
+        return HIPK_ERR_ARG;
+    }
+    int64_t cycles = 0;
+    int happy = 0;
+    int64_t prof_valid = 0;
+    rc = HIPK_OK;
+    while (cycles < maxiter && res_norm > atol_eff) {
+        hipk_gm_cycle_init_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, incremental, ptol);
+        for (int k = 0; k < m; ++k) {
+            T *w = V + (int64_t)(k + 1) * ldv;
+            hipk_spmv_args sw = sa;
+            sw.x = V + (int64_t)k * ldv;
+            sw.y = w;
+            sw.mode = HIPK_SPMV_DOT_YY;
+            sw.part0 = part_spare;
+            sw.part1 = part_ww;
+            sw.stop_it = &scal->stop_step;
+            sw.it = k;
+            prof.before(stream);
+            if ((rc = hipk_launch_spmv(A, sw, stream)) != HIPK_OK) break;
+            prof.after(stream);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq);
+                hipk_gm_multidot_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                               part_md);
+                hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
+                hipk_gm_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_qq);
+            }
+            hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, k, w, part_qq,
+                                                                            part_ww);
+        }
+        if (rc != HIPK_OK) break;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            hipk_set_error("hipk_gmres_solve: HIP failure inside a restart cycle");
+            rc = HIPK_ERR_HIP;
+            break;
+        }
+        const int k = (int)hs->steps_done;
+        matvecs += k;
+        if (prof_valid == cycles * m) prof_valid += k;  // leading launches that did work
+        if (hs->breakdown) happy = 1;
+        hipk_gm_y yy;
+        memset(&yy, 0, sizeof(yy));
+        if (k > 0) {
+            if (!incremental) {
+                hipk_lstsq_normal(hs->H, HIPK_GM_LDH, k, res_norm, yy.y);
+            } else {
+                for (int i = k - 1; i >= 0; --i) {  // solve_triangular, TSL:630
+                    double s = hs->beta_vec[i];
+                    for (int p = i + 1; p < k; ++p) s = fma(-hs->R[i * HIPK_GM_LDH + p], yy.y[p], s);
+                    yy.y[i] = s / hs->R[i * HIPK_GM_LDH + i];
+                }
+            }
+            hipk_gm_xupdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, k, V, ldv, x, yy);
+        }
+        if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) break;
+        ++matvecs;
+        hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            hipk_set_error("hipk_gmres_solve: HIP failure at the end of a restart cycle");
+            rc = HIPK_ERR_HIP;
+            break;
+        }
+        res_norm = head[0];
+        ++cycles;
+    }
+    free(hs);
+    if (rc != HIPK_OK) return rc;
+
+    // TSL:766-773
+    hipk_spmv_args sf = sr;
+    sf.y = tmp;
+    if ((rc = hipk_launch_spmv(A, sf, stream)) != HIPK_OK) return rc;
+    ++matvecs;
+    if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_xx, stream)) != HIPK_OK) return rc;
+    hipk_gm_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, gm.g, part_res, part_xx);
+    HIPK_CHECK_HIP(hipGetLastError());
+    double fin[4];
+    HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
+    HIPK_CHECK_HIP(hipMemcpyAsync(fin, scal, sizeof(fin), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+    st->iterations = cycles;
+    st->matvecs = matvecs;
+    st->b_norm = b_norm;
+    st->residual_norm = hipk_norm_from_sq(fin[2]);
+    st->x_norm = hipk_norm_from_sq(fin[3]);
+    st->threshold = atol_eff * 10;  // TSL:769
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+    st->breakdown = happy;
+    st->recurrence_rs = res_norm;
+    float ms = 0.f;
+    HIPK_CHECK_HIP(hipEventElapsedTime(&ms, whole.a, whole.b));
+    st->solve_ms = ms;
+    HIPK_CHECK_HIP(prof.collect(st, prof_valid));
+    return HIPK_OK;
+}
+
+extern "C" int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
+                                const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
+                 "Unsupported solve_method");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
+                 "b/x must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_gmres_work_bytes(A->n_rows, prm->restart, A->dtype), HIPK_ERR_WORKSPACE,
+                 "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_gmres_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st, (hipStream_t)stream);
+    return hipk_gmres_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+}

@@ -129,6 +129,8 @@ struct hipk_poller {
     }
 };
 
+static inline size_t hipk_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 // torch.maximum semantics (NaN wins).
 static inline double hipk_tmax(double a, double b) {
     if (isnan(a) || isnan(b)) return NAN;
