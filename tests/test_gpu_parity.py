@@ -146,3 +146,37 @@ def test_cg_n4m_headline_properties(hipk):
     assert torch.allclose(lhs, rhs, rtol=1e-12, atol=1e-12)
     # and against torch's own CSR matmul (the reference's SpMV, TSL:191)
     assert torch.allclose(hipk.spmv(h, u), torch.matmul(A, u), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("r", golden_runs("bicgstab"), ids=run_id)
+def test_bicgstab_bit_exact_vs_oracle(hipk, oracle, r):
+    d = load_case(r["case"])
+    x, info, st = _solve_gpu("bicgstab", d, r)
+    ref = oracle.bicgstab(d["crow"], d["col"], d["val"], d["b"], x0=d["x0"] if r["has_x0"] else None, **r["kwargs"])
+    assert np.array_equal(x, ref.x)                                   # bit-exact vs the oracle
+    assert (info, st.iterations, st.matvecs, st.breakdown) == (ref.info, ref.iterations, ref.matvecs, ref.breakdown)
+    assert st.residual_norm == ref.residual_norm
+    # vs the reference itself: BiCGStab is trajectory-chaotic, so a band (conftest.py)
+    assert abs(st.matvecs - r["matvecs"]) <= max(2, BICGSTAB_MATVEC_BAND * r["matvecs"])
+    tol = r["kwargs"].get("tol", 1e-5)
+    assert info == r["info"] or st.residual_norm <= 50 * tol * st.b_norm
+
+
+@pytest.mark.parametrize("r", golden_runs("gmres"), ids=run_id)
+def test_gmres_vs_oracle_and_reference(hipk, oracle, r):
+    d = load_case(r["case"])
+    x, info, st = _solve_gpu("gmres", d, r)
+    kw = dict(r["kwargs"])
+    # the GPU run takes the `device.type == 'cuda'` tolerance branch (TSL:737-740); so must the oracle
+    ref = oracle.gmres(d["crow"], d["col"], d["val"], d["b"], x0=d["x0"] if r["has_x0"] else None,
+                       gpu_tolerances=True, **kw)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert np.linalg.norm(x - ref.x) <= 1e-9 * np.linalg.norm(ref.x)
+    assert np.array_equal(x, ref.x), "GMRES on the GPU is expected to be bit-identical to the oracle"
+    # vs the reference fixture (generated on CPU => CPU tolerance branch): identical verdict; the cycle count can
+    # only differ where the GPU branch's larger floor (eps*1000*n vs eps*100*n) stops a cycle earlier
+    assert info == r["info"]
+    assert st.matvecs <= r["matvecs"]
+    x_ref = d[r["tag"] + "_x"]
+    tol = kw.get("tol", 1e-5)
+    assert np.linalg.norm(x - x_ref) <= max(1e-8, 50 * tol) * np.linalg.norm(x_ref)
