@@ -146,6 +146,42 @@ size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype);
 int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
                      const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
+/* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
+ * The reference is single-device; the row-partitioned solver (north_star) drives the
+ * SAME fused kernels from the host side of each rank and exchanges (a) the x-vector
+ * halo and (b) the chunk partial sums between launches.  Rows are partitioned on
+ * reduction-chunk boundaries of the GLOBAL problem, so every rank reduces the
+ * all-gathered partials in the same fixed order: results are bitwise identical to the
+ * single-GPU solve for any rank count.
+ *   chunk_rows : chunk size of the GLOBAL row count (hipk_chunk_size(n_global))
+ *   g_red      : number of partials of ALL ranks (hipk_chunk_count(n_global))
+ * Kernels index partial OUTPUTS by local chunk and read partial INPUTS from the
+ * gathered (global) arrays. */
+int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                       const void *crow_dev, const void *col_dev, int idx_bytes,
+                       const void *val_dev, int dtype, int chunk_rows, hipk_stream_t stream);
+/* mode bits: 1 part0[c] = <w, out>; 2 part1[c] = <out, out>; 4 out = bsub - A x */
+int hipk_spmv_ex(hipk_csr_t h, const void *x, void *y, int mode, const void *w, const void *bsub,
+                 double *part0, double *part1, const int64_t *stop_dev, int64_t it,
+                 hipk_stream_t stream);
+int hipk_dot_parts(int64_t n, int chunk_rows, const void *x, const void *y, int dtype,
+                   double *part, hipk_stream_t stream);
+/* out_dev[0] = fixed-order sum of part[0..g)  (the second level of every dot) */
+int hipk_reduce_parts(const double *part_dev, int g, double *out_dev, hipk_stream_t stream);
+/* dst[i] = src[idx[i]], i < m  (halo pack) */
+int hipk_gather(int64_t m, const int32_t *idx_dev, const void *src, void *dst, int dtype,
+                hipk_stream_t stream);
+size_t hipk_cg_scal_bytes(void); /* device scalar block: {gamma[2], atol2, bs, res2, xx, stop_it(int64), pad} */
+int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rr,
+                  const double *part_bb, const void *r, void *p, int dtype, double tol, double atol,
+                  int64_t maxiter, hipk_stream_t stream);
+int hipk_cg_update(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
+                   const double *part_pAp, const void *p, const void *Ap, void *x, void *r,
+                   double *part_rr_out, int dtype, hipk_stream_t stream);
+int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it,
+                      int64_t maxiter, const double *part_rr, const void *r, void *p, int dtype,
+                      hipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,11 @@
  *     thread" t of 256 owns elements {2t,2t+1} + 512 j and accumulates with fma in
  *     ascending order; 256 accumulators are folded by v[t] += v[t+s], s = 128..1;
  *     chunk partials are folded the same way (thread t takes partials t, t+256, ..).
+ *   - "tiled dot" (every dot FUSED into an SpMV epilogue: <p,Ap>, <rhat,q>, <t,s>, <t,t>,
+ *     ||A v||^2, ||b - A x||^2): rows are cut in tiles of 256; thread t of a tile forms the
+ *     rounded product a_i*b_i of row t (0 beyond n); the 256 products are folded by the
+ *     same tree into a TILE partial; the tile partials of a chunk are folded like chunk
+ *     partials (thread t takes t, t+256, .. then the tree) into the chunk partial.
  *   - SpMV row: products rounded, then added in CSR order (rows <= 32 entries);
  *     longer rows: 64 strided lane sums folded by v[l] += v[l+s], s = 32..1.
  *   - element-wise updates: multiply, round, add, round (as `_add(x, _mul(a, p))`).
@@ -119,6 +124,17 @@ void orc_dot_parts(int64_t n, const double *a, const double *b, double *parts) {
     }
 }
 
+/* same with an explicit chunk size: the partials a rank of the row-partitioned solver owns */
+void orc_dot_parts_ch(int64_t n, int ch, const double *a, const double *b, double *parts) {
+    const int g = (int)((n + ch - 1) / ch);
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int c = 0; c < g; ++c) {
+        const int64_t base = (int64_t)c * ch;
+        const int64_t end = base + ch < n ? base + ch : n;
+        parts[c] = (base < end) ? chunk_dot(a, b, base, end) : 0.0;
+    }
+}
+
 double orc_reduce_parts(const double *parts, int g) { return reduce_parts(parts, g); }
 
 /* `_vdot_real_tree` (TSL:130-139) */
@@ -127,6 +143,36 @@ double orc_dot(int64_t n, const double *a, const double *b) {
     orc_chunk_geom(n, &ch, &g);
     double *parts = (double *)malloc(sizeof(double) * (size_t)g);
     orc_dot_parts(n, a, b, parts);
+    const double r = reduce_parts(parts, g);
+    free(parts);
+    return r;
+}
+
+/* chunk partials of the tiled dot (what hipk_spmv_kernel + hipk_tile_combine_kernel produce) */
+void orc_dot_tiled_parts_ch(int64_t n, int ch, const double *a, const double *b, double *parts) {
+    const int g = (int)((n + ch - 1) / ch);
+    const int tpc = ch / 256;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int c = 0; c < g; ++c) {
+        double tp[ORC_MAX_PARTS];
+        const int64_t base = (int64_t)c * ch;
+        const int64_t end = base + ch < n ? base + ch : n;
+        int nt = 0;
+        for (int64_t t0 = base; t0 < end; t0 += 256, ++nt) {
+            double v[ORC_THREADS];
+            for (int t = 0; t < 256; ++t) v[t] = (t0 + t < end) ? a[t0 + t] * b[t0 + t] : 0.0;
+            tp[nt] = tree256(v);
+        }
+        (void)tpc;
+        parts[c] = reduce_parts(tp, nt);
+    }
+}
+
+double orc_dot_tiled(int64_t n, const double *a, const double *b) {
+    int ch, g;
+    orc_chunk_geom(n, &ch, &g);
+    double *parts = (double *)malloc(sizeof(double) * (size_t)g);
+    orc_dot_tiled_parts_ch(n, ch, a, b, parts);
     const double r = reduce_parts(parts, g);
     free(parts);
     return r;
@@ -188,7 +234,7 @@ static void isolve_epilogue(const csr_t *A, const double *b, const double *x, do
                             double bs, double *tmp, orc_stats *st) {
     /* TSL:1007-1016 */
     orc_spmv(A->n, A->crow, A->col, A->val, x, b, tmp);
-    st->residual_norm = norm_from_sq(orc_dot(A->n, tmp, tmp));
+    st->residual_norm = norm_from_sq(orc_dot_tiled(A->n, tmp, tmp)); /* fused in the SpMV */
     st->b_norm = norm_from_sq(bs);
     st->x_norm = norm_from_sq(orc_dot(A->n, x, x));
     st->threshold = tmax((double)(float)tol * st->b_norm, (double)(float)atol);
@@ -210,13 +256,13 @@ int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val
     const double atol2 = a2 > a3 ? a2 : a3;
     orc_spmv(n, crow, col, val, x, b, r);
     int64_t matvecs = 1;
-    double gamma = orc_dot(n, r, r);
+    double gamma = orc_dot_tiled(n, r, r); /* fused in the residual SpMV */
     memcpy(p, r, sizeof(double) * (size_t)n);
     int64_t k = 0;
     while (!(k >= maxiter || gamma <= atol2)) {
         orc_spmv(n, crow, col, val, p, NULL, Ap);
         ++matvecs;
-        const double pAp = orc_dot(n, p, Ap);
+        const double pAp = orc_dot_tiled(n, p, Ap); /* fused in the SpMV */
         const double alpha = gamma / pAp;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
@@ -266,10 +312,13 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
     double alpha = 1.0, omega = 1.0, rho = 1.0, rs = 0.0;
     int64_t k = 0;
     int code = 0;
+    /* <r,r> and <rhat,r> of the NEXT iteration are produced by the x/r update kernel (plain dot spec);
+       those of iteration 0 come fused out of the initial residual SpMV (tiled spec), rhat = r0 */
+    double rs_next = orc_dot_tiled(n, r, r), rho_next = rs_next;
     while (k < maxiter) {
-        rs = orc_dot(n, r, r);
+        rs = rs_next;
         if (rs <= atol2) break;
-        const double rho_new = orc_dot(n, rhat, r);
+        const double rho_new = rho_next;
         if (fabs(rho_new) < ORC_EPS * fabs(rho)) {
             code = -10;
             break;
@@ -284,7 +333,7 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
         }
         orc_spmv(n, crow, col, val, p, NULL, q);
         ++matvecs;
-        const double alpha_new = rho_new / orc_dot(n, rhat, q);
+        const double alpha_new = rho_new / orc_dot_tiled(n, rhat, q);
         if (fabs(alpha_new) < ORC_EPS) {
             code = -11;
             break;
@@ -297,12 +346,12 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
         const int exit_early = orc_dot(n, s, s) < atol2;
         orc_spmv(n, crow, col, val, s, NULL, t);
         ++matvecs;
-        const double tt = orc_dot(n, t, t);
+        const double tt = orc_dot_tiled(n, t, t);
         double omega_new;
         if (fabs(tt) < ORC_EPS)
             omega_new = 0.0;
         else
-            omega_new = orc_dot(n, t, s) / tt;
+            omega_new = orc_dot_tiled(n, s, t) / tt;
         if (fabs(omega_new) < ORC_EPS && !exit_early) {
             code = -11;
             break;
@@ -321,6 +370,8 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
                 r[i] = s[i] - m3;
             }
         }
+        rs_next = orc_dot(n, r, r);
+        rho_next = orc_dot(n, rhat, r);
         rho = rho_new;
         alpha = alpha_new;
         omega = omega_new;
@@ -461,7 +512,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
     double *res = V; /* residual lives in column 0 */
     orc_spmv(n, crow, col, val, x, b, res);
     int64_t matvecs = 1;
-    double res_norm = norm_from_sq(orc_dot(n, res, res));
+    double res_norm = norm_from_sq(orc_dot_tiled(n, res, res));
     {
         const int use = res_norm > ORC_EPS;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
@@ -484,7 +535,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
             double *w = V + (size_t)(k + 1) * n;
             orc_spmv(n, crow, col, val, V + (size_t)k * n, NULL, w);
             ++matvecs;
-            double norm0 = norm_from_sq(orc_dot(n, w, w));
+            double norm0 = norm_from_sq(orc_dot_tiled(n, w, w)); /* fused in the SpMV */
             if (!(norm0 > ORC_EPS)) norm0 = 0.0;
             /* CGS, <= 2 passes (TSL:284-328) */
             for (int j = 0; j <= k; ++j) rvec[j] = 0.0;
@@ -562,7 +613,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
         }
         orc_spmv(n, crow, col, val, x, b, res);
         ++matvecs;
-        res_norm = norm_from_sq(orc_dot(n, res, res));
+        res_norm = norm_from_sq(orc_dot_tiled(n, res, res));
         {
             const int use = res_norm > ORC_EPS;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
@@ -574,7 +625,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
     /* TSL:766-773 */
     orc_spmv(n, crow, col, val, x, b, tmp);
     ++matvecs;
-    st->residual_norm = norm_from_sq(orc_dot(n, tmp, tmp));
+    st->residual_norm = norm_from_sq(orc_dot_tiled(n, tmp, tmp));
     st->x_norm = norm_from_sq(orc_dot(n, x, x));
     st->b_norm = b_norm;
     st->threshold = atol_eff * 10;

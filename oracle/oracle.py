@@ -71,6 +71,10 @@ def lib():
         L.orc_dot.argtypes = [i64, dp, dp]
         L.orc_dot.restype = ctypes.c_double
         L.orc_dot_parts.argtypes = [i64, dp, dp, dp]
+        L.orc_dot_parts_ch.argtypes = [i64, ctypes.c_int, dp, dp, dp]
+        L.orc_dot_tiled_parts_ch.argtypes = [i64, ctypes.c_int, dp, dp, dp]
+        L.orc_dot_tiled.argtypes = [i64, dp, dp]
+        L.orc_dot_tiled.restype = ctypes.c_double
         L.orc_reduce_parts.argtypes = [dp, ctypes.c_int]
         L.orc_reduce_parts.restype = ctypes.c_double
         L.orc_spmv.argtypes = [i64, ip, ip, dp, dp, dp, dp]
@@ -120,6 +124,34 @@ def dot_parts(a, b) -> np.ndarray:
     _, g = chunk_geom(a.size)
     parts = np.zeros(g, dtype=np.float64)
     lib().orc_dot_parts(a.size, _d(a), _d(b), _d(parts))
+    return parts
+
+
+def dot_parts_ch(a, b, ch: int) -> np.ndarray:
+    """Chunk partials of <a,b> with an explicit chunk size (a row block of a partitioned vector)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    g = (a.size + ch - 1) // ch
+    parts = np.zeros(max(g, 0), dtype=np.float64)
+    if a.size:
+        lib().orc_dot_parts_ch(a.size, int(ch), _d(a), _d(b), _d(parts))
+    return parts
+
+
+def dot_tiled(a, b) -> float:
+    """The dot an SpMV epilogue produces ("tiled dot" spec, krylov_oracle.c header)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return float(lib().orc_dot_tiled(a.size, _d(a), _d(b)))
+
+
+def dot_tiled_parts_ch(a, b, ch: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    g = (a.size + ch - 1) // ch
+    parts = np.zeros(max(g, 0), dtype=np.float64)
+    if a.size:
+        lib().orc_dot_tiled_parts_ch(a.size, int(ch), _d(a), _d(b), _d(parts))
     return parts
 
 

@@ -62,7 +62,19 @@ __global__ void hipk_narrow_check_kernel(const I *__restrict__ crow_in, const I 
 extern "C" int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                                const void *crow_dev, const void *col_dev, int idx_bytes,
                                const void *val_dev, int dtype, hipk_stream_t stream_) {
+    return hipk_csr_create_ex(out, n_rows, n_cols, nnz, crow_dev, col_dev, idx_bytes, val_dev, dtype, 0, stream_);
+}
+
+extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                  const void *crow_dev, const void *col_dev, int idx_bytes,
+                                  const void *val_dev, int dtype, int chunk_rows, hipk_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (chunk_rows != 0) {
+        bool ok = chunk_rows >= HIPK_BASE_CHUNK && (chunk_rows % HIPK_BASE_CHUNK) == 0;
+        const int q = ok ? chunk_rows / HIPK_BASE_CHUNK : 0;
+        ok = ok && (q & (q - 1)) == 0 && (n_rows + chunk_rows - 1) / chunk_rows <= HIPK_MAX_PARTS;
+        HIPK_REQUIRE(ok, HIPK_ERR_ARG, "chunk_rows must be 2048*2^k and give at most 2048 chunks");
+    }
     HIPK_REQUIRE(out != nullptr, HIPK_ERR_ARG, "out is null");
     *out = nullptr;
     HIPK_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, HIPK_ERR_ARG, "negative size");
@@ -82,12 +94,18 @@ extern "C" int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, 
     h->dtype = dtype;
     h->val = val_dev;
     h->geom = hipk_make_geom(n_rows);
+    if (chunk_rows != 0) {  // row block of a larger problem: use the GLOBAL chunk size
+        h->geom.ch = chunk_rows;
+        h->geom.g = (int)((n_rows + chunk_rows - 1) / chunk_rows);
+        if (h->geom.g < 1) h->geom.g = 1;
+    }
     int *bad = nullptr;
     int bad_h = 0;
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess) e = hipMalloc((void **)&h->crow, sizeof(int) * (size_t)(n_rows + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
     if (e == hipSuccess) e = hipMalloc((void **)&bad, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tile_part, sizeof(double) * 2 * (size_t)((n_rows + 255) / 256 + 1));
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_poll, 16 * sizeof(int64_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
     if (e == hipSuccess) {
@@ -124,6 +142,7 @@ extern "C" int hipk_csr_destroy(hipk_csr_t h) {
     if (!h) return HIPK_OK;
     if (h->crow) (void)hipFree(h->crow);
     if (h->col) (void)hipFree(h->col);
+    if (h->tile_part) (void)hipFree(h->tile_part);
     if (h->host_poll) (void)hipHostFree(h->host_poll);
     delete h;
     return HIPK_OK;
@@ -138,14 +157,23 @@ extern "C" int64_t hipk_csr_spmv_bytes(hipk_csr_t h) {
 }
 
 // ------------------------------------------------------------------ SpMV launch
-// CAP (LDS product slots per group): 1280 = 256 rows x 5 nnz, the 5-point stencil's
-// natural group, and it keeps the workgroup at 16 KB LDS => 8 workgroups per CU.
-int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a, hipStream_t stream) {
-    const int grid = hipk_xcd_grid(a.g);
+// CAP (LDS product slots per tile): 1280 = 256 rows x 5 nnz, the 5-point stencil's tile, and it keeps the
+// workgroup at 11 KB LDS => 8 workgroups per CU.  Denser tiles take the kernel's general path.
+int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t stream) {
+    hipk_spmv_args a = a_;
+    const int ntiles = (int)((a.n + 255) / 256);
+    const int grid = ((ntiles + 7) >> 3) << 3;
+    a.tpart0 = h->tile_part;
+    a.tpart1 = h->tile_part + ntiles;
     if (h->dtype == HIPK_F64)
         hipk_spmv_kernel<double, 1280><<<grid, HIPK_THREADS, 0, stream>>>(a);
     else
         hipk_spmv_kernel<float, 2048><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+        hipk_tile_combine_kernel<<<a.g, HIPK_THREADS, 0, stream>>>(
+            (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+            a.part1, ntiles, a.ch / 256, a.stop_it, a.it);
+    }
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;
 }
@@ -190,4 +218,28 @@ extern "C" int hipk_spmv_dot(hipk_csr_t h, const void *x, void *y, const void *w
         if (rc != HIPK_OK) return rc;
     }
     return hipk_launch_finish1(a.part0, h->n_rows > 0 ? a.g : 0, out_dev, stream);
+}
+
+extern "C" int hipk_spmv_ex(hipk_csr_t h, const void *x, void *y, int mode, const void *w, const void *bsub,
+                            double *part0, double *part1, const int64_t *stop_dev, int64_t it,
+                            hipk_stream_t stream) {
+    HIPK_REQUIRE(h && x && y, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE((mode & ~7) == 0, HIPK_ERR_ARG, "unknown mode bits");
+    HIPK_REQUIRE(!(mode & HIPK_SPMV_DOT_W) || (w && part0), HIPK_ERR_ARG, "mode 1 needs w and part0");
+    HIPK_REQUIRE(!(mode & HIPK_SPMV_DOT_YY) || part1, HIPK_ERR_ARG, "mode 2 needs part1");
+    HIPK_REQUIRE(!(mode & HIPK_SPMV_RESID) || bsub, HIPK_ERR_ARG, "mode 4 needs bsub");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y) && hipk_aligned16(w) && hipk_aligned16(bsub), HIPK_ERR_ALIGN,
+                 "vectors must be 16-byte aligned");
+    HIPK_REQUIRE(x != y && w != y && bsub != y, HIPK_ERR_ARG, "y must not alias an input");
+    if (h->n_rows == 0) return HIPK_OK;
+    hipk_spmv_args a;
+    hipk_fill_spmv_args(h, a, x, y);
+    a.mode = mode;
+    a.w = w;
+    a.bsub = bsub;
+    a.part0 = part0;
+    a.part1 = part1;
+    a.stop_it = stop_dev;
+    a.it = it;
+    return hipk_launch_spmv(h, a, (hipStream_t)stream);
 }

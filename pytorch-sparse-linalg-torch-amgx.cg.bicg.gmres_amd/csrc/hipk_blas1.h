@@ -55,3 +55,6 @@ int hipk_launch_finish1(const double *part, int g, double *out_dev, hipStream_t 
 // part[c] = chunk partial of <x,y>
 int hipk_launch_dot_parts(int64_t n, const void *x, const void *y, int dtype, double *part,
                           hipStream_t stream);
+// same with an explicit chunk size (row block of a larger, partitioned vector)
+int hipk_launch_dot_parts_ch(int64_t n, int ch, const void *x, const void *y, int dtype, double *part,
+                             hipStream_t stream);

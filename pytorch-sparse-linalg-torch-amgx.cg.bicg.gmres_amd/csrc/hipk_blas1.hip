@@ -61,7 +61,15 @@ int hipk_launch_finish1(const double *part, int g, double *out_dev, hipStream_t 
 
 int hipk_launch_dot_parts(int64_t n, const void *x, const void *y, int dtype, double *part,
                           hipStream_t stream) {
-    const hipk_geom gm = hipk_make_geom(n);
+    return hipk_launch_dot_parts_ch(n, hipk_make_geom(n).ch, x, y, dtype, part, stream);
+}
+
+int hipk_launch_dot_parts_ch(int64_t n, int ch, const void *x, const void *y, int dtype, double *part,
+                             hipStream_t stream) {
+    hipk_geom gm;
+    gm.n = n;
+    gm.ch = ch;
+    gm.g = (int)((n + ch - 1) / ch);
     if (n <= 0) return HIPK_OK;
     if (dtype == HIPK_F64)
         hipk_dot_kernel<double><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, (const double *)x,
@@ -110,4 +118,43 @@ extern "C" int hipk_axpy(int64_t n, double a, const void *x, void *y, int dtype,
 }
 extern "C" int hipk_xpby(int64_t n, const void *x, double b, void *y, int dtype, hipk_stream_t stream) {
     return hipk_axpy_like(1, n, b, x, y, dtype, (hipStream_t)stream);
+}
+
+extern "C" int hipk_dot_parts(int64_t n, int chunk_rows, const void *x, const void *y, int dtype, double *part,
+                              hipk_stream_t stream) {
+    HIPK_REQUIRE(n >= 0 && x && y && part, HIPK_ERR_ARG, "bad argument");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    HIPK_REQUIRE(chunk_rows >= HIPK_BASE_CHUNK && chunk_rows % HIPK_BASE_CHUNK == 0, HIPK_ERR_ARG, "chunk_rows");
+    HIPK_REQUIRE((n + chunk_rows - 1) / chunk_rows <= HIPK_MAX_PARTS, HIPK_ERR_ARG, "too many chunks");
+    HIPK_REQUIRE(hipk_aligned16(x) && hipk_aligned16(y), HIPK_ERR_ALIGN, "x/y must be 16-byte aligned");
+    return hipk_launch_dot_parts_ch(n, chunk_rows, x, y, dtype, part, (hipStream_t)stream);
+}
+
+template <typename T>
+__global__ void hipk_gather_kernel(int64_t m, const int *__restrict__ idx, const T *__restrict__ src,
+                                   T *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) dst[i] = src[idx[i]];
+}
+
+extern "C" int hipk_gather(int64_t m, const int32_t *idx_dev, const void *src, void *dst, int dtype,
+                           hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(m >= 0, HIPK_ERR_ARG, "negative size");
+    if (m == 0) return HIPK_OK;
+    HIPK_REQUIRE(idx_dev && src && dst, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    int grid = (int)((m + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (dtype == HIPK_F64)
+        hipk_gather_kernel<double><<<grid, 256, 0, stream>>>(m, idx_dev, (const double *)src, (double *)dst);
+    else
+        hipk_gather_kernel<float><<<grid, 256, 0, stream>>>(m, idx_dev, (const float *)src, (float *)dst);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_reduce_parts(const double *part_dev, int g, double *out_dev, hipk_stream_t stream) {
+    HIPK_REQUIRE(part_dev && out_dev && g >= 0 && g <= HIPK_MAX_PARTS, HIPK_ERR_ARG, "bad argument");
+    return hipk_launch_finish1(part_dev, g, out_dev, (hipStream_t)stream);
 }

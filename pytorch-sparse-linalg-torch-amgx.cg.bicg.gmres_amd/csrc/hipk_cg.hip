@@ -39,7 +39,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
     int64_t maxiter) {
     __shared__ double sbuf[2 * HIPK_THREADS];
     double gamma0, bs;
-    hipk_reduce_parts2(part_rr, part_bb, g, gamma0, bs, sbuf);
+    hipk_reduce_parts2(part_rr, part_bb, g, gamma0, bs, sbuf);  // g = partial count of ALL ranks
     const int c = blockIdx.x;
     hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
         T rv[hipk_vec<T>::VEC];
@@ -271,4 +271,80 @@ extern "C" int hipk_cg_solve(hipk_csr_t A, const void *b, void *x, void *work, s
     if (A->dtype == HIPK_F64)
         return hipk_cg_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st, (hipStream_t)stream);
     return hipk_cg_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ step API (include/hipk.h)
+extern "C" size_t hipk_cg_scal_bytes(void) { return sizeof(hipk_cg_scal); }
+
+static int hipk_step_check(int64_t n_local, int chunk_rows, int g_red, int dtype) {
+    HIPK_REQUIRE(n_local > 0, HIPK_ERR_ARG, "n_local must be positive");
+    HIPK_REQUIRE(chunk_rows >= HIPK_BASE_CHUNK && chunk_rows % HIPK_BASE_CHUNK == 0, HIPK_ERR_ARG, "chunk_rows");
+    HIPK_REQUIRE(g_red >= 1 && g_red <= HIPK_MAX_PARTS, HIPK_ERR_ARG, "g_red out of range");
+    HIPK_REQUIRE((n_local + chunk_rows - 1) / chunk_rows <= g_red, HIPK_ERR_ARG, "more local chunks than g_red");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rr,
+                             const double *part_bb, const void *r, void *p, int dtype, double tol, double atol,
+                             int64_t maxiter, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_rr && part_bb && r && p, HIPK_ERR_ARG, "null argument");
+    const float tolf = (float)tol, atolf = (float)atol;
+    const double tol2 = (double)(tolf * tolf), atol_sq = (double)(atolf * atolf);
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cg_start_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev,
+                                                                         part_rr, part_bb, (const double *)r, (double *)p,
+                                                                         tol2, atol_sq, maxiter);
+    else
+        hipk_cg_start_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev,
+                                                                        part_rr, part_bb, (const float *)r, (float *)p, tol2,
+                                                                        atol_sq, maxiter);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cg_update(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
+                              const double *part_pAp, const void *p, const void *Ap, void *x, void *r,
+                              double *part_rr_out, int dtype, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_pAp && p && Ap && x && r && part_rr_out, HIPK_ERR_ARG, "null argument");
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cg_update_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
+                                                                          (const hipk_cg_scal *)scal_dev, it, part_pAp,
+                                                                          (const double *)p, (const double *)Ap, (double *)x,
+                                                                          (double *)r, part_rr_out);
+    else
+        hipk_cg_update_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
+                                                                         (const hipk_cg_scal *)scal_dev, it, part_pAp,
+                                                                         (const float *)p, (const float *)Ap, (float *)x,
+                                                                         (float *)r, part_rr_out);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it,
+                                 int64_t maxiter, const double *part_rr, const void *r, void *p, int dtype,
+                                 hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_rr && r && p, HIPK_ERR_ARG, "null argument");
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cg_direction_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
+                                                                             (hipk_cg_scal *)scal_dev, it, maxiter, part_rr,
+                                                                             (const double *)r, (double *)p);
+    else
+        hipk_cg_direction_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
+                                                                            (hipk_cg_scal *)scal_dev, it, maxiter, part_rr,
+                                                                            (const float *)r, (float *)p);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
 }

@@ -1,21 +1,25 @@
-// hipk_spmv.h -- CSR SpMV for gfx950, LDS-staged ("stream") with fused dots.
+// hipk_spmv.h -- CSR SpMV for gfx950: lean 256-row tiles, LDS-staged products, fused dots.
 //
 // Replaces `torch.matmul(A, v)` (TSL:191) and, fused, the dot that follows it in
 // every solver loop (TSL:846 <p,Ap>; TSL:910 <rhat,q>; TSL:926-930 <t,s>,<t,t>;
 // TSL:352 ||A v||) and the residual form b - A x (TSL:820, 875, 791, 1008).
 //
-// Work decomposition (one workgroup of 256 threads per reduction chunk):
-//   chunk  = CH rows (CH = 2048 * 2^k, <= 2048 chunks; hipk_common.h)
-//   tile   = 256*VEC rows of the chunk (512 fp64 / 1024 fp32): row pointers staged in LDS
-//   group  = a run of <= 256 rows of the tile whose nnz fit CAP LDS slots:
-//            col/val are read fully coalesced (lane i <-> nnz j0+i), x is gathered
-//            (L2 hits: XCD-aware chunk placement), the PRODUCTS go to LDS, then
-//            thread r sums row r's products from LDS in CSR order (rows longer
-//            than HIPK_LONG_ROW are summed by a whole wavefront, lanes strided)
-//   output = thread t writes rows {VEC*t..VEC*t+VEC-1} of the tile as one 16-byte store
-//            and accumulates the fused dots in exactly the order of the stand-alone
-//            dot kernel (reduction spec), so fused and unfused dots are bit-identical.
-// The kernel is HBM-bound: 12 B/nnz + 4 B/row of matrix, 8 B/row in, 8 B/row out (fp64).
+// One workgroup of 256 threads per TILE of 256 consecutive rows (matrix independent):
+//   * the tile's entries are read fully coalesced (lane i <-> entry j0+i): `col` with the
+//     default cache policy, `val` NON-TEMPORAL -- val is the one pure stream (160 MB at
+//     N=4M); keeping it out of the 256 MiB Infinity Cache lets x, y, crow and col
+//     (and, inside a solve, the Krylov vectors) stay resident there (profiles/: 65 -> 56 us);
+//   * x is gathered (L2/Infinity Cache hits: XCD-aware tile placement), the PRODUCTS go
+//     to LDS, thread t then sums row t's products from LDS in CSR order (rows longer than
+//     HIPK_LONG_ROW are summed by a whole wavefront, lanes strided, fixed tree);
+//   * thread t writes y[t] and forms w_t*y_t / y_t*y_t; the 256 values are folded with the
+//     spec tree into one TILE partial; a tiny second kernel folds the tile partials of each
+//     reduction chunk into the chunk partial the consumers expect ("tiled dot" spec, mirrored
+//     by oracle/krylov_oracle.c).  8 workgroups per CU are resident (11 KB LDS, ~40 VGPRs):
+//     latency is hidden by occupancy, not by a software pipeline (measured both, profiles/).
+//   * tiles with more than CAP entries take a general path: groups of rows whose entries fit
+//     CAP, one row longer than CAP streamed by a single wavefront.
+// The kernel is HBM/Infinity-Cache bound: 12 B/nnz + 4 B/row of matrix, 8 B/row in, 8 B/row out.
 #pragma once
 #include "hipk_common.h"
 
@@ -40,29 +44,40 @@ struct hipk_spmv_args {
     double *part1;
     const int64_t *stop_it;  // device word: kernels with it >= *stop_it do nothing (may be null)
     int64_t it;
+    double *tpart0;  // tile partials (handle-owned scratch), filled by the launcher
+    double *tpart1;
 };
 
 #ifdef __HIPCC__
-// rows of the chunk whose row pointers are staged in LDS at once ("super-tile")
-#define HIPK_SPMV_ST 2048
+#define HIPK_TILE 256
+
+template <typename T>
+__device__ __forceinline__ T hipk_ld_nt(const T *p) {
+    return __builtin_nontemporal_load(p);
+}
+
+// XCD-aware placement of tiles: workgroups b and b+8 share an XCD (round-robin dispatch), so XCD k
+// gets the k-th contiguous eighth of the tiles and the x lines a stencil re-reads hit in ITS L2.
+__device__ __forceinline__ int hipk_xcd_tile(int b, int ntiles) {
+    const int per = (ntiles + 7) >> 3;
+    const int c = (b & 7) * per + (b >> 3);
+    return (c < ntiles && (b >> 3) < per) ? c : -1;
+}
 
 template <typename T, int CAP>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args a) {
-    constexpr int VEC = hipk_vec<T>::VEC;
-    constexpr int SUB = HIPK_THREADS * VEC;
     constexpr int NI = CAP / HIPK_THREADS;
-    constexpr int ST = HIPK_SPMV_ST;
     static_assert(CAP % HIPK_THREADS == 0, "CAP must be a multiple of the workgroup size");
     static_assert(CAP * sizeof(T) >= 512 * sizeof(double), "prod[] doubles as reduction scratch");
-    static_assert(ST % SUB == 0, "super-tile must hold whole output tiles");
+    static_assert(HIPK_TILE == HIPK_THREADS, "one row per thread");
 
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
-    const int c = hipk_xcd_chunk(blockIdx.x, a.g);
-    if (c < 0) return;
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tile = hipk_xcd_tile(blockIdx.x, ntiles);
+    if (tile < 0) return;
 
     __shared__ __attribute__((aligned(16))) T prod[CAP];
-    __shared__ __attribute__((aligned(16))) T ytile[SUB];
-    __shared__ int crowL[ST + 1];
+    __shared__ int crowL[HIPK_TILE + 1];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -72,41 +87,19 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
     const T *__restrict__ val = (const T *)a.val;
     const T *__restrict__ x = (const T *)a.x;
     T *__restrict__ y = (T *)a.y;
-    const T *__restrict__ w = (const T *)a.w;
-    const T *__restrict__ bsub = (const T *)a.bsub;
     const int mode = a.mode;
 
-    const int64_t row0 = (int64_t)c * a.ch;
-    const int64_t row1 = (row0 + a.ch < a.n) ? row0 + a.ch : a.n;
-    double acc0 = 0.0, acc1 = 0.0;
+    const int64_t r0 = (int64_t)tile * HIPK_TILE;
+    const int nr = (int)((a.n - r0 < HIPK_TILE) ? (a.n - r0) : HIPK_TILE);
+    if (t < nr) crowL[t] = crow[r0 + t];
+    if (t == 0) crowL[nr] = crow[r0 + nr];  // nr can be 256: one more pointer than threads
+    __syncthreads();
+    const int j0 = crowL[0];
+    const int cnt = crowL[nr] - j0;
+    T yrow = (T)0;  // row t of the tile
 
-    // group end: largest re in (ra, lim] with at most CAP entries; re == ra <=> row ra alone exceeds CAP
-    auto find_group = [&](int ra, int lim) -> int {
-        const int j0 = crowL[ra];
-        int hi = (ra + HIPK_THREADS < lim) ? ra + HIPK_THREADS : lim;
-        if (crowL[hi] - j0 <= CAP) return hi;
-        int lo = ra;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (crowL[mid] - j0 <= CAP) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-
-    for (int64_t st0 = row0; st0 < row1; st0 += ST) {
-        const int nst = (int)((row1 - st0 < ST) ? (row1 - st0) : ST);
-        __syncthreads();  // previous super-tile fully consumed before crowL is overwritten
-        for (int i = t; i <= nst; i += HIPK_THREADS) crowL[i] = crow[st0 + i];
-        __syncthreads();
-
-        // ---- software pipeline over groups: col/val of group g+1 are in flight while
-        // group g gathers x, multiplies, and is reduced from LDS.
-        int tile0 = 0;                                  // first row of the current output tile
-        int tile1 = (SUB < nst) ? SUB : nst;            // end of the current output tile
-        int ra = 0;
-        int re = find_group(ra, tile1);
-        int j0 = crowL[ra];
-        int cnt = (re > ra) ? crowL[re] - j0 : 0;
+    if (cnt <= CAP) {
+        // ---------------- fast path: the whole tile in one shot
         int cc[NI];
         T vv[NI];
 #pragma unroll
@@ -114,68 +107,94 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
             const int j = t + i * HIPK_THREADS;
             if (j < cnt) {
                 cc[i] = col[j0 + j];
-                vv[i] = val[j0 + j];
+                vv[i] = hipk_ld_nt(val + j0 + j);
             }
         }
-        while (true) {
-            // -- bounds of the next group (may open the next output tile)
-            const int ra2 = (re > ra) ? re : ra + 1;
-            const bool tile_done = (ra2 >= tile1);
-            const bool has_next = (ra2 < nst);
-            int tile1n = tile1;
-            if (tile_done) tile1n = (tile1 + SUB < nst) ? tile1 + SUB : nst;
-            int re2 = ra2, j02 = 0, cnt2 = 0;
-            if (has_next) {
-                re2 = find_group(ra2, tile1n);
-                j02 = crowL[ra2];
-                cnt2 = (re2 > ra2) ? crowL[re2] - j02 : 0;
-            }
-            // -- gather x for the current group, then put the next group's loads in flight
-            T xv[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int j = t + i * HIPK_THREADS;
-                if (j < cnt) xv[i] = x[cc[i]];
+        for (int i = 0; i < NI; ++i) {
+            const int j = t + i * HIPK_THREADS;
+            if (j < cnt) prod[j] = vv[i] * x[cc[i]];
+        }
+        __syncthreads();
+        int is_long = 0;
+        if (t < nr) {
+            const int lo = crowL[t] - j0;
+            const int len = crowL[t + 1] - j0 - lo;
+            if (len <= HIPK_LONG_ROW) {
+                T s = (T)0;
+                for (int j = 0; j < len; ++j) s = s + prod[lo + j];
+                yrow = s;
+            } else {
+                is_long = 1;
             }
-            int cc2[NI];
-            T vv2[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int j = t + i * HIPK_THREADS;
-                if (j < cnt2) {
-                    cc2[i] = col[j02 + j];
-                    vv2[i] = val[j02 + j];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int j = t + i * HIPK_THREADS;
-                if (j < cnt) prod[j] = vv[i] * xv[i];
-            }
-            if (re == ra) {
-                // one row with more than CAP entries: a single wavefront streams it from global
-                // memory, lanes strided by 64, same summation tree as a long LDS row
-                if (wave == 0) {
-                    const int j1 = crowL[ra + 1];
+        }
+        if (__syncthreads_or(is_long)) {
+            // long rows: one wavefront per row, lanes strided by 64, fixed tree; result handed to thread r via LDS
+            __shared__ T ylong[HIPK_TILE];
+            for (int r = wave; r < nr; r += HIPK_THREADS / 64) {
+                const int lo = crowL[r] - j0;
+                const int hi = crowL[r + 1] - j0;
+                if (hi - lo > HIPK_LONG_ROW) {
                     T s = (T)0;
-                    for (int j = j0 + lane; j < j1; j += 64) s = s + val[j] * x[col[j]];
+                    for (int j = lo + lane; j < hi; j += 64) s = s + prod[j];
 #pragma unroll
                     for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
-                    if (lane == 0) ytile[ra - tile0] = s;
+                    if (lane == 0) ylong[r] = s;
                 }
             }
             __syncthreads();
-
+            if (is_long) yrow = ylong[t];
+        }
+    } else {
+        // ---------------- general path: groups of rows whose entries fit CAP
+        __shared__ T ystage[HIPK_TILE];
+        int ra = 0;
+        while (ra < nr) {
+            const int g0 = crowL[ra];
+            int hi = nr;
+            int re;
+            if (crowL[hi] - g0 <= CAP) {
+                re = hi;
+            } else {
+                int lo = ra;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (crowL[mid] - g0 <= CAP) lo = mid; else hi = mid;
+                }
+                re = lo;
+            }
+            if (re == ra) {
+                // one row with more than CAP entries: a single wavefront streams it from memory,
+                // lanes strided by 64, same summation tree as a long LDS row
+                if (wave == 0) {
+                    const int g1 = crowL[ra + 1];
+                    T s = (T)0;
+                    for (int j = g0 + lane; j < g1; j += 64) s = s + hipk_ld_nt(val + j) * x[col[j]];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
+                    if (lane == 0) ystage[ra] = s;
+                }
+                __syncthreads();
+                ra += 1;
+                continue;
+            }
+            const int gcnt = crowL[re] - g0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = t + i * HIPK_THREADS;
+                if (j < gcnt) prod[j] = hipk_ld_nt(val + g0 + j) * x[col[g0 + j]];
+            }
+            __syncthreads();
             int is_long = 0;
             {
                 const int r = ra + t;
                 if (r < re) {
-                    const int lo = crowL[r] - j0;
-                    const int len = crowL[r + 1] - j0 - lo;
+                    const int lo = crowL[r] - g0;
+                    const int len = crowL[r + 1] - g0 - lo;
                     if (len <= HIPK_LONG_ROW) {
                         T s = (T)0;
                         for (int j = 0; j < len; ++j) s = s + prod[lo + j];
-                        ytile[r - tile0] = s;
+                        ystage[r] = s;
                     } else {
                         is_long = 1;
                     }
@@ -183,79 +202,62 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
             }
             if (__syncthreads_or(is_long)) {
                 for (int r = ra + wave; r < re; r += HIPK_THREADS / 64) {
-                    const int lo = crowL[r] - j0;
-                    const int hi2 = crowL[r + 1] - j0;
+                    const int lo = crowL[r] - g0;
+                    const int hi2 = crowL[r + 1] - g0;
                     if (hi2 - lo > HIPK_LONG_ROW) {
                         T s = (T)0;
                         for (int j = lo + lane; j < hi2; j += 64) s = s + prod[j];
 #pragma unroll
                         for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
-                        if (lane == 0) ytile[r - tile0] = s;
+                        if (lane == 0) ystage[r] = s;
                     }
                 }
                 __syncthreads();
             }
-
-            if (tile_done) {
-                // ---- output + fused dots, in reduction-spec order
-                const int ns = tile1 - tile0;
-                const int i0 = VEC * t;
-                if (i0 < ns) {
-                    const int64_t gi = st0 + tile0 + i0;
-                    T out[VEC];
-                    const int nv = (ns - i0 < VEC) ? ns - i0 : VEC;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) out[k] = (k < nv) ? ytile[i0 + k] : (T)0;
-                    if (mode & HIPK_SPMV_RESID) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            if (k < nv) out[k] = bsub[gi + k] - out[k];
-                    }
-                    if (nv == VEC) {
-                        typename hipk_vec<T>::type ov;
-                        T *op = (T *)&ov;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) op[k] = out[k];
-                        *(typename hipk_vec<T>::type *)(y + gi) = ov;
-                    } else {
-                        for (int k = 0; k < nv; ++k) y[gi + k] = out[k];
-                    }
-                    if (mode & HIPK_SPMV_DOT_W) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            if (k < nv) acc0 = fma((double)w[gi + k], (double)out[k], acc0);
-                    }
-                    if (mode & HIPK_SPMV_DOT_YY) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            if (k < nv) acc1 = fma((double)out[k], (double)out[k], acc1);
-                    }
-                }
-                tile0 = tile1;
-                tile1 = tile1n;
-                // the next group's ytile writes come after its own barrier, i.e. after every
-                // thread has finished reading ytile here.
-            }
-            if (!has_next) break;
-            ra = ra2;
-            re = re2;
-            j0 = j02;
-            cnt = cnt2;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                cc[i] = cc2[i];
-                vv[i] = vv2[i];
-            }
+            ra = re;
         }
+        if (t < nr) yrow = ystage[t];
     }
 
+    // ---------------- output + fused dots ("tiled dot": one value per row, spec tree per tile)
+    double d0 = 0.0, d1 = 0.0;
+    if (t < nr) {
+        T out = yrow;
+        if (mode & HIPK_SPMV_RESID) out = ((const T *)a.bsub)[r0 + t] - out;
+        y[r0 + t] = out;
+        if (mode & HIPK_SPMV_DOT_W) d0 = (double)((const T *)a.w)[r0 + t] * (double)out;
+        if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+    }
     if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
         __syncthreads();
-        hipk_block_sum2(acc0, acc1, (double *)prod);
+        hipk_block_sum2(d0, d1, (double *)prod);
         if (t == 0) {
-            if (mode & HIPK_SPMV_DOT_W) a.part0[c] = acc0;
-            if (mode & HIPK_SPMV_DOT_YY) a.part1[c] = acc1;
+            if (mode & HIPK_SPMV_DOT_W) a.tpart0[tile] = d0;
+            if (mode & HIPK_SPMV_DOT_YY) a.tpart1[tile] = d1;
         }
+    }
+}
+
+// chunk partial c = spec fold of the tile partials of chunk c (tiles_per_chunk = CH / 256)
+static __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_combine_kernel(const double *__restrict__ tp0,
+                                                                         const double *__restrict__ tp1,
+                                                                         double *__restrict__ part0,
+                                                                         double *__restrict__ part1, int ntiles,
+                                                                         int tiles_per_chunk,
+                                                                         const int64_t *__restrict__ stop_it,
+                                                                         int64_t it) {
+    if (stop_it != nullptr && it >= *stop_it) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const int c = blockIdx.x;
+    const int first = c * tiles_per_chunk;
+    const int cntt = (ntiles - first < tiles_per_chunk) ? ntiles - first : tiles_per_chunk;
+    if (tp0 != nullptr) {
+        const double r = hipk_reduce_parts(tp0 + first, cntt, sbuf);
+        if (threadIdx.x == 0) part0[c] = r;
+    }
+    if (tp1 != nullptr) {
+        const double r = hipk_reduce_parts(tp1 + first, cntt, sbuf);
+        if (threadIdx.x == 0) part1[c] = r;
     }
 }
 #endif

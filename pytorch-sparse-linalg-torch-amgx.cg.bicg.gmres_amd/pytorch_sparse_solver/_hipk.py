@@ -30,6 +30,9 @@ SYMBOLS = [
     "hipk_cg_work_bytes", "hipk_cg_solve",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
+    # step API (row-partitioned multi-GPU CG)
+    "hipk_csr_create_ex", "hipk_spmv_ex", "hipk_dot_parts", "hipk_reduce_parts", "hipk_gather",
+    "hipk_cg_scal_bytes", "hipk_cg_start", "hipk_cg_update", "hipk_cg_direction",
 ]
 
 
@@ -135,6 +138,16 @@ def lib():
     L.hipk_gmres_work_bytes.argtypes = [i64, i32, i32]
     L.hipk_gmres_work_bytes.restype = ctypes.c_size_t
     L.hipk_gmres_solve.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    dbl = ctypes.c_double
+    L.hipk_csr_create_ex.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, i32, vp]
+    L.hipk_spmv_ex.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.hipk_dot_parts.argtypes = [i64, i32, vp, vp, i32, vp, vp]
+    L.hipk_reduce_parts.argtypes = [vp, i32, vp, vp]
+    L.hipk_gather.argtypes = [i64, vp, vp, vp, i32, vp]
+    L.hipk_cg_scal_bytes.restype = ctypes.c_size_t
+    L.hipk_cg_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
+    L.hipk_cg_update.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, i32, vp]
     _lib = L
     return L
 

@@ -1,0 +1,312 @@
+"""Row-partitioned multi-GPU CG: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+
+New against the reference, which is single-process/single-device.  The
+solver is the SAME algorithm as `cg` (TSL:806-856 via `_isolve`, TSL:968-1016) and runs the
+SAME fused gfx950 kernels as the single-GPU path (include/hipk.h "step API"); between
+launches the ranks exchange only
+
+  * the x-vector HALO before each SpMV: the entries of p a rank's rows reference but do not
+    own (2 x ny doubles for the 5-point stencil), `all_to_all_single` of packed slabs --
+    never the full vector;
+  * the chunk PARTIAL SUMS of each dot (<= 2048 doubles in total): `all_gather_into_tensor`,
+    after which EVERY rank folds all partials in the same fixed order.  Rows are split on
+    reduction-chunk boundaries of the global problem, so the result is bitwise identical
+    to the single-GPU solve for any number of ranks (tests/test_distributed_gloo.py).
+
+The orchestration below is backend-agnostic (`ops` object): the product ships `HipOps`
+(libhipk.so on CUDA/ROCm tensors); the CPU test double lives in tests/ and is never
+imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+BASE_CHUNK = 2048
+MAX_PARTS = 2048
+MODE_DOT_W, MODE_DOT_YY, MODE_RESID = 1, 2, 4
+
+
+def chunk_geometry(n: int):
+    """(chunk size, chunk count) of an n-vector: hipk_make_geom (csrc/hipk_common.h) in Python."""
+    full = BASE_CHUNK * MAX_PARTS
+    q = max(1, (n + full - 1) // full)
+    p = 1
+    while p < q:
+        p <<= 1
+    ch = BASE_CHUNK * p
+    return ch, max(1, (n + ch - 1) // ch)
+
+
+@dataclass
+class RowPartition:
+    """Contiguous row blocks aligned to the reduction chunks of the global problem."""
+    n_global: int
+    world: int
+    rank: int
+
+    def __post_init__(self):
+        self.ch, self.g = chunk_geometry(self.n_global)
+        self.per = (self.g + self.world - 1) // self.world          # chunks per rank (last ranks may have fewer)
+        self.c0 = min(self.g, self.rank * self.per)
+        self.c1 = min(self.g, (self.rank + 1) * self.per)
+        self.row0 = min(self.n_global, self.c0 * self.ch)
+        self.row1 = min(self.n_global, self.c1 * self.ch)
+        self.n_local = self.row1 - self.row0
+        self.g_local = self.c1 - self.c0
+
+    def owner_of(self, rows: torch.Tensor) -> torch.Tensor:
+        return torch.clamp(torch.div(rows, self.ch * self.per, rounding_mode="floor"), max=self.world - 1)
+
+    def bounds(self, r: int):
+        c0, c1 = min(self.g, r * self.per), min(self.g, (r + 1) * self.per)
+        return min(self.n_global, c0 * self.ch), min(self.n_global, c1 * self.ch)
+
+
+class HaloPlan:
+    """Which owned entries each peer needs from me, and where received entries land (built once)."""
+
+    def __init__(self, col_global: torch.Tensor, part: RowPartition, group=None):
+        dev = col_global.device
+        owned = (col_global >= part.row0) & (col_global < part.row1)
+        ghosts = torch.unique(col_global[~owned])                     # sorted global ids I need
+        self.n_ghost = int(ghosts.numel())
+        owners = part.owner_of(ghosts)
+        self.recv_splits = torch.bincount(owners, minlength=part.world).tolist() if self.n_ghost else [0] * part.world
+        # local numbering: owned -> [0, n_local), ghost k -> n_local + k
+        col_local = torch.empty_like(col_global)
+        col_local[owned] = col_global[owned] - part.row0
+        if self.n_ghost:
+            col_local[~owned] = part.n_local + torch.searchsorted(ghosts, col_global[~owned])
+        self.col_local = col_local
+        # tell every owner which of its rows I need (setup-time collective)
+        send_counts = torch.tensor(self.recv_splits, dtype=torch.int64, device=dev)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        self.send_splits = recv_counts.tolist()
+        wanted = torch.empty(int(sum(self.send_splits)), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(wanted, ghosts.to(torch.int64), self.send_splits, self.recv_splits, group=group)
+        self.send_idx = (wanted - part.row0).to(torch.int32)          # my local rows, grouped by destination
+        self.n_send = int(self.send_idx.numel())
+        if self.n_send:
+            assert int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < part.n_local
+
+
+class HipOps:
+    """The product backend: libhipk.so kernels on this rank's GPU (no CPU fallback)."""
+
+    def __init__(self, device):
+        from . import _hipk
+        self.k = _hipk
+        self.L = _hipk.lib()
+        self.device = torch.device(device)
+        self.dtype = torch.float64
+
+    # -- memory
+    def empty(self, n, dtype=None):
+        return torch.empty(n, dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, n, dtype=None):
+        return torch.zeros(n, dtype=dtype or self.dtype, device=self.device)
+
+    def _s(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _p(self, t):
+        return None if t is None else t.data_ptr()
+
+    def make_matrix(self, crow, col_local, val, n_local, n_cols_ext, ch):
+        h = ctypes.c_void_p()
+        crow, col_local, val = crow.contiguous(), col_local.to(crow.dtype).contiguous(), val.contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.L.hipk_csr_create_ex(ctypes.byref(h), n_local, n_cols_ext, val.numel(), crow.data_ptr(),
+                                           col_local.data_ptr(), crow.element_size(), val.data_ptr(),
+                                           self.k.HIPK_F64, ch, self._s())
+        self.k._check(rc, "hipk_csr_create_ex")
+        return {"h": h, "keep": (crow, col_local, val)}
+
+    def free_matrix(self, m):
+        self.L.hipk_csr_destroy(m["h"])
+
+    def spmv(self, m, x_ext, y, mode=0, w=None, bsub=None, part0=None, part1=None, stop=None, it=0):
+        self.k._check(self.L.hipk_spmv_ex(m["h"], x_ext.data_ptr(), y.data_ptr(), mode, self._p(w), self._p(bsub),
+                                          self._p(part0), self._p(part1), self._p(stop), it, self._s()), "hipk_spmv_ex")
+
+    def dot_parts(self, n, ch, x, y, part):
+        self.k._check(self.L.hipk_dot_parts(n, ch, x.data_ptr(), y.data_ptr(), self.k.HIPK_F64, part.data_ptr(),
+                                            self._s()), "hipk_dot_parts")
+
+    def reduce_parts(self, part, g):
+        out = self.empty(1)
+        self.k._check(self.L.hipk_reduce_parts(part.data_ptr(), g, out.data_ptr(), self._s()), "hipk_reduce_parts")
+        return out
+
+    def gather(self, idx, src, dst):
+        self.k._check(self.L.hipk_gather(idx.numel(), idx.data_ptr(), src.data_ptr(), dst.data_ptr(), self.k.HIPK_F64,
+                                         self._s()), "hipk_gather")
+
+    def scal_alloc(self):
+        return torch.zeros(int(self.L.hipk_cg_scal_bytes()) // 8, dtype=torch.float64, device=self.device)
+
+    def stop_word(self, scal):
+        return scal[6:7].view(torch.int64)          # hipk_cg_scal.stop_it
+
+    def cg_start(self, n, ch, g, scal, part_rr, part_bb, r, p, tol, atol, maxiter):
+        self.k._check(self.L.hipk_cg_start(n, ch, g, scal.data_ptr(), part_rr.data_ptr(), part_bb.data_ptr(),
+                                           r.data_ptr(), p.data_ptr(), self.k.HIPK_F64, float(tol), float(atol),
+                                           maxiter, self._s()), "hipk_cg_start")
+
+    def cg_update(self, n, ch, g, scal, it, part_pAp, p, Ap, x, r, part_out):
+        self.k._check(self.L.hipk_cg_update(n, ch, g, scal.data_ptr(), it, part_pAp.data_ptr(), p.data_ptr(),
+                                            Ap.data_ptr(), x.data_ptr(), r.data_ptr(), part_out.data_ptr(),
+                                            self.k.HIPK_F64, self._s()), "hipk_cg_update")
+
+    def cg_direction(self, n, ch, g, scal, it, maxiter, part_rr, r, p):
+        self.k._check(self.L.hipk_cg_direction(n, ch, g, scal.data_ptr(), it, maxiter, part_rr.data_ptr(),
+                                               r.data_ptr(), p.data_ptr(), self.k.HIPK_F64, self._s()),
+                      "hipk_cg_direction")
+
+    def read_scal(self, scal):
+        h = scal.cpu()
+        return {"gamma": (h[0].item(), h[1].item()), "atol2": h[2].item(), "bs": h[3].item(),
+                "stop_it": int(h[6:7].view(torch.int64).item())}
+
+
+@dataclass
+class DistStats:
+    iterations: int
+    matvecs: int
+    info: int
+    b_norm: float
+    residual_norm: float
+    x_norm: float
+    threshold: float
+
+
+class DistProblem:
+    """A rank's row block of a global CSR system, its halo plan and its device matrix."""
+
+    def __init__(self, crow: torch.Tensor, col_global: torch.Tensor, val: torch.Tensor, b_local: torch.Tensor,
+                 part: RowPartition, ops, group=None):
+        self.part, self.ops, self.group = part, ops, group
+        assert crow.numel() == part.n_local + 1 and b_local.numel() == part.n_local
+        self.plan = HaloPlan(col_global, part, group)
+        self.n_local = part.n_local
+        self.n_ext = part.n_local + self.plan.n_ghost
+        self.nnz_local = int(val.numel())
+        self.b = b_local.contiguous()
+        self.A = ops.make_matrix(crow, self.plan.col_local, val, part.n_local, max(self.n_ext, 1), part.ch) \
+            if part.n_local > 0 else None
+        # algorithmic bytes of this rank's SpMV (SURVEY 8d formula on the local block)
+        self.spmv_bytes = self.nnz_local * 12 + (part.n_local + 1) * 4 + 2 * part.n_local * 8
+        self.send_buf = ops.empty(max(self.plan.n_send, 1))
+
+    def halo_exchange(self, v_ext: torch.Tensor) -> None:
+        """Fill v_ext[n_local:] with the peers' entries this rank's rows reference."""
+        pl = self.plan
+        if pl.n_send:
+            self.ops.gather(pl.send_idx, v_ext, self.send_buf)
+        recv = v_ext[self.n_local:self.n_local + pl.n_ghost]
+        dist.all_to_all_single(recv, self.send_buf[:pl.n_send], pl.recv_splits, pl.send_splits, group=self.group)
+
+
+def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,
+            maxiter: Optional[int] = None, check_every: int = 32):
+    """Row-partitioned CG; returns (x_local, info, DistStats). Same stopping rule, same `info` rule and,
+    bit for bit, the same iterates as the single-device solve."""
+    ops, part, group = prob.ops, prob.part, prob.group
+    n, ch, G, per, world = part.n_local, part.ch, part.g, part.per, part.world
+    maxiter = 10 * part.n_global if maxiter is None else int(maxiter)
+    x = ops.zeros(max(prob.n_ext, 1))                      # x and p carry the halo tail
+    if x0_local is not None:
+        x[:n] = x0_local
+    p = ops.zeros(max(prob.n_ext, 1))
+    r, Ap = ops.zeros(max(n, 1)), ops.zeros(max(n, 1))
+    part_loc = ops.zeros(per)                               # this rank's chunk partials (zero padded)
+    spare = ops.zeros(per)
+    g_pAp, g_rr, g_bb = ops.zeros(world * per), ops.zeros(world * per), ops.zeros(world * per)
+    scal = ops.scal_alloc()
+    stop = ops.stop_word(scal)
+
+    def gather_parts(dst):
+        dist.all_gather_into_tensor(dst, part_loc, group=group)
+
+    # r0 = b - A x0, <r0,r0>; <b,b>   (TSL:815-826)
+    prob.halo_exchange(x)
+    if n:
+        ops.spmv(prob.A, x, r, MODE_RESID | MODE_DOT_YY, bsub=prob.b, part0=spare, part1=part_loc)
+    gather_parts(g_rr)
+    if n:
+        ops.dot_parts(n, ch, prob.b, prob.b, part_loc)
+    gather_parts(g_bb)
+    if n:
+        ops.cg_start(n, ch, G, scal, g_rr, g_bb, r, p, tol, atol, maxiter)
+    it, stop_it = 0, None
+    while it < maxiter:
+        end = min(maxiter, it + check_every)
+        while it < end:
+            prob.halo_exchange(p)
+            if n:
+                ops.spmv(prob.A, p, Ap, MODE_DOT_W, w=p, part0=part_loc, part1=spare, stop=stop, it=it)
+            gather_parts(g_pAp)
+            if n:
+                ops.cg_update(n, ch, G, scal, it, g_pAp, p, Ap, x, r, part_loc)
+            gather_parts(g_rr)
+            if n:
+                ops.cg_direction(n, ch, G, scal, it, maxiter, g_rr, r, p)
+            it += 1
+        stop_it = _agree_stop(ops, scal, n, group, world)
+        if stop_it <= it:
+            break
+    if stop_it is None:
+        stop_it = _agree_stop(ops, scal, n, group, world)
+    iterations = min(stop_it, it)
+    # TSL:1007-1014: true residual and ||x|| decide info
+    prob.halo_exchange(x)
+    if n:
+        ops.spmv(prob.A, x, Ap, MODE_RESID | MODE_DOT_YY, bsub=prob.b, part0=spare, part1=part_loc)
+    gather_parts(g_rr)
+    res2 = ops.reduce_parts(g_rr, G)
+    if n:
+        ops.dot_parts(n, ch, x, x, part_loc)
+    gather_parts(g_pAp)
+    xx = ops.reduce_parts(g_pAp, G)
+    bs = ops.reduce_parts(g_bb, G)
+    res2, xx, bs = float(res2.item()), float(xx.item()), float(bs.item())
+    b_norm, res_norm, x_norm = max(bs, 0.0) ** 0.5, max(res2, 0.0) ** 0.5, (xx if xx == xx else float("nan"))
+    x_norm = max(xx, 0.0) ** 0.5 if xx == xx else float("nan")
+    thr = max(float(torch.tensor(tol, dtype=torch.float32).item()) * b_norm,
+              float(torch.tensor(atol, dtype=torch.float32).item()))
+    info = -1 if (x_norm != x_norm or res_norm > thr) else 0
+    return x[:n], info, DistStats(iterations, iterations + 2, info, b_norm, res_norm, x_norm, thr)
+
+
+def _agree_stop(ops, scal, n, group, world) -> int:
+    """Every rank derives the same stop word from the same gathered partials; ranks without rows
+    (more ranks than chunks) take it from the others."""
+    s = ops.read_scal(scal)["stop_it"] if n else (1 << 62)
+    if world > 1:
+        t = torch.tensor([s], dtype=torch.int64, device=scal.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        s = int(t.item())
+    return s
+
+
+class DistPoissonProblem(DistProblem):
+    """bench.py workload: 5-point Poisson on a (nx_per_rank * world) x ny grid, b = ones, rank r owning
+    grid lines [r nx_per_rank, (r+1) nx_per_rank) -- requires ny * nx_per_rank to be chunk aligned, else
+    the chunk-aligned partition of RowPartition is used as is."""
+
+    def __init__(self, nx_per_rank: int, ny: int, rank: int, world: int, device, group=None):
+        from .utils.matrix_utils import stencil5_csr_components
+        ops = HipOps(device)
+        nx = nx_per_rank * world
+        part = RowPartition(nx * ny, world, rank)
+        crow, col, val = stencil5_csr_components(nx, ny, 4.0, -1.0, -1.0, -1.0, -1.0, row_begin=part.row0,
+                                                 row_end=part.row1, device=device)
+        b = torch.ones(part.n_local, dtype=torch.float64, device=device)
+        super().__init__(crow, col, val, b, part, ops, group)

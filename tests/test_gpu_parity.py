@@ -67,14 +67,14 @@ def test_dot_bit_exact(hipk, oracle, n):
     assert got == oracle.dot(a, b)
 
 
-def test_fused_spmv_dot_equals_separate(hipk, oracle):
+def test_fused_spmv_dot_is_the_tiled_dot(hipk, oracle):
     d = load_case("poisson_nx64")
     h = hipk.handle_for(dev_csr(d))
     rng = np.random.default_rng(2)
     x, w = rng.standard_normal(4096), rng.standard_normal(4096)
     y, dt = hipk.spmv_dot(h, torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV))
     y_ref = oracle.spmv(d["crow"], d["col"], d["val"], x)
-    assert np.array_equal(y.cpu().numpy(), y_ref) and dt.item() == oracle.dot(w, y_ref)
+    assert np.array_equal(y.cpu().numpy(), y_ref) and dt.item() == oracle.dot_tiled(w, y_ref)
 
 
 def test_axpy_xpby_rounding(hipk):
@@ -158,8 +158,7 @@ def test_bicgstab_bit_exact_vs_oracle(hipk, oracle, r):
     assert st.residual_norm == ref.residual_norm
     # vs the reference itself: BiCGStab is trajectory-chaotic, so a band (conftest.py)
     assert abs(st.matvecs - r["matvecs"]) <= max(2, BICGSTAB_MATVEC_BAND * r["matvecs"])
-    tol = r["kwargs"].get("tol", 1e-5)
-    assert info == r["info"] or st.residual_norm <= 50 * tol * st.b_norm
+    assert info == r["info"] or st.residual_norm <= 1e-6 * st.b_norm    # recurrence/true-residual gap, see test_oracle_golden
 
 
 @pytest.mark.parametrize("r", golden_runs("gmres"), ids=run_id)
