@@ -3,6 +3,7 @@
 
 #include "hipk_blas1.h"
 #include "hipk_common.h"
+#include "hipk_solve.h"
 #include "hipk_spmv.h"
 
 // ------------------------------------------------------------------ errors
@@ -42,6 +43,7 @@ template <typename I>
 __global__ void hipk_narrow_check_kernel(const I *__restrict__ crow_in, const I *__restrict__ col_in,
                                          int *__restrict__ crow, int *__restrict__ col, int64_t n_rows,
                                          int64_t n_cols, int64_t nnz, int *__restrict__ bad) {
+    // bad[0]: error flags; bad[1]: longest row; bad[2]: most entries in a 256-row tile
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = i0; i <= n_rows; i += stride) {
@@ -50,6 +52,15 @@ __global__ void hipk_narrow_check_kernel(const I *__restrict__ crow_in, const I 
         if (i == 0 && v != 0) atomicOr(bad, 2);
         if (i == n_rows && v != nnz) atomicOr(bad, 4);
         if (i < n_rows && (int64_t)crow_in[i + 1] < v) atomicOr(bad, 8);
+        if (i < n_rows) {
+            const int64_t len = (int64_t)crow_in[i + 1] - v;
+            if (len > 0) atomicMax(bad + 1, (int)(len > INT32_MAX ? INT32_MAX : len));
+            if ((i & 255) == 0) {
+                const int64_t e = (i + 256 < n_rows) ? i + 256 : n_rows;
+                const int64_t tl = (int64_t)crow_in[e] - v;
+                if (tl > 0) atomicMax(bad + 2, (int)(tl > INT32_MAX ? INT32_MAX : tl));
+            }
+        }
         crow[i] = (int)v;
     }
     for (int64_t j = i0; j < nnz; j += stride) {
@@ -100,14 +111,15 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         if (h->geom.g < 1) h->geom.g = 1;
     }
     int *bad = nullptr;
-    int bad_h = 0;
+    int bad3[3] = {0, 0, 0};
+    int &bad_h = bad3[0];
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess) e = hipMalloc((void **)&h->crow, sizeof(int) * (size_t)(n_rows + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&bad, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&bad, 3 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->tile_part, sizeof(double) * 2 * (size_t)((n_rows + 255) / 256 + 1));
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_poll, 16 * sizeof(int64_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 3 * sizeof(int), stream);
     if (e == hipSuccess) {
         const int64_t work = (nnz > n_rows + 1) ? nnz : n_rows + 1;
         int grid = (int)((work + 255) / 256);
@@ -122,7 +134,7 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
                                                                    h->crow, h->col, n_rows, n_cols, nnz, bad);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad_h, bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bad3, bad, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (bad) (void)hipFree(bad);
     if (e != hipSuccess || bad_h != 0) {
@@ -134,6 +146,8 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         hipk_csr_destroy(h);
         return e != hipSuccess ? HIPK_ERR_HIP : HIPK_ERR_ARG;
     }
+    h->max_row_len = bad3[1];
+    h->max_tile_nnz = bad3[2];
     *out = h;
     return HIPK_OK;
 }
@@ -159,16 +173,25 @@ extern "C" int64_t hipk_csr_spmv_bytes(hipk_csr_t h) {
 // ------------------------------------------------------------------ SpMV launch
 // CAP (LDS product slots per tile): 1280 = 256 rows x 5 nnz, the 5-point stencil's tile, and it keeps the
 // workgroup at 11 KB LDS => 8 workgroups per CU.  Denser tiles take the kernel's general path.
-int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t stream) {
+int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t stream, hipk_spmv_profiler *prof) {
     hipk_spmv_args a = a_;
     const int ntiles = (int)((a.n + 255) / 256);
     const int grid = ((ntiles + 7) >> 3) << 3;
     a.tpart0 = h->tile_part;
     a.tpart1 = h->tile_part + ntiles;
-    if (h->dtype == HIPK_F64)
-        hipk_spmv_kernel<double, 1280><<<grid, HIPK_THREADS, 0, stream>>>(a);
-    else
-        hipk_spmv_kernel<float, 2048><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    if (prof) prof->before(stream);
+    if (h->dtype == HIPK_F64) {
+        if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)
+            hipk_spmv_kernel<double, 1280, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+        else
+            hipk_spmv_kernel<double, 1280, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    } else {
+        if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)
+            hipk_spmv_kernel<float, 2048, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+        else
+            hipk_spmv_kernel<float, 2048, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
+    }
+    if (prof) prof->after(stream);
     if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
         hipk_tile_combine_kernel<<<a.g, HIPK_THREADS, 0, stream>>>(
             (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,

@@ -336,9 +336,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, co
             hipk_bi_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr, part_rhr,
                                                                             r, q, p);
             sq.it = it;
-            prof.before(stream);
-            if ((rc = hipk_launch_spmv(A, sq, stream)) != HIPK_OK) return rc;
-            prof.after(stream);
+            if ((rc = hipk_launch_spmv(A, sq, stream, &prof)) != HIPK_OK) return rc;
             hipk_bi_supdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq, r,
                                                                           q, s, part_ss);
             stt.it = it;

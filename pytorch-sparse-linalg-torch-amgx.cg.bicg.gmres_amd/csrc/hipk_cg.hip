@@ -214,9 +214,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         const int64_t end = (it + check < maxiter) ? it + check : maxiter;
         for (; it < end; ++it) {
             sa.it = it;
-            prof.before(stream);
-            if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
-            prof.after(stream);
+            if ((rc = hipk_launch_spmv(A, sa, stream, &prof)) != HIPK_OK) return rc;
             hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, p, Ap, x, r,
                                                                          part_b);
             hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_b,

@@ -541,9 +541,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
             sw.part1 = part_ww;
             sw.stop_it = &scal->stop_step;
             sw.it = k;
-            prof.before(stream);
-            if ((rc = hipk_launch_spmv(A, sw, stream)) != HIPK_OK) break;
-            prof.after(stream);
+            if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq);
                 hipk_gm_multidot_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,

@@ -205,13 +205,28 @@ class DistProblem:
         self.spmv_bytes = self.nnz_local * 12 + (part.n_local + 1) * 4 + 2 * part.n_local * 8
         self.send_buf = ops.empty(max(self.plan.n_send, 1))
 
+    # ---- the three collectives of the solver (overridable: tests stage them through the host)
     def halo_exchange(self, v_ext: torch.Tensor) -> None:
         """Fill v_ext[n_local:] with the peers' entries this rank's rows reference."""
         pl = self.plan
         if pl.n_send:
             self.ops.gather(pl.send_idx, v_ext, self.send_buf)
         recv = v_ext[self.n_local:self.n_local + pl.n_ghost]
-        dist.all_to_all_single(recv, self.send_buf[:pl.n_send], pl.recv_splits, pl.send_splits, group=self.group)
+        self._all_to_all(recv, self.send_buf[:pl.n_send], pl.recv_splits, pl.send_splits)
+
+    def _all_to_all(self, recv, send, recv_splits, send_splits) -> None:
+        dist.all_to_all_single(recv, send, recv_splits, send_splits, group=self.group)
+
+    def gather_parts(self, dst: torch.Tensor, src: torch.Tensor) -> None:
+        """dst[r*per:(r+1)*per] = rank r's chunk partials, in rank (= global chunk) order."""
+        dist.all_gather_into_tensor(dst, src, group=self.group)
+
+    def agree_min(self, value: int) -> int:
+        if self.part.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device=self.ops.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
 
 
 def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,
@@ -233,7 +248,7 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
     stop = ops.stop_word(scal)
 
     def gather_parts(dst):
-        dist.all_gather_into_tensor(dst, part_loc, group=group)
+        prob.gather_parts(dst, part_loc)
 
     # r0 = b - A x0, <r0,r0>; <b,b>   (TSL:815-826)
     prob.halo_exchange(x)
@@ -259,11 +274,11 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
             if n:
                 ops.cg_direction(n, ch, G, scal, it, maxiter, g_rr, r, p)
             it += 1
-        stop_it = _agree_stop(ops, scal, n, group, world)
+        stop_it = _agree_stop(prob, scal)
         if stop_it <= it:
             break
     if stop_it is None:
-        stop_it = _agree_stop(ops, scal, n, group, world)
+        stop_it = _agree_stop(prob, scal)
     iterations = min(stop_it, it)
     # TSL:1007-1014: true residual and ||x|| decide info
     prob.halo_exchange(x)
@@ -285,15 +300,11 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
     return x[:n], info, DistStats(iterations, iterations + 2, info, b_norm, res_norm, x_norm, thr)
 
 
-def _agree_stop(ops, scal, n, group, world) -> int:
+def _agree_stop(prob, scal) -> int:
     """Every rank derives the same stop word from the same gathered partials; ranks without rows
     (more ranks than chunks) take it from the others."""
-    s = ops.read_scal(scal)["stop_it"] if n else (1 << 62)
-    if world > 1:
-        t = torch.tensor([s], dtype=torch.int64, device=scal.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        s = int(t.item())
-    return s
+    s = prob.ops.read_scal(scal)["stop_it"] if prob.n_local else (1 << 62)
+    return prob.agree_min(s)
 
 
 class DistPoissonProblem(DistProblem):

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, kind, nx, ny, tol, maxiter, tmp_path):
+def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu"):
     out = str(tmp_path / f"res_{world}_{kind}.json")
     port = _free_port()
     procs = []
@@ -27,7 +27,7 @@ def _run(world, kind, nx, ny, tol, maxiter, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), kind, str(nx), str(ny),
-                                       str(tol), str(maxiter), out], env=env, stdout=subprocess.PIPE,
+                                       str(tol), str(maxiter), out, mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -62,3 +62,40 @@ def test_dist_cg_bitwise_equals_single_rank(world, kind, nx, ny, tmp_path):
 def test_dist_cg_maxiter_cutoff(tmp_path):
     r = _run(2, "poisson", 96, 64, 1e-12, 9, tmp_path)
     assert r["bitwise_equal"] and set(r["iterations"]) == {9} and set(r["info"]) == {-1} and r["ref_info"] == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny", [(2, "poisson", 96, 64), (3, "random_spd", 80, 77), (4, "poisson", 96, 64)])
+def test_dist_cg_hip_kernels_multi_rank_on_one_gpu(world, kind, nx, ny, tmp_path):
+    """The REAL step API (libhipk.so) under a multi-rank partition: ranks share cuda:0, collectives are staged
+    through the host over gloo.  Must equal the single-rank oracle solve bit for bit."""
+    r = _run(world, kind, nx, ny, 1e-8, -1, tmp_path, mode="hip")
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {0} and set(r["iterations"]) == {r["ref_iterations"]}
+
+
+@pytest.mark.gpu
+def test_dist_cg_nccl_world1_equals_single_gpu(tmp_path):
+    """RCCL path smoke test at world_size 1 (the only size the 1-GPU box allows): DistPoissonProblem + dist_cg
+    through torch.distributed 'nccl' must equal the single-device cg() bit for bit."""
+    code = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path[:0] = [%r, %r]
+from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
+from pytorch_sparse_solver.module_a import cg, get_last_stats
+from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+prob = DistPoissonProblem(nx_per_rank=96, ny=64, rank=0, world=1, device=torch.device("cuda", 0))
+x, info, st = dist_cg(prob, tol=1e-8)
+A = create_poisson_2d_csr(96, 64, device="cuda:0")
+xr, info_r = cg(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8)
+s = get_last_stats()
+print(json.dumps({"equal": bool(torch.equal(x, xr)), "info": info, "info_r": info_r, "it": st.iterations, "it_r": s.iterations,
+                  "res": st.residual_norm, "res_r": s.residual_norm}))
+dist.destroy_process_group()
+''' % (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["equal"] and r["info"] == r["info_r"] == 0 and r["it"] == r["it_r"] and r["res"] == r["res_r"], r
