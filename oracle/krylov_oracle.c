@@ -1,7 +1,9 @@
 /*
  * krylov_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * CPU restatement (plain C, fp64) of the reference's Module-A hot path:
+ * CPU restatement (plain C; fp64, and with -DORC_F32 the fp32-storage extension: vectors and
+ * matrix values in float, every dot accumulated in fp64, scalars in fp64) of the reference's
+ * Module-A hot path:
  *   cg / bicgstab / gmres of
  *   /root/reference/src/pytorch_sparse_solver/module_a/torch_sparse_linalg.py  (= TSL)
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
@@ -21,8 +23,8 @@
  *     chunk partials are folded the same way (thread t takes partials t, t+256, ..).
  *   - "tiled dot" (every dot FUSED into an SpMV epilogue: <p,Ap>, <rhat,q>, <t,s>, <t,t>,
  *     ||A v||^2, ||b - A x||^2): rows are cut in tiles of 256; thread t of a tile forms the
- *     rounded product a_i*b_i of row t (0 beyond n); the 256 products are folded by the
- *     same tree into a TILE partial; the tile partials of a chunk are folded like chunk
+ *     rounded product a_i*b_i of row t (0 beyond n); each wavefront's 64 products are folded
+ *     by v[l] += v[l+s], s = 32..1, and the TILE partial is ((s0+s1)+(s2+s3)); the tile partials of a chunk are folded like chunk
  *     partials (thread t takes t, t+256, .. then the tree) into the chunk partial.
  *   - SpMV row: products rounded, then added in CSR order (rows <= 32 entries);
  *     longer rows: 64 strided lane sums folded by v[l] += v[l+s], s = 32..1.
@@ -44,8 +46,33 @@
 #define ORC_MAX_PARTS 2048
 #define ORC_BASE_CHUNK 2048
 #define ORC_LONG_ROW 32
-#define ORC_EPS 2.220446049250313e-16 /* torch.finfo(torch.float64).eps */
+#define ORC_EPS64 2.220446049250313e-16 /* torch.finfo(torch.float64).eps */
+#define ORC_EPS32 1.1920928955078125e-07 /* torch.finfo(torch.float32).eps */
+#ifdef ORC_F32
+typedef float real;
+#define ORC_EPS ORC_EPS32 /* guards use the eps of the working dtype; the GMRES absolute floor keeps ORC_EPS64 */
+#else
+typedef double real;
+#define ORC_EPS ORC_EPS64
+#endif
+#define ORC_VEC (16 / (int)sizeof(real)) /* elements a virtual thread owns per step: 16-byte accesses */
 #define ORC_INV_SQRT2 0.7071067811865476 /* TSL:63 */
+
+#ifdef ORC_F32 /* second compilation of this file with -DORC_F32: fp32 storage, symbols orc32_* */
+#define orc_set_threads orc32_set_threads
+#define orc_get_threads orc32_get_threads
+#define orc_chunk_geom orc32_chunk_geom
+#define orc_dot_parts orc32_dot_parts
+#define orc_dot_parts_ch orc32_dot_parts_ch
+#define orc_reduce_parts orc32_reduce_parts
+#define orc_dot orc32_dot
+#define orc_dot_tiled_parts_ch orc32_dot_tiled_parts_ch
+#define orc_dot_tiled orc32_dot_tiled
+#define orc_spmv orc32_spmv
+#define orc_cg orc32_cg
+#define orc_bicgstab orc32_bicgstab
+#define orc_gmres orc32_gmres
+#endif
 
 static int g_threads = 1;
 
@@ -100,20 +127,20 @@ static double reduce_parts(const double *part, int g) {
     return tree256(v);
 }
 
-static double chunk_dot(const double *a, const double *b, int64_t base, int64_t end) {
+static double chunk_dot(const real *a, const real *b, int64_t base, int64_t end) {
     double v[ORC_THREADS];
     for (int t = 0; t < ORC_THREADS; ++t) v[t] = 0.0;
-    /* element e of the chunk belongs to virtual thread (e mod 512)/2; ascending e is
-       ascending order inside every thread */
+    /* element e of the chunk belongs to virtual thread (e mod 256 VEC)/VEC, VEC = 16 B / sizeof(real)
+       (2 for fp64, 4 for fp32); ascending e is ascending order inside every thread */
     for (int64_t i = base; i < end; ++i) {
-        const int t = (int)(((i - base) & 511) >> 1);
-        v[t] = fma(a[i], b[i], v[t]);
+        const int t = (int)(((i - base) % (ORC_THREADS * ORC_VEC)) / ORC_VEC);
+        v[t] = fma((double)a[i], (double)b[i], v[t]);
     }
     return tree256(v);
 }
 
 /* G chunk partials of <a,b> (also what a rank of the row-partitioned solver owns) */
-void orc_dot_parts(int64_t n, const double *a, const double *b, double *parts) {
+void orc_dot_parts(int64_t n, const real *a, const real *b, double *parts) {
     int ch, g;
     orc_chunk_geom(n, &ch, &g);
 #pragma omp parallel for schedule(static) if (g_threads > 1)
@@ -125,7 +152,7 @@ void orc_dot_parts(int64_t n, const double *a, const double *b, double *parts) {
 }
 
 /* same with an explicit chunk size: the partials a rank of the row-partitioned solver owns */
-void orc_dot_parts_ch(int64_t n, int ch, const double *a, const double *b, double *parts) {
+void orc_dot_parts_ch(int64_t n, int ch, const real *a, const real *b, double *parts) {
     const int g = (int)((n + ch - 1) / ch);
 #pragma omp parallel for schedule(static) if (g_threads > 1)
     for (int c = 0; c < g; ++c) {
@@ -138,7 +165,7 @@ void orc_dot_parts_ch(int64_t n, int ch, const double *a, const double *b, doubl
 double orc_reduce_parts(const double *parts, int g) { return reduce_parts(parts, g); }
 
 /* `_vdot_real_tree` (TSL:130-139) */
-double orc_dot(int64_t n, const double *a, const double *b) {
+double orc_dot(int64_t n, const real *a, const real *b) {
     int ch, g;
     orc_chunk_geom(n, &ch, &g);
     double *parts = (double *)malloc(sizeof(double) * (size_t)g);
@@ -149,7 +176,7 @@ double orc_dot(int64_t n, const double *a, const double *b) {
 }
 
 /* chunk partials of the tiled dot (what hipk_spmv_kernel + hipk_tile_combine_kernel produce) */
-void orc_dot_tiled_parts_ch(int64_t n, int ch, const double *a, const double *b, double *parts) {
+void orc_dot_tiled_parts_ch(int64_t n, int ch, const real *a, const real *b, double *parts) {
     const int g = (int)((n + ch - 1) / ch);
     const int tpc = ch / 256;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
@@ -159,16 +186,22 @@ void orc_dot_tiled_parts_ch(int64_t n, int ch, const double *a, const double *b,
         const int64_t end = base + ch < n ? base + ch : n;
         int nt = 0;
         for (int64_t t0 = base; t0 < end; t0 += 256, ++nt) {
-            double v[ORC_THREADS];
-            for (int t = 0; t < 256; ++t) v[t] = (t0 + t < end) ? a[t0 + t] * b[t0 + t] : 0.0;
-            tp[nt] = tree256(v);
+            double v[ORC_THREADS], sw[4];
+            for (int t = 0; t < 256; ++t) v[t] = (t0 + t < end) ? (double)a[t0 + t] * (double)b[t0 + t] : 0.0;
+            for (int w = 0; w < 4; ++w) { /* one wavefront: v[l] += v[l+s], s = 32..1 */
+                double *u = v + 64 * w;
+                for (int s = 32; s >= 1; s >>= 1)
+                    for (int l = 0; l < s; ++l) u[l] = u[l] + u[l + s];
+                sw[w] = u[0];
+            }
+            tp[nt] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
         }
         (void)tpc;
         parts[c] = reduce_parts(tp, nt);
     }
 }
 
-double orc_dot_tiled(int64_t n, const double *a, const double *b) {
+double orc_dot_tiled(int64_t n, const real *a, const real *b) {
     int ch, g;
     orc_chunk_geom(n, &ch, &g);
     double *parts = (double *)malloc(sizeof(double) * (size_t)g);
@@ -179,21 +212,21 @@ double orc_dot_tiled(int64_t n, const double *a, const double *b) {
 }
 
 /* ------------------------------------------------------------------ SpMV */
-static double row_sum(const int32_t *col, const double *val, const double *x, int lo, int hi) {
+static real row_sum(const int32_t *col, const real *val, const real *x, int lo, int hi) {
     const int len = hi - lo;
     if (len <= ORC_LONG_ROW) {
-        double s = 0.0;
+        real s = (real)0;
         for (int j = lo; j < hi; ++j) {
-            const double p = val[j] * x[col[j]];
+            const real p = val[j] * x[col[j]];
             s = s + p;
         }
         return s;
     }
-    double v[64];
+    real v[64];
     for (int l = 0; l < 64; ++l) {
-        double s = 0.0;
+        real s = (real)0;
         for (int j = lo + l; j < hi; j += 64) {
-            const double p = val[j] * x[col[j]];
+            const real p = val[j] * x[col[j]];
             s = s + p;
         }
         v[l] = s;
@@ -204,11 +237,11 @@ static double row_sum(const int32_t *col, const double *val, const double *x, in
 }
 
 /* y = A x  (`torch.matmul(A, v)`, TSL:191); bsub != NULL: y = bsub - A x (TSL:820) */
-void orc_spmv(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *x,
-              const double *bsub, double *y) {
+void orc_spmv(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *x,
+              const real *bsub, real *y) {
 #pragma omp parallel for schedule(static) if (g_threads > 1)
     for (int64_t r = 0; r < n; ++r) {
-        const double s = row_sum(col, val, x, crow[r], crow[r + 1]);
+        const real s = row_sum(col, val, x, crow[r], crow[r + 1]);
         y[r] = bsub ? bsub[r] - s : s;
     }
 }
@@ -227,11 +260,11 @@ static double norm_from_sq(double v) { return sqrt(v < 0.0 ? 0.0 : v); } /* `_no
 typedef struct {
     int64_t n;
     const int32_t *crow, *col;
-    const double *val;
+    const real *val;
 } csr_t;
 
-static void isolve_epilogue(const csr_t *A, const double *b, const double *x, double tol, double atol,
-                            double bs, double *tmp, orc_stats *st) {
+static void isolve_epilogue(const csr_t *A, const real *b, const real *x, double tol, double atol,
+                            double bs, real *tmp, orc_stats *st) {
     /* TSL:1007-1016 */
     orc_spmv(A->n, A->crow, A->col, A->val, x, b, tmp);
     st->residual_norm = norm_from_sq(orc_dot_tiled(A->n, tmp, tmp)); /* fused in the SpMV */
@@ -242,14 +275,14 @@ static void isolve_epilogue(const csr_t *A, const double *b, const double *x, do
 }
 
 /* ------------------------------------------------------------------ CG: TSL:806-856 via _isolve TSL:968-1016 */
-int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
-           double *x /* in: x0, out: x */, double tol, double atol, int64_t maxiter, orc_stats *st) {
+int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b,
+           real *x /* in: x0, out: x */, double tol, double atol, int64_t maxiter, orc_stats *st) {
     csr_t A = {n, crow, col, val};
     memset(st, 0, sizeof(*st));
     if (maxiter < 0) maxiter = 10 * n;
-    double *r = (double *)malloc(sizeof(double) * (size_t)n);
-    double *p = (double *)malloc(sizeof(double) * (size_t)n);
-    double *Ap = (double *)malloc(sizeof(double) * (size_t)n);
+    real *r = (real *)malloc(sizeof(real) * (size_t)n);
+    real *p = (real *)malloc(sizeof(real) * (size_t)n);
+    real *Ap = (real *)malloc(sizeof(real) * (size_t)n);
     const double bs = orc_dot(n, b, b);
     const float tolf = (float)tol, atolf = (float)atol; /* torch.tensor(python float) is fp32 */
     const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
@@ -257,7 +290,7 @@ int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val
     orc_spmv(n, crow, col, val, x, b, r);
     int64_t matvecs = 1;
     double gamma = orc_dot_tiled(n, r, r); /* fused in the residual SpMV */
-    memcpy(p, r, sizeof(double) * (size_t)n);
+    memcpy(p, r, sizeof(real) * (size_t)n);
     int64_t k = 0;
     while (!(k >= maxiter || gamma <= atol2)) {
         orc_spmv(n, crow, col, val, p, NULL, Ap);
@@ -266,16 +299,16 @@ int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val
         const double alpha = gamma / pAp;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const double m0 = alpha * p[i];
+            const real m0 = (real)alpha * p[i];
             x[i] = x[i] + m0;
-            const double m1 = alpha * Ap[i];
+            const real m1 = (real)alpha * Ap[i];
             r[i] = r[i] - m1;
         }
         const double rr = orc_dot(n, r, r);
         const double beta = rr / gamma;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const double m = beta * p[i];
+            const real m = (real)beta * p[i];
             p[i] = r[i] + m;
         }
         gamma = rr;
@@ -292,14 +325,14 @@ int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const double *val
 }
 
 /* ------------------------------------------------------------------ BiCGStab: TSL:859-964 */
-int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
-                 double *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
+int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b,
+                 real *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
     csr_t A = {n, crow, col, val};
     memset(st, 0, sizeof(*st));
     if (maxiter < 0) maxiter = 10 * n;
-    const size_t nb = sizeof(double) * (size_t)n;
-    double *r = (double *)malloc(nb), *rhat = (double *)malloc(nb), *p = (double *)malloc(nb);
-    double *q = (double *)malloc(nb), *s = (double *)malloc(nb), *t = (double *)malloc(nb);
+    const size_t nb = sizeof(real) * (size_t)n;
+    real *r = (real *)malloc(nb), *rhat = (real *)malloc(nb), *p = (real *)malloc(nb);
+    real *q = (real *)malloc(nb), *s = (real *)malloc(nb), *t = (real *)malloc(nb);
     const double bs = orc_dot(n, b, b);
     const float tolf = (float)tol, atolf = (float)atol;
     const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
@@ -326,9 +359,9 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
         const double beta = rho_new / rho * alpha / omega; /* left to right, TSL:906 */
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const double t1 = omega * q[i];
-            const double t2 = p[i] - t1;
-            const double t3 = beta * t2;
+            const real t1 = (real)omega * q[i];
+            const real t2 = p[i] - t1;
+            const real t3 = (real)beta * t2;
             p[i] = r[i] + t3;
         }
         orc_spmv(n, crow, col, val, p, NULL, q);
@@ -340,7 +373,7 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
         }
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const double m = alpha_new * q[i];
+            const real m = (real)alpha_new * q[i];
             s[i] = r[i] - m;
         }
         const int exit_early = orc_dot(n, s, s) < atol2;
@@ -358,15 +391,15 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const doubl
         }
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const double m0 = alpha_new * p[i];
+            const real m0 = (real)alpha_new * p[i];
             if (exit_early) {
                 x[i] = x[i] + m0;
                 r[i] = s[i];
             } else {
-                const double m1 = omega_new * s[i];
-                const double m2 = m0 + m1;
+                const real m1 = (real)omega_new * s[i];
+                const real m2 = m0 + m1;
                 x[i] = x[i] + m2;
-                const double m3 = omega_new * t[i];
+                const real m3 = (real)omega_new * t[i];
                 r[i] = s[i] - m3;
             }
         }
@@ -485,16 +518,16 @@ static void givens(double a, double b, double *cs, double *sn) {
 }
 
 /* gpu_tolerances: 1 = the `device.type == 'cuda'` branch of TSL:737-744 */
-int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *val, const double *b,
-              double *x, double tol, double atol, int restart, int64_t maxiter, int method /*0 batched,1 incremental*/,
+int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b,
+              real *x, double tol, double atol, int restart, int64_t maxiter, int method /*0 batched,1 incremental*/,
               int gpu_tolerances, orc_stats *st) {
     memset(st, 0, sizeof(*st));
     if (restart < 1 || restart > 31) return -1;
     if (maxiter < 0) maxiter = 10 * n;
     const int m = restart;
-    const size_t nb = sizeof(double) * (size_t)n;
-    double *V = (double *)malloc(nb * (size_t)(m + 1)); /* column j at V + j*n */
-    double *tmp = (double *)malloc(nb);
+    const size_t nb = sizeof(real) * (size_t)n;
+    real *V = (real *)malloc(nb * (size_t)(m + 1)); /* column j at V + j*n */
+    real *tmp = (real *)malloc(nb);
     double H[32 * 32], R[32 * 32], gv[32][2], beta_vec[33], rvec[32], hvec[32], y[32];
     const int ldh = 32;
 
@@ -504,19 +537,19 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
     const double sq = sqrt((double)n);
     const double cand = (gpu_tolerances ? 1e-12 : 1e-14) * sq;
     const double adaptive = (cand > tol) ? cand : (double)(float)tol; /* python max(): float stays a float -> fp32 tensor */
-    const double base_atol = (double)(float)(ORC_EPS * (gpu_tolerances ? 1000 : 100) * (double)n);
+    const double base_atol = (double)(float)(ORC_EPS64 * (gpu_tolerances ? 1000 : 100) * (double)n);
     const double atol_eff = tmax(adaptive * b_norm, tmax((double)(float)atol, base_atol));
     const double ptol = b_norm * tmin(1.0, atol_eff / b_norm); /* TSL:750-753, M = identity */
 
     /* TSL:791-792 */
-    double *res = V; /* residual lives in column 0 */
+    real *res = V; /* residual lives in column 0 */
     orc_spmv(n, crow, col, val, x, b, res);
     int64_t matvecs = 1;
     double res_norm = norm_from_sq(orc_dot_tiled(n, res, res));
     {
         const int use = res_norm > ORC_EPS;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
-        for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / res_norm : 0.0;
+        for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / (real)res_norm : (real)0;
         if (!use) res_norm = 0.0;
     }
     int64_t cycles = 0;
@@ -532,7 +565,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
         double err = res_norm;
         while (k < m && !breakdown && (method == 0 || err > ptol)) {
             /* ---- `_kth_arnoldi_iteration` (TSL:331-388) */
-            double *w = V + (size_t)(k + 1) * n;
+            real *w = V + (size_t)(k + 1) * n;
             orc_spmv(n, crow, col, val, V + (size_t)k * n, NULL, w);
             ++matvecs;
             double norm0 = norm_from_sq(orc_dot_tiled(n, w, w)); /* fused in the SpMV */
@@ -552,8 +585,8 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
 #pragma omp parallel for schedule(static) if (g_threads > 1)
                 for (int64_t i = 0; i < n; ++i) {
                     double s = 0.0;
-                    for (int j = 0; j <= k; ++j) s = fma(V[(size_t)j * n + i], hvec[j], s);
-                    w[i] = w[i] - s;
+                    for (int j = 0; j <= k; ++j) s = fma((double)V[(size_t)j * n + i], hvec[j], s);
+                    w[i] = (real)((double)w[i] - s);
                 }
                 for (int j = 0; j <= k; ++j) rvec[j] = rvec[j] + hvec[j];
                 qnorm = norm_from_sq(orc_dot(n, w, w));
@@ -564,7 +597,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
             const double thr = ORC_EPS * norm0;
             const int use = norm1 > thr;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
-            for (int64_t i = 0; i < n; ++i) w[i] = use ? w[i] / norm1 : 0.0;
+            for (int64_t i = 0; i < n; ++i) w[i] = use ? w[i] / (real)norm1 : (real)0;
             if (!use) norm1 = 0.0;
             for (int j = 0; j <= k; ++j) H[j * ldh + k] = rvec[j];
             H[(k + 1) * ldh + k] = norm1;
@@ -607,8 +640,8 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
 #pragma omp parallel for schedule(static) if (g_threads > 1)
             for (int64_t i = 0; i < n; ++i) {
                 double s = 0.0;
-                for (int j = 0; j < k; ++j) s = fma(V[(size_t)j * n + i], y[j], s);
-                x[i] = x[i] + s;
+                for (int j = 0; j < k; ++j) s = fma((double)V[(size_t)j * n + i], y[j], s);
+                x[i] = (real)((double)x[i] + s);
             }
         }
         orc_spmv(n, crow, col, val, x, b, res);
@@ -617,7 +650,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const double *
         {
             const int use = res_norm > ORC_EPS;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
-            for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / res_norm : 0.0;
+            for (int64_t i = 0; i < n; ++i) res[i] = use ? res[i] / (real)res_norm : (real)0;
             if (!use) res_norm = 0.0;
         }
         ++cycles;

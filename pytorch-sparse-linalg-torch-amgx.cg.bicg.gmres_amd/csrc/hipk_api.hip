@@ -193,9 +193,9 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     }
     if (prof) prof->after(stream);
     if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
-        hipk_tile_combine_kernel<<<a.g, HIPK_THREADS, 0, stream>>>(
+        hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
             (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
-            a.part1, ntiles, a.ch / 256, a.stop_it, a.it);
+            a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
     }
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;

@@ -35,6 +35,36 @@ __device__ __forceinline__ void hipk_st(T *__restrict__ p, int64_t i, int nv,
     }
 }
 
+// Non-temporal variants: streams that are dead after this access should not occupy the Infinity Cache.
+template <typename T>
+__device__ __forceinline__ void hipk_ld_nt_vec(const T *__restrict__ p, int64_t i, int nv, T (&out)[hipk_vec<T>::VEC]) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (nv == VEC) {
+        typedef T native_t __attribute__((ext_vector_type(hipk_vec<T>::VEC)));
+        const native_t v = __builtin_nontemporal_load((const native_t *)(p + i));
+        const T *vp = (const T *)&v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = vp[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = (k < nv) ? p[i + k] : (T)0;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void hipk_st_nt_vec(T *__restrict__ p, int64_t i, int nv, const T (&in)[hipk_vec<T>::VEC]) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (nv == VEC) {
+        typedef T native_t __attribute__((ext_vector_type(hipk_vec<T>::VEC)));
+        native_t v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = in[k];
+        __builtin_nontemporal_store(v, (native_t *)(p + i));
+    } else {
+        for (int k = 0; k < nv; ++k) p[i + k] = in[k];
+    }
+}
+
 // Iterate the calling thread's elements of chunk c in reduction-spec order.
 // f(int64_t i, int nv): i = first element, nv = valid elements (1..VEC).
 template <typename T, typename F>

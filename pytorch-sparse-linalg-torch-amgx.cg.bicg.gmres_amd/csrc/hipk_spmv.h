@@ -12,8 +12,8 @@
 //   * x is gathered (L2/Infinity Cache hits: XCD-aware tile placement), the PRODUCTS go
 //     to LDS, thread t then sums row t's products from LDS in CSR order (rows longer than
 //     HIPK_LONG_ROW are summed by a whole wavefront, lanes strided, fixed tree);
-//   * thread t writes y[t] and forms w_t*y_t / y_t*y_t; the 256 values are folded with the
-//     spec tree into one TILE partial; a tiny second kernel folds the tile partials of each
+//   * thread t writes y[t] and forms w_t*y_t / y_t*y_t; the 256 values are folded (shuffle tree per
+//     wavefront, then ((s0+s1)+(s2+s3))) into one TILE partial; a tiny second kernel folds the tile partials of each
 //     reduction chunk into the chunk partial the consumers expect ("tiled dot" spec, mirrored
 //     by oracle/krylov_oracle.c).  8 workgroups per CU are resident (11 KB LDS, ~40 VGPRs):
 //     latency is hidden by occupancy, not by a software pipeline (measured both, profiles/).
@@ -232,35 +232,66 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
         if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
     }
     if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+        // tile partial = ((s0 + s1) + (s2 + s3)), s_w = wavefront w's 64 values folded by v[l] += v[l+s], s = 32..1:
+        // shuffles only, one barrier per tile
+        __shared__ double wsum[2][HIPK_THREADS / 64];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            d0 = d0 + __shfl_down(d0, s);
+            d1 = d1 + __shfl_down(d1, s);
+        }
+        if (lane == 0) {
+            wsum[0][wave] = d0;
+            wsum[1][wave] = d1;
+        }
         __syncthreads();
-        hipk_block_sum2(d0, d1, (double *)prod);
         if (t == 0) {
-            if (mode & HIPK_SPMV_DOT_W) a.tpart0[tile] = d0;
-            if (mode & HIPK_SPMV_DOT_YY) a.tpart1[tile] = d1;
+            if (mode & HIPK_SPMV_DOT_W) a.tpart0[tile] = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]);
+            if (mode & HIPK_SPMV_DOT_YY) a.tpart1[tile] = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
         }
     }
 }
 
-// chunk partial c = spec fold of the tile partials of chunk c (tiles_per_chunk = CH / 256)
+// chunk partial c = spec fold of the tile partials of chunk c (tiles_per_chunk = CH / 256).
+// One WAVEFRONT per chunk (4 chunks per workgroup, no barriers): lane l plays the spec's virtual threads
+// l, l+64, l+128, l+192 (each takes partials t, t+256, .. ascending), then the tree 128, 64, 32..1.
+__device__ __forceinline__ double hipk_wave_fold(const double *__restrict__ tp, int cnt, int lane) {
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = lane + 64 * j;
+        double acc = 0.0;
+        for (int i = t; i < cnt; i += HIPK_THREADS) acc = acc + tp[i];
+        a[j] = acc;
+    }
+    a[0] = a[0] + a[2];  // s = 128
+    a[1] = a[1] + a[3];
+    double v = a[0] + a[1];  // s = 64
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_down(v, s);
+    return v;  // valid in lane 0
+}
+
 static __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_combine_kernel(const double *__restrict__ tp0,
-                                                                         const double *__restrict__ tp1,
-                                                                         double *__restrict__ part0,
-                                                                         double *__restrict__ part1, int ntiles,
-                                                                         int tiles_per_chunk,
-                                                                         const int64_t *__restrict__ stop_it,
-                                                                         int64_t it) {
+                                                                                const double *__restrict__ tp1,
+                                                                                double *__restrict__ part0,
+                                                                                double *__restrict__ part1, int ntiles,
+                                                                                int tiles_per_chunk, int nchunks,
+                                                                                const int64_t *__restrict__ stop_it,
+                                                                                int64_t it) {
     if (stop_it != nullptr && it >= *stop_it) return;
-    __shared__ double sbuf[HIPK_THREADS];
-    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (HIPK_THREADS / 64) + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
     const int first = c * tiles_per_chunk;
     const int cntt = (ntiles - first < tiles_per_chunk) ? ntiles - first : tiles_per_chunk;
     if (tp0 != nullptr) {
-        const double r = hipk_reduce_parts(tp0 + first, cntt, sbuf);
-        if (threadIdx.x == 0) part0[c] = r;
+        const double r = hipk_wave_fold(tp0 + first, cntt, lane);
+        if (lane == 0) part0[c] = r;
     }
     if (tp1 != nullptr) {
-        const double r = hipk_reduce_parts(tp1 + first, cntt, sbuf);
-        if (threadIdx.x == 0) part1[c] = r;
+        const double r = hipk_wave_fold(tp1 + first, cntt, lane);
+        if (lane == 0) part1[c] = r;
     }
 }
 #endif

@@ -179,3 +179,62 @@ def test_gmres_vs_oracle_and_reference(hipk, oracle, r):
     x_ref = d[r["tag"] + "_x"]
     tol = kw.get("tol", 1e-5)
     assert np.linalg.norm(x - x_ref) <= max(1e-8, 50 * tol) * np.linalg.norm(x_ref)
+
+
+# ---------------------------------------------------------------- mid-size systems: still bit-exact vs the oracle
+def _csr_np(A):
+    Ac = A.cpu()
+    return Ac.crow_indices().numpy(), Ac.col_indices().numpy(), Ac.values().numpy()
+
+
+def test_cg_n1m_bit_exact_vs_oracle(hipk, oracle):
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    nx = 1000
+    A = create_poisson_2d_csr(nx, nx, device=DEV)
+    b = torch.ones(nx * nx, dtype=torch.float64, device=DEV)
+    x, info = cg(A, b, tol=1e-6)
+    st = get_last_stats()
+    oracle.set_threads(16)
+    ref = oracle.cg(*_csr_np(A), np.ones(nx * nx), tol=1e-6)
+    oracle.set_threads(1)
+    assert info == ref.info == 0 and st.iterations == ref.iterations
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+
+
+def test_bicgstab_convdiff_512_bit_exact_vs_oracle(hipk, oracle):
+    """BASELINE config 3 shape (nonsymmetric convection-diffusion, b = A randn) at nx = 512."""
+    from pytorch_sparse_solver.module_a import bicgstab, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
+    nx = 512
+    A = create_convdiff_2d_csr(nx, nx, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    xt = torch.randn(nx * nx, dtype=torch.float64, generator=g)
+    crow, col, val = _csr_np(A)
+    b = oracle.spmv(crow, col, val, xt.numpy())
+    x, info = bicgstab(A, torch.from_numpy(b).to(DEV), tol=1e-6)
+    st = get_last_stats()
+    oracle.set_threads(16)
+    ref = oracle.bicgstab(crow, col, val, b, tol=1e-6)
+    oracle.set_threads(1)
+    assert info == ref.info == 0 and st.iterations == ref.iterations and st.breakdown == ref.breakdown == 0
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert st.residual_norm <= 1e-6 * st.b_norm
+
+
+@pytest.mark.parametrize("method", ["batched", "incremental"])
+def test_gmres_ldc_nx100_bit_exact_vs_oracle(hipk, oracle, method):
+    """BASELINE config 4: LDC pressure matrix at the example's default nx = 100, gmres(tol=1e-10, maxiter=1000,
+    restart=30) as ldc_solver_module_a.py:21 calls it; RHS = a consistent (zero-sum) random field."""
+    from pytorch_sparse_solver.module_a import get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_ldc_pressure_csr
+    nx = 100
+    A = create_ldc_pressure_csr(nx, device=DEV)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(nx * nx)
+    b -= b.mean()
+    x, info = gmres(A, torch.from_numpy(b).to(DEV), tol=1e-10, maxiter=1000, restart=30, solve_method=method)
+    st = get_last_stats()
+    ref = oracle.gmres(*_csr_np(A), b, tol=1e-10, maxiter=1000, restart=30, solve_method=method, gpu_tolerances=True)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert np.array_equal(x.cpu().numpy(), ref.x)
