@@ -83,12 +83,25 @@ def lib():
         L.orc_bicgstab.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_gmres.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                 ctypes.c_int, ctypes.c_int, sp]
+        # fp32-storage variant (same source compiled with -DORC_F32): vectors/values float, dots and scalars fp64
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.orc32_dot.argtypes = [i64, fp, fp]
+        L.orc32_dot.restype = ctypes.c_double
+        L.orc32_dot_tiled.argtypes = [i64, fp, fp]
+        L.orc32_dot_tiled.restype = ctypes.c_double
+        L.orc32_spmv.argtypes = [i64, ip, ip, fp, fp, fp, fp]
+        L.orc32_cg.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc32_bicgstab.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc32_gmres.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
+                                  ctypes.c_int, ctypes.c_int, sp]
+        L.orc32_set_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
 
 def set_threads(t: int) -> None:
     lib().orc_set_threads(int(t))
+    lib().orc32_set_threads(int(t))
 
 
 def _d(a):
@@ -208,6 +221,71 @@ def gmres(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=No
     rc = lib().orc_gmres(b.size, _i(crow), _i(col), _d(val), _d(b), _d(x), float(tol), float(atol), int(restart),
                          -1 if maxiter is None else int(maxiter), method, 1 if gpu_tolerances else 0,
                          ctypes.byref(st))
+    if rc != 0:
+        raise ValueError("oracle gmres supports 1 <= restart <= 31")
+    return _result(x, st)
+
+
+# ---------------------------------------------------------------------------------------------- fp32 storage
+def _f(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def dot32(a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc32_dot(a.size, _f(a), _f(b)))
+
+
+def dot_tiled32(a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc32_dot_tiled(a.size, _f(a), _f(b)))
+
+
+def spmv32(crow, col, val, x, bsub=None) -> np.ndarray:
+    crow, col = np.ascontiguousarray(crow, dtype=np.int32), np.ascontiguousarray(col, dtype=np.int32)
+    val, x = _f32(val), _f32(x)
+    y = np.empty(crow.size - 1, dtype=np.float32)
+    if bsub is not None:
+        bsub = _f32(bsub)
+    lib().orc32_spmv(y.size, _i(crow), _i(col), _f(val), _f(x), _f(bsub) if bsub is not None else None, _f(y))
+    return y
+
+
+def _prep32(crow, col, val, b, x0):
+    crow, col = np.ascontiguousarray(crow, dtype=np.int32), np.ascontiguousarray(col, dtype=np.int32)
+    val, b = _f32(val), _f32(b)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float32, copy=True)
+    return crow, col, val, b, x
+
+
+def cg32(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    crow, col, val, b, x = _prep32(crow, col, val, b, x0)
+    st = _Stats()
+    lib().orc32_cg(b.size, _i(crow), _i(col), _f(val), _f(b), _f(x), float(tol), float(atol),
+                   -1 if maxiter is None else int(maxiter), ctypes.byref(st))
+    return _result(x, st)
+
+
+def bicgstab32(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    crow, col, val, b, x = _prep32(crow, col, val, b, x0)
+    st = _Stats()
+    lib().orc32_bicgstab(b.size, _i(crow), _i(col), _f(val), _f(b), _f(x), float(tol), float(atol),
+                         -1 if maxiter is None else int(maxiter), ctypes.byref(st))
+    return _result(x, st)
+
+
+def gmres32(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=None, solve_method="batched",
+            gpu_tolerances=False) -> OracleResult:
+    crow, col, val, b, x = _prep32(crow, col, val, b, x0)
+    st = _Stats()
+    method = {"batched": 0, "incremental": 1}[solve_method]
+    rc = lib().orc32_gmres(b.size, _i(crow), _i(col), _f(val), _f(b), _f(x), float(tol), float(atol), int(restart),
+                           -1 if maxiter is None else int(maxiter), method, 1 if gpu_tolerances else 0,
+                           ctypes.byref(st))
     if rc != 0:
         raise ValueError("oracle gmres supports 1 <= restart <= 31")
     return _result(x, st)

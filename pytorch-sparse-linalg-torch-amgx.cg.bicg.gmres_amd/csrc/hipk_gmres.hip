@@ -26,6 +26,7 @@
 #define HIPK_GM_MAXM 31
 #define HIPK_GM_LDH 32
 #define HIPK_EPS64 2.220446049250313e-16
+#define HIPK_EPS32 1.1920928955078125e-07
 #define HIPK_INV_SQRT2 0.7071067811865476
 
 struct hipk_gm_scal {
@@ -183,17 +184,17 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
 
 // second CGS pass iff ||r|| < ||q|| / sqrt(2)  (TSL:313-326), norms guarded as `_safe_normalize`
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_scal *__restrict__ scal, int k, int g,
-                                                                      const double *__restrict__ part_qq) {
+                                                                      const double *__restrict__ part_qq, double eps) {
     if (k >= scal->stop_step) return;
     __shared__ double sbuf[HIPK_THREADS];
     const double qq = hipk_reduce_parts(part_qq, g, sbuf);
     if (threadIdx.x == 0) {
         double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
-        if (!(qnorm > HIPK_EPS64)) qnorm = 0.0;
+        if (!(qnorm > eps)) qnorm = 0.0;
         double rr = 0.0;
         for (int j = 0; j <= k; ++j) rr = fma(scal->rvec[j], scal->rvec[j], rr);
         double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
-        if (!(rnorm > HIPK_EPS64)) rnorm = 0.0;
+        if (!(rnorm > eps)) rnorm = 0.0;
         scal->qnorm = qnorm;
         scal->pass2 = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1 : 0;
     }
@@ -223,15 +224,15 @@ __device__ __forceinline__ void hipk_givens(double a, double b, double &cs, doub
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     int64_t n, int ch, int g, hipk_gm_scal *__restrict__ scal, int k, T *__restrict__ w,
-    const double *__restrict__ part_qq, const double *__restrict__ part_ww) {
+    const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps) {
     if (k >= scal->stop_step) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double qq, ww;
     hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
     double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
     double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
-    if (!(norm0 > HIPK_EPS64)) norm0 = 0.0;
-    const double thr = HIPK_EPS64 * norm0;
+    if (!(norm0 > eps)) norm0 = 0.0;
+    const double thr = eps * norm0;
     const bool use = norm1 > thr;
     const T nrm = (T)norm1;
     hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
@@ -339,12 +340,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_resnorm_kernel(int64_t n
                                                                        hipk_gm_scal *__restrict__ scal,
                                                                        T *__restrict__ v0,
                                                                        const double *__restrict__ part_res,
-                                                                       const double *__restrict__ part_bb) {
+                                                                       const double *__restrict__ part_bb, double eps) {
     __shared__ double sbuf[2 * HIPK_THREADS];
     double res2, bs;
     hipk_reduce_parts2(part_res, part_bb, g, res2, bs, sbuf);
     const double norm = sqrt(res2 < 0.0 ? 0.0 : res2);
-    const bool use = norm > HIPK_EPS64;
+    const bool use = norm > eps;
     const T nrm = (T)norm;
     hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
@@ -473,6 +474,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
     T *V = (T *)vbase;
     T *tmp = (T *)(vbase + (size_t)(m + 1) * vec);
     const int incremental = (prm->gmres_method == HIPK_GMRES_INCREMENTAL) ? 1 : 0;
+    // guards (`_safe_normalize`, breakdown threshold) use the eps of the working dtype, as torch.finfo(dtype) would
+    const double eps_t = (sizeof(T) == 8) ? HIPK_EPS64 : HIPK_EPS32;
     const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;  // TSL:719-721
 
     hipk_event_pair whole;
@@ -502,7 +505,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
     if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
     if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) return rc;
     ++matvecs;
-    hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb);
+    hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb, eps_t);
     HIPK_CHECK_HIP(hipGetLastError());
     double head[2];
     HIPK_CHECK_HIP(hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream));
@@ -512,7 +515,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
     const double b_norm = hipk_norm_from_sq(bs);
 
     // TSL:735-753 (python floats become fp32 tensors; python max() keeps a float a float)
-    const double eps = (A->dtype == HIPK_F64) ? HIPK_EPS64 : HIPK_EPS64;  // fp32 extension keeps the fp64 floor
+    const double eps = HIPK_EPS64;  // the absolute floor keeps the fp64 eps also for fp32 storage
     const double sq = sqrt((double)n);
     const double cand = (prm->gpu_tolerances ? 1e-12 : 1e-14) * sq;
     const double adaptive = (cand > prm->tol) ? cand : (double)(float)prm->tol;
@@ -543,14 +546,14 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
             sw.it = k;
             if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq);
+                if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
                 hipk_gm_multidot_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
                                                                                part_md);
                 hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
                 hipk_gm_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_qq);
             }
             hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, k, w, part_qq,
-                                                                            part_ww);
+                                                                            part_ww, eps_t);
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -579,7 +582,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
         }
         if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) break;
         ++matvecs;
-        hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb);
+        hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb, eps_t);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) {
             hipk_set_error("hipk_gmres_solve: HIP failure at the end of a restart cycle");

@@ -238,3 +238,55 @@ def test_gmres_ldc_nx100_bit_exact_vs_oracle(hipk, oracle, method):
     ref = oracle.gmres(*_csr_np(A), b, tol=1e-10, maxiter=1000, restart=30, solve_method=method, gpu_tolerances=True)
     assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
     assert np.array_equal(x.cpu().numpy(), ref.x)
+
+
+# ---------------------------------------------------------------- fp32 storage (extension)
+def _dev_csr32(d):
+    n = int(d["n"])
+    return torch.sparse_csr_tensor(torch.from_numpy(d["crow"]).long(), torch.from_numpy(d["col"]).long(),
+                                   torch.from_numpy(d["val"].astype(np.float32)), size=(n, n)).to(DEV)
+
+
+@pytest.mark.parametrize("case", ["poisson_nx64", "convdiff_nx32", "ldc_nx32_step0", "spd_n100", "poisson_17x13"])
+def test_fp32_spmv_and_dots_bit_exact(hipk, oracle, case):
+    d = load_case(case)
+    h = hipk.handle_for(_dev_csr32(d))
+    rng = np.random.default_rng(8)
+    n = int(d["n"])
+    x, w = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    y_ref = oracle.spmv32(d["crow"], d["col"], d["val"], x)
+    y, dt = hipk.spmv_dot(h, torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV))
+    assert np.array_equal(y.cpu().numpy(), y_ref)
+    assert dt.item() == oracle.dot_tiled32(w, y_ref)
+    assert hipk.dot(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)).item() == oracle.dot32(x, w)
+
+
+@pytest.mark.parametrize("case,solver,kw", [
+    ("poisson_nx64", "cg", {"tol": 1e-4}),
+    ("poisson_17x13", "cg", {"tol": 1e-4}),
+    ("spd_n100", "cg", {"tol": 1e-5}),
+    ("convdiff_nx64", "bicgstab", {"tol": 1e-4}),
+    ("ldc_nx32_step1", "bicgstab", {"tol": 1e-4, "maxiter": 1000}),
+    ("ldc_nx32_step0", "gmres", {"tol": 1e-4, "restart": 30, "maxiter": 1000}),
+    ("ldc_nx16_step1", "gmres", {"tol": 1e-4, "restart": 30, "maxiter": 1000, "solve_method": "incremental"}),
+    ("convdiff_nx32", "gmres", {"tol": 1e-4, "restart": 10}),
+])
+def test_fp32_solves_bit_exact_vs_fp32_oracle(hipk, oracle, case, solver, kw):
+    """fp32 A selects fp32 storage (reference: RuntimeError); b is cast to fp32, x returned in fp32.
+    BASELINE config 4 ('gmres(restart=30) ... fp32') is the LDC case here."""
+    from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats, gmres
+    d = load_case(case)
+    A = _dev_csr32(d)
+    b32 = d["b"].astype(np.float32)
+    x, info = {"cg": cg, "bicgstab": bicgstab, "gmres": gmres}[solver](A, torch.from_numpy(d["b"]).to(DEV), **kw)
+    st = get_last_stats()
+    okw = dict(kw)
+    if solver == "gmres":
+        okw["gpu_tolerances"] = True
+    ref = getattr(oracle, solver + "32")(d["crow"], d["col"], d["val"], b32, **okw)
+    assert x.dtype == torch.float32
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert st.residual_norm == ref.residual_norm
+    tol = kw["tol"]
+    assert st.residual_norm <= (20 if case.startswith("ldc") else 2) * tol * st.b_norm
