@@ -86,6 +86,10 @@ from pytorch_sparse_solver.module_a import cg, get_last_stats
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 prob = DistPoissonProblem(nx_per_rank=96, ny=64, rank=0, world=1, device=torch.device("cuda", 0))
+assert prob.comm is not None, "direct RCCL communicator expected on the nccl backend"
+# exercise the grouped send/recv wrapper (a rank never sends to itself in the solver): self exchange of 3 + 2 doubles
+a = torch.arange(5, dtype=torch.float64, device="cuda:0"); r = torch.zeros(5, dtype=torch.float64, device="cuda:0")
+prob.comm.all_to_all(r, a, [5], [5]); torch.cuda.synchronize(); assert torch.equal(r, a)
 x, info, st = dist_cg(prob, tol=1e-8)
 A = create_poisson_2d_csr(96, 64, device="cuda:0")
 xr, info_r = cg(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8)
