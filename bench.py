@@ -176,6 +176,25 @@ def main():
         ms = e0.elapsed_time(e1) / 200
         spmv_standalone = {"us": ms * 1e3, "GB/s": spmv_bytes / (ms * 1e-3) / 1e9, "reps": 200}
 
+    if world > 1:
+        # roofline leg at N > 1: this rank's local SpMV (no communication), HIP events on the launch stream
+        xe = prob.ops.zeros(max(prob.n_ext, 1))
+        xe.normal_(generator=torch.Generator(device=dev).manual_seed(rank))
+        ye = prob.ops.zeros(prob.n_local)
+        for _ in range(10):
+            prob.ops.spmv(prob.A, xe, ye)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            prob.ops.spmv(prob.A, xe, ye)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 100
+        ach = prob.spmv_bytes / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "hipk_spmv_kernel<double,1280,*> on rank 0's row block, stand-alone",
+                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "avg_launch_us": ms * 1e3, "launches_timed": 100, "algorithmic_bytes_per_launch": prob.spmv_bytes}
+
     if rank == 0:
         out = {
             "metric": "cg_iters_per_sec",

@@ -234,8 +234,12 @@ def _cache_key(A: torch.Tensor):
         parts = (A.crow_indices(), A.col_indices(), A.values())
     elif A.layout == torch.sparse_coo:
         parts = (A._indices(), A._values())
-    else:
+    elif A.layout == torch.sparse_csc:          # e.g. the transpose view of a CSR matrix (adjoint solves)
+        parts = (A.ccol_indices(), A.row_indices(), A.values())
+    elif A.layout == torch.strided:
         parts = (A,)
+    else:
+        raise HipkError(f"unsupported tensor layout {A.layout}")
     return (str(A.layout), tuple(A.shape), str(A.device), A.dtype) + tuple(
         (p.data_ptr(), p._version, p.numel()) for p in parts)
 

@@ -368,7 +368,10 @@ def _use_implicit_diff(A: Any, b: Any) -> bool:
 
 
 def _transpose_of(A: torch.Tensor) -> torch.Tensor:
-    return A.T.conj() if torch.is_complex(A) else A.T
+    """A^H for the adjoint solve (TSL:1245). `.T` is not implemented for sparse-compressed CUDA tensors, so sparse
+    layouts go through `.t()` (CSR -> CSC view of the same data; the handle builder converts it back to CSR once)."""
+    At = A.T if A.layout == torch.strided else A.t()
+    return At.conj() if torch.is_complex(A) else At
 
 
 class ImplicitAdjointFunction(torch.autograd.Function):
@@ -446,7 +449,9 @@ def bicgstab(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[
 
 
 def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
-    if _fast_ok(A, b, x0, M):
+    # the device-resident GMRES keeps at most 31 basis vectors (H in a fixed device block); larger Krylov
+    # spaces take the generic path (documented routing rule, not a fallback on failure)
+    if _fast_ok(A, b, x0, M) and 1 <= restart <= 31:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method)
     P = _Flat(A, b, x0, M)
     if maxiter is None:

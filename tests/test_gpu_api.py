@@ -1,0 +1,149 @@
+"""GPU tests of the public API surface around the fast path: reference test recipes on the device
+(test_module_a.py:93-315, test_gpu_validation.py:128-217, test_unified.py:90-228), generic path on CUDA tensors,
+autograd through the fast path, handle cache reuse (LDC caller pattern), C-ABI error paths."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _spd(n, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(n, n, dtype=torch.float64, generator=g)
+    return (G @ G.T + n * torch.eye(n, dtype=torch.float64)).to(DEV), g
+
+
+def test_reference_recipes_dense_inputs_on_gpu(hipk):
+    """The reference feeds DENSE matrices: they are converted to CSR once and take the HIP path."""
+    from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats, gmres
+    n = 100
+    A = (2 * torch.eye(n, dtype=torch.float64) - torch.diag(torch.ones(n - 1, dtype=torch.float64), 1)
+         - torch.diag(torch.ones(n - 1, dtype=torch.float64), -1)).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    b = A @ torch.randn(n, dtype=torch.float64, generator=g).to(DEV)
+    x, info = cg(A, b, tol=1e-10, maxiter=1000)                          # test_module_a.py:93-124
+    assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-6
+    assert type(get_last_stats()).__name__ == "SolveStats"                # the HIP path ran, not the generic one
+    B = A + 0.1 * torch.randn(n, n, dtype=torch.float64, generator=g).to(DEV) + 5 * torch.eye(n, dtype=torch.float64).to(DEV)
+    b2 = B @ torch.randn(n, dtype=torch.float64, generator=g).to(DEV)
+    x, info = bicgstab(B, b2, tol=1e-10, maxiter=1000)                   # :126-161
+    assert info == 0 and (torch.norm(b2 - B @ x) / torch.norm(b2)).item() < 1e-5
+    C = torch.randn(n, n, dtype=torch.float64, generator=g).to(DEV) + 10 * torch.eye(n, dtype=torch.float64).to(DEV)
+    b3 = C @ torch.randn(n, dtype=torch.float64, generator=g).to(DEV)
+    for m in ("batched", "incremental"):
+        x, info = gmres(C, b3, tol=1e-10, maxiter=1000, restart=30, solve_method=m)   # :163-195, :273-315
+        assert info == 0 and (torch.norm(b3 - C @ x) / torch.norm(b3)).item() < 1e-5
+    # COO input and fp32 right-hand side promotion
+    x, info = cg(A.to_sparse_coo(), b.float(), tol=1e-6)
+    assert info == 0 and x.dtype == torch.float64
+
+
+def test_generic_path_on_cuda_tensors_matches_fast_path(hipk):
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    A, g = _spd(80)
+    b = torch.randn(80, dtype=torch.float64, generator=g).to(DEV)
+    x_fast, info_fast = cg(A, b, tol=1e-10)
+    it_fast = get_last_stats().iterations
+    x_gen, info_gen = cg(lambda v: A @ v, b, tol=1e-10)                  # callable operator: generic path, torch ops on GPU
+    assert type(get_last_stats()).__name__ == "_GenericStats" and get_last_stats().iterations == it_fast
+    assert info_fast == info_gen == 0 and torch.allclose(x_fast, x_gen, rtol=1e-10, atol=1e-12)
+    dinv = 1.0 / torch.diagonal(A)
+    x_m, info_m = cg(A, b, tol=1e-10, M=lambda v: dinv * v)             # preconditioner: generic path
+    assert info_m == 0 and torch.allclose(x_m, x_fast, rtol=1e-7, atol=1e-9)
+
+
+def test_autograd_on_the_fast_path(hipk):
+    """test_gpu_validation.py:166-215: gradients exist, are finite and non-zero; here also checked against A^-T 1."""
+    from pytorch_sparse_solver.module_a import (bicgstab, bicgstab_differentiable, cg, cg_differentiable, gmres,
+                                                gmres_differentiable)
+    A, g = _spd(96)
+    expect = torch.linalg.solve(A.T, torch.ones(96, dtype=torch.float64, device=DEV))
+    for fn, kw in ((cg, {}), (bicgstab, {}), (gmres, {"restart": 30})):
+        b = torch.randn(96, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
+        x, info = fn(A.to_sparse_csr(), b, tol=1e-10, **kw)
+        x.sum().backward()
+        assert info == 0 and torch.allclose(b.grad, expect, rtol=1e-6, atol=1e-9)
+    for fn in (cg_differentiable, bicgstab_differentiable, gmres_differentiable):
+        b = torch.randn(96, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
+        fn(A, b, tol=1e-10).sum().backward()
+        assert torch.isfinite(b.grad).all() and b.grad.abs().sum() > 0
+
+
+def test_dispatcher_on_gpu(hipk):
+    from pytorch_sparse_solver import SparseSolver, solve
+    A, g = _spd(100)
+    b = torch.randn(100, dtype=torch.float64, generator=g).to(DEV)
+    s = SparseSolver()
+    x, r = s.solve(A, b, method="cg", backend="module_a", tol=1e-8)      # test_unified.py:90-127
+    assert r.converged and r.residual < 1e-5 and r.backend == "module_a" and r.iterations is None
+    for m in ("cg", "bicgstab", "gmres"):
+        x, r = solve(A.to_sparse_csr(), b, method=m, tol=1e-6)
+        assert r.converged and r.residual <= 1e-4
+
+
+def test_handle_cache_reuse_for_repeated_solves(hipk):
+    """The LDC stepper pattern (ldc_solver_common.py:185-201): one matrix, many right-hand sides."""
+    from pytorch_sparse_solver.module_a import bicgstab
+    from pytorch_sparse_solver.utils.matrix_utils import create_ldc_pressure_csr
+    hipk.clear_cache()
+    A = create_ldc_pressure_csr(48, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    handles = set()
+    for _ in range(4):
+        b = torch.randn(48 * 48, dtype=torch.float64, generator=g).to(DEV)
+        b -= b.mean()
+        x, info = bicgstab(A, b, tol=1e-10, maxiter=1000)
+        assert info == 0
+        handles.add(id(hipk.handle_for(A)))
+    assert len(handles) == 1 and len(hipk._CACHE) == 1
+    A.values().mul_(2.0)                                                  # in-place change => new handle
+    assert id(hipk.handle_for(A)) not in handles
+
+
+def test_c_abi_error_paths(hipk):
+    L = hipk.lib()
+    x = torch.zeros(64, dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, dtype=torch.float64, device=DEV)
+    sc = hipk.scratch(DEV)
+    assert L.hipk_dot(63, x.data_ptr() + 8, x.data_ptr(), hipk.HIPK_F64, out.data_ptr(), sc.data_ptr(), None) == -3   # HIPK_ERR_ALIGN
+    assert b"aligned" in L.hipk_last_error()
+    assert L.hipk_dot(-1, x.data_ptr(), x.data_ptr(), hipk.HIPK_F64, out.data_ptr(), sc.data_ptr(), None) == -1       # HIPK_ERR_ARG
+    assert L.hipk_dot(64, x.data_ptr(), x.data_ptr(), 7, out.data_ptr(), sc.data_ptr(), None) == -4                   # HIPK_ERR_UNSUPPORTED
+    h = ctypes.c_void_p()
+    crow = torch.tensor([0, 1, 2], device=DEV)
+    col = torch.tensor([0, 1], device=DEV)
+    val = torch.ones(2, dtype=torch.float64, device=DEV)
+    assert L.hipk_csr_create(ctypes.byref(h), 2, 2, 2, crow.data_ptr(), col.data_ptr(), 3, val.data_ptr(), 1, None) == -1  # idx_bytes
+    assert L.hipk_csr_create(ctypes.byref(h), 2, 2, 2, crow.data_ptr(), col.data_ptr(), 8, val.data_ptr(), 1, None) == 0
+    prm, st = hipk.Params(), hipk.Stats()
+    prm.tol, prm.maxiter = 1e-6, -1
+    b = torch.ones(2, dtype=torch.float64, device=DEV)
+    xs = torch.zeros(2, dtype=torch.float64, device=DEV)
+    work = torch.empty(16, dtype=torch.uint8, device=DEV)
+    assert L.hipk_cg_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), 16, ctypes.byref(prm), ctypes.byref(st), None) == -5  # workspace
+    prm.restart = 40
+    wb = L.hipk_gmres_work_bytes(2, 31, 1)
+    work = torch.empty(wb, dtype=torch.uint8, device=DEV)
+    assert L.hipk_gmres_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st), None) == -4  # restart > 31
+    assert L.hipk_cg_solve(h, b.data_ptr(), b.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st), None) == -1  # aliasing
+    L.hipk_csr_destroy(h)
+    # shape errors through the Python surface keep the reference's exception types
+    from pytorch_sparse_solver.module_a import cg
+    with pytest.raises(ValueError, match="square matrix"):
+        cg(torch.zeros(3, 4, dtype=torch.float64, device=DEV), torch.zeros(4, dtype=torch.float64, device=DEV))
+    with pytest.raises(ValueError, match="matching shapes"):
+        cg(torch.eye(4, dtype=torch.float64, device=DEV), torch.ones(4, dtype=torch.float64, device=DEV),
+           x0=torch.zeros(3, dtype=torch.float64, device=DEV))
+
+
+def test_restart_above_31_uses_reference_semantics(hipk):
+    """The HIP GMRES holds at most 31 basis vectors; larger restarts must still work (generic path)."""
+    from pytorch_sparse_solver.module_a import gmres
+    A, g = _spd(60)
+    b = torch.randn(60, dtype=torch.float64, generator=g).to(DEV)
+    x, info = gmres(A, b, tol=1e-10, restart=40)
+    assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-8
