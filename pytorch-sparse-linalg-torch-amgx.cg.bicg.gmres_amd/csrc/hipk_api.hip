@@ -117,7 +117,7 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     if (e == hipSuccess) e = hipMalloc((void **)&h->crow, sizeof(int) * (size_t)(n_rows + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
     if (e == hipSuccess) e = hipMalloc((void **)&bad, 3 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->tile_part, sizeof(double) * 2 * (size_t)((n_rows + 255) / 256 + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tile_part, sizeof(double) * 8 * (size_t)((n_rows + 255) / 256 + 1));
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_poll, 16 * sizeof(int64_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 3 * sizeof(int), stream);
     if (e == hipSuccess) {
@@ -178,7 +178,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     const int ntiles = (int)((a.n + 255) / 256);
     const int grid = ((ntiles + 7) >> 3) << 3;
     a.tpart0 = h->tile_part;
-    a.tpart1 = h->tile_part + ntiles;
+    a.tpart1 = h->tile_part + 4 * (size_t)ntiles;
     if (prof) prof->before(stream);
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)

@@ -82,7 +82,7 @@ struct hipk_csr_s {
     int device;
     // pinned host word block used by solves to poll the device stop word
     int64_t *host_poll;  // hipHostMalloc, 16 x int64
-    double *tile_part;   // device, 2 x ceil(n_rows/256): per-tile partials of the fused dots
+    double *tile_part;   // device, 2 x 4 x ceil(n_rows/256): per-wavefront sums of the fused dots (4 per tile)
     int max_row_len;     // structure analysis at creation
     int max_tile_nnz;    //   (tile = 256 consecutive rows)
 };
