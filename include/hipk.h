@@ -175,12 +175,14 @@ size_t hipk_cg_scal_bytes(void); /* device scalar block: {gamma[2], atol2, bs, r
 int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rr,
                   const double *part_bb, const void *r, void *p, int dtype, double tol, double atol,
                   int64_t maxiter, hipk_stream_t stream);
+/* r -= alpha Ap, partials of <r,r>   (alpha = gamma / sum(part_pAp)) */
 int hipk_cg_update(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
-                   const double *part_pAp, const void *p, const void *Ap, void *x, void *r,
-                   double *part_rr_out, int dtype, hipk_stream_t stream);
+                   const double *part_pAp, const void *Ap, void *r, double *part_rr_out, int dtype,
+                   hipk_stream_t stream);
+/* x += alpha p; p = r + beta p; gamma <- <r,r>; stop test   (the x update rides on the pass over p) */
 int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it,
-                      int64_t maxiter, const double *part_rr, const void *r, void *p, int dtype,
-                      hipk_stream_t stream);
+                      int64_t maxiter, const double *part_pAp, const double *part_rr, const void *r, void *p,
+                      void *x, int dtype, hipk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -3,12 +3,12 @@
 // Restates `_isolve(_cg_solve)` (TSL:806-856, 968-1016) for M = identity as three
 // kernels per iteration, all scalars living in device memory:
 //   K1 spmv+dot   Ap = A p, partials of <p,Ap>            (TSL:845-846)   B_spmv
-//   K2 update     alpha = gamma/<p,Ap>; x += alpha p; r -= alpha Ap; partials of <r,r>
-//                                                          (TSL:846-850)   48 n bytes
-//   K3 direction  beta = <r,r>/gamma; p = r + beta p; gamma <- <r,r>; stop test
-//                                                          (TSL:851-853, 841) 24 n bytes
-// = B_spmv + 72 n bytes per iteration, the compulsory traffic between the two global
-// reductions.  Every workgroup re-derives alpha/beta from the chunk
+//   K2 update     alpha = gamma/<p,Ap>; r -= alpha Ap; partials of <r,r>
+//                                                          (TSL:846, 848-850)   24 n bytes
+//   K3 direction  alpha again (same partials, same bits), beta = <r,r>/gamma; x += alpha p; p = r + beta p;
+//                 gamma <- <r,r>; stop test                (TSL:847, 851-853, 841) 40 n bytes
+// = B_spmv + 64 n bytes per iteration: the x update rides on the pass that already streams p, 8 n bytes
+// less than the 72 n of SURVEY 8d; the arithmetic per element is unchanged.  Every workgroup re-derives alpha/beta from the chunk
 // partials of the previous kernel with the fixed tree, so no grid barrier, no atomics
 // and no host round trip are needed; the host only polls `stop_it` every check_every
 // iterations and the kernels of iterations >= stop_it return immediately, so the
@@ -61,8 +61,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
-    const double *__restrict__ part_pAp, const T *__restrict__ p, const T *__restrict__ Ap, T *__restrict__ x,
-    T *__restrict__ r, double *__restrict__ part_rr) {
+    const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr) {
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[HIPK_THREADS];
     const double pAp = hipk_reduce_parts(part_pAp, g, sbuf);
@@ -72,20 +71,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     double acc = 0.0;
     hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T pv[VEC], av[VEC], xv[VEC], rv[VEC];
-        hipk_ld<T>(p, i, nv, pv);
+        T av[VEC], rv[VEC];
         hipk_ld<T>(Ap, i, nv, av);
-        hipk_ld<T>((const T *)x, i, nv, xv);
         hipk_ld<T>((const T *)r, i, nv, rv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const T m0 = alpha * pv[k];
-            xv[k] = xv[k] + m0;  // TSL:847
             const T m1 = alpha * av[k];
             rv[k] = rv[k] - m1;  // TSL:848
             if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);  // TSL:850
         }
-        hipk_st<T>(x, i, nv, xv);
         hipk_st<T>(r, i, nv, rv);
     });
     acc = hipk_block_sum(acc, sbuf);
@@ -95,23 +89,30 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
-    const double *__restrict__ part_rr, const T *__restrict__ r, T *__restrict__ p) {
+    const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
+    T *__restrict__ p, T *__restrict__ x) {
     if (it >= scal->stop_it) return;
-    __shared__ double sbuf[HIPK_THREADS];
-    const double rr = hipk_reduce_parts(part_rr, g, sbuf);
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double pAp, rr;
+    hipk_reduce_parts2(part_pAp, part_rr, g, pAp, rr, sbuf);
     const double gamma = scal->gamma[it & 1];
-    const T beta = (T)(rr / gamma);  // TSL:851
+    const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
+    const T beta = (T)(rr / gamma);    // TSL:851
     const int c = blockIdx.x;
     hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T rv[VEC], pv[VEC];
+        T rv[VEC], pv[VEC], xv[VEC];
         hipk_ld<T>(r, i, nv, rv);
         hipk_ld<T>((const T *)p, i, nv, pv);
+        hipk_ld<T>((const T *)x, i, nv, xv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * pv[k];
+            xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
             const T m = beta * pv[k];
-            pv[k] = rv[k] + m;  // TSL:852
+            pv[k] = rv[k] + m;   // TSL:852
         }
+        hipk_st<T>(x, i, nv, xv);
         hipk_st<T>(p, i, nv, pv);
     });
     if (c == 0 && threadIdx.x == 0) {
@@ -215,10 +216,9 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         for (; it < end; ++it) {
             sa.it = it;
             if ((rc = hipk_launch_spmv(A, sa, stream, &prof)) != HIPK_OK) return rc;
-            hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, p, Ap, x, r,
-                                                                         part_b);
-            hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_b,
-                                                                            r, p);
+            hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
+            hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
+                                                                            part_b, r, p, x);
         }
         HIPK_CHECK_HIP(hipGetLastError());
         HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
@@ -306,43 +306,43 @@ extern "C" int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *s
 }
 
 extern "C" int hipk_cg_update(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
-                              const double *part_pAp, const void *p, const void *Ap, void *x, void *r,
-                              double *part_rr_out, int dtype, hipk_stream_t stream_) {
+                              const double *part_pAp, const void *Ap, void *r, double *part_rr_out, int dtype,
+                              hipk_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
     if (rc != HIPK_OK) return rc;
-    HIPK_REQUIRE(scal_dev && part_pAp && p && Ap && x && r && part_rr_out, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(scal_dev && part_pAp && Ap && r && part_rr_out, HIPK_ERR_ARG, "null argument");
     const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
     if (dtype == HIPK_F64)
         hipk_cg_update_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
                                                                           (const hipk_cg_scal *)scal_dev, it, part_pAp,
-                                                                          (const double *)p, (const double *)Ap, (double *)x,
-                                                                          (double *)r, part_rr_out);
+                                                                          (const double *)Ap, (double *)r, part_rr_out);
     else
         hipk_cg_update_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
                                                                          (const hipk_cg_scal *)scal_dev, it, part_pAp,
-                                                                         (const float *)p, (const float *)Ap, (float *)x,
-                                                                         (float *)r, part_rr_out);
+                                                                         (const float *)Ap, (float *)r, part_rr_out);
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;
 }
 
 extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it,
-                                 int64_t maxiter, const double *part_rr, const void *r, void *p, int dtype,
-                                 hipk_stream_t stream_) {
+                                 int64_t maxiter, const double *part_pAp, const double *part_rr, const void *r, void *p,
+                                 void *x, int dtype, hipk_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
     if (rc != HIPK_OK) return rc;
-    HIPK_REQUIRE(scal_dev && part_rr && r && p, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(scal_dev && part_pAp && part_rr && r && p && x, HIPK_ERR_ARG, "null argument");
     const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
     if (dtype == HIPK_F64)
         hipk_cg_direction_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
-                                                                             (hipk_cg_scal *)scal_dev, it, maxiter, part_rr,
-                                                                             (const double *)r, (double *)p);
+                                                                             (hipk_cg_scal *)scal_dev, it, maxiter,
+                                                                             part_pAp, part_rr, (const double *)r,
+                                                                             (double *)p, (double *)x);
     else
         hipk_cg_direction_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
-                                                                            (hipk_cg_scal *)scal_dev, it, maxiter, part_rr,
-                                                                            (const float *)r, (float *)p);
+                                                                            (hipk_cg_scal *)scal_dev, it, maxiter,
+                                                                            part_pAp, part_rr, (const float *)r,
+                                                                            (float *)p, (float *)x);
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;
 }

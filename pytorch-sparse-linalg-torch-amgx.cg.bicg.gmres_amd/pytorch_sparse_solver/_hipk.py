@@ -146,8 +146,8 @@ def lib():
     L.hipk_gather.argtypes = [i64, vp, vp, vp, i32, vp]
     L.hipk_cg_scal_bytes.restype = ctypes.c_size_t
     L.hipk_cg_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
-    L.hipk_cg_update.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp]
-    L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, i32, vp]
+    L.hipk_cg_update.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, vp, i32, vp]
+    L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, i32, vp]
     _lib = L
     return L
 

@@ -160,15 +160,15 @@ class HipOps:
                                            r.data_ptr(), p.data_ptr(), self.k.HIPK_F64, float(tol), float(atol),
                                            maxiter, self._s()), "hipk_cg_start")
 
-    def cg_update(self, n, ch, g, scal, it, part_pAp, p, Ap, x, r, part_out):
-        self.k._check(self.L.hipk_cg_update(n, ch, g, scal.data_ptr(), it, part_pAp.data_ptr(), p.data_ptr(),
-                                            Ap.data_ptr(), x.data_ptr(), r.data_ptr(), part_out.data_ptr(),
-                                            self.k.HIPK_F64, self._s()), "hipk_cg_update")
+    def cg_update(self, n, ch, g, scal, it, part_pAp, Ap, r, part_out):
+        self.k._check(self.L.hipk_cg_update(n, ch, g, scal.data_ptr(), it, part_pAp.data_ptr(), Ap.data_ptr(),
+                                            r.data_ptr(), part_out.data_ptr(), self.k.HIPK_F64, self._s()),
+                      "hipk_cg_update")
 
-    def cg_direction(self, n, ch, g, scal, it, maxiter, part_rr, r, p):
-        self.k._check(self.L.hipk_cg_direction(n, ch, g, scal.data_ptr(), it, maxiter, part_rr.data_ptr(),
-                                               r.data_ptr(), p.data_ptr(), self.k.HIPK_F64, self._s()),
-                      "hipk_cg_direction")
+    def cg_direction(self, n, ch, g, scal, it, maxiter, part_pAp, part_rr, r, p, x):
+        self.k._check(self.L.hipk_cg_direction(n, ch, g, scal.data_ptr(), it, maxiter, part_pAp.data_ptr(),
+                                               part_rr.data_ptr(), r.data_ptr(), p.data_ptr(), x.data_ptr(),
+                                               self.k.HIPK_F64, self._s()), "hipk_cg_direction")
 
     def read_scal(self, scal):
         h = scal.cpu()
@@ -356,10 +356,10 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
                 ops.spmv(prob.A, p, Ap, MODE_DOT_W, w=p, part0=part_loc, part1=spare, stop=stop, it=it)
             gather_parts(g_pAp)
             if n:
-                ops.cg_update(n, ch, G, scal, it, g_pAp, p, Ap, x, r, part_loc)
+                ops.cg_update(n, ch, G, scal, it, g_pAp, Ap, r, part_loc)
             gather_parts(g_rr)
             if n:
-                ops.cg_direction(n, ch, G, scal, it, maxiter, g_rr, r, p)
+                ops.cg_direction(n, ch, G, scal, it, maxiter, g_pAp, g_rr, r, p, x)
             it += 1
         stop_it = _agree_stop(prob, scal)
         if stop_it <= it:

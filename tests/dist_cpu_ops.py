@@ -68,23 +68,25 @@ class OracleOps:
         scal[0], scal[1], scal[2], scal[3] = gamma0, 0.0, atol2, bs
         self.stop_word(scal)[0] = 0 if (maxiter <= 0 or gamma0 <= atol2) else INT64_MAX
 
-    def cg_update(self, n, ch, g, scal, it, part_pAp, p, Ap, x, r, part_out):
+    def cg_update(self, n, ch, g, scal, it, part_pAp, Ap, r, part_out):
         if it >= int(self.stop_word(scal).item()):
             return
         pAp = O.reduce_parts(part_pAp.numpy()[:g])
         alpha = float(scal[it & 1].item()) / pAp
-        xn, rn, pn, an = x.numpy(), r.numpy(), p.numpy(), Ap.numpy()
-        xn[:n] = xn[:n] + alpha * pn[:n]
+        rn, an = r.numpy(), Ap.numpy()
         rn[:n] = rn[:n] - alpha * an[:n]
         q = O.dot_parts_ch(rn[:n], rn[:n], ch)
         part_out[:q.size] = torch.from_numpy(q)
 
-    def cg_direction(self, n, ch, g, scal, it, maxiter, part_rr, r, p):
+    def cg_direction(self, n, ch, g, scal, it, maxiter, part_pAp, part_rr, r, p, x):
         if it >= int(self.stop_word(scal).item()):
             return
+        pAp = O.reduce_parts(part_pAp.numpy()[:g])
         rr = O.reduce_parts(part_rr.numpy()[:g])
-        beta = rr / float(scal[it & 1].item())
-        pn, rn = p.numpy(), r.numpy()
+        gamma = float(scal[it & 1].item())
+        alpha, beta = gamma / pAp, rr / gamma
+        pn, rn, xn = p.numpy(), r.numpy(), x.numpy()
+        xn[:n] = xn[:n] + alpha * pn[:n]
         pn[:n] = rn[:n] + beta * pn[:n]
         scal[(it + 1) & 1] = rr
         if it + 1 >= maxiter or rr <= float(scal[2].item()):
