@@ -157,10 +157,19 @@ def main():
         xx = torch.zeros_like(b)
         pst = _hipk.solve("cg", h, b, xx, tol=args.tol, atol=0.0, maxiter=256, profile=True)
         ach = spmv_bytes / (pst.spmv_ms_avg * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed PMC passes (collected separately with rocprofv3 --pmc)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_spmv.json")))
+            if nx == NX:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials), "
                                           "timed inside the CG loop",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": None, "avg_launch_us": pst.spmv_ms_avg * 1e3, "launches_timed": pst.spmv_profiled,
+                "traffic": traffic, "traffic_source": "profiles/r01g_pmc_spmv.json (2*FETCH_SIZE + WRITE_SIZE)",
+                "avg_launch_us": pst.spmv_ms_avg * 1e3, "launches_timed": pst.spmv_profiled,
+                "event_pair_overhead_us_subtracted": pst.event_overhead_ms * 1e3,
                 "algorithmic_bytes_per_launch": spmv_bytes}
         g = torch.Generator(device=dev).manual_seed(0)
         xr = torch.randn(nx * nx, dtype=torch.float64, device=dev, generator=g)

@@ -77,8 +77,9 @@ typedef struct {
     double threshold;       /* the value residual_norm was compared against                         */
     double recurrence_rs;   /* last recurrence <r,r> (CG: gamma)                                    */
     double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
-    double spmv_ms_avg;     /* average SpMV kernel time when params.profile=1, else 0               */
+    double spmv_ms_avg;     /* average SpMV kernel time when params.profile=1 (event-pair overhead removed) */
     int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
+    double event_overhead_ms; /* elapsed time of an EMPTY event pair on the stream (calibration), already subtracted */
 } hipk_stats;
 
 int hipk_version(void);

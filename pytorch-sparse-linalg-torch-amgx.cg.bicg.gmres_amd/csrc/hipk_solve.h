@@ -23,12 +23,14 @@ struct hipk_event_pair {
 // bench.py can quote the kernel's duration in its real cache context.
 struct hipk_spmv_profiler {
     static constexpr int kMax = 256;
+    static constexpr int kCal = 32;  // empty pairs recorded at the end: what an event pair costs by itself
     bool on;
     std::vector<hipEvent_t> ev;
     int used = 0;
+    bool calibrated = false;
     explicit hipk_spmv_profiler(bool enable) : on(enable) {
         if (!on) return;
-        ev.resize(2 * kMax, nullptr);
+        ev.resize(2 * (kMax + kCal), nullptr);
         for (auto &e : ev)
             if (hipEventCreate(&e) != hipSuccess) {
                 on = false;
@@ -48,11 +50,32 @@ struct hipk_spmv_profiler {
             ++used;
         }
     }
+    // record kCal back-to-back empty pairs (call once, before the final synchronise)
+    void calibrate(hipStream_t s) {
+        if (!on || calibrated) return;
+        for (int k = 0; k < kCal; ++k) {
+            (void)hipEventRecord(ev[2 * (kMax + k)], s);
+            (void)hipEventRecord(ev[2 * (kMax + k) + 1], s);
+        }
+        calibrated = true;
+    }
     // valid: number of leading bracketed launches that did real work
     hipError_t collect(hipk_stats *st, int64_t valid = INT64_MAX) {
         st->spmv_ms_avg = 0.0;
         st->spmv_profiled = 0;
+        st->event_overhead_ms = 0.0;
         if (!on) return hipSuccess;
+        double over = 0.0;
+        if (calibrated) {
+            for (int k = 0; k < kCal; ++k) {
+                float ms = 0.f;
+                hipError_t e = hipEventElapsedTime(&ms, ev[2 * (kMax + k)], ev[2 * (kMax + k) + 1]);
+                if (e != hipSuccess) return e;
+                over += ms;
+            }
+            over /= kCal;
+        }
+        st->event_overhead_ms = over;
         const int cnt = (int)((valid < used) ? valid : used);
         double sum = 0.0;
         for (int k = 0; k < cnt; ++k) {
@@ -61,7 +84,7 @@ struct hipk_spmv_profiler {
             if (e != hipSuccess) return e;
             sum += ms;
         }
-        if (cnt > 0) st->spmv_ms_avg = sum / cnt;
+        if (cnt > 0) st->spmv_ms_avg = sum / cnt - over;
         st->spmv_profiled = cnt;
         return hipSuccess;
     }

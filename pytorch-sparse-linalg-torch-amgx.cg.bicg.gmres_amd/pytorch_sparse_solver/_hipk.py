@@ -64,6 +64,7 @@ class Stats(ctypes.Structure):
         ("solve_ms", ctypes.c_double),
         ("spmv_ms_avg", ctypes.c_double),
         ("spmv_profiled", ctypes.c_int64),
+        ("event_overhead_ms", ctypes.c_double),
     ]
 
 
@@ -83,6 +84,7 @@ class SolveStats:
     solve_ms: float
     spmv_ms_avg: float
     spmv_profiled: int
+    event_overhead_ms: float = 0.0
 
 
 class HipkError(RuntimeError):
@@ -334,7 +336,8 @@ def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Par
     return SolveStats(method=method, iterations=st.iterations, matvecs=st.matvecs, info=st.info,
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
-                      spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled)
+                      spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
+                      event_overhead_ms=st.event_overhead_ms)
 
 
 def solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,

@@ -94,6 +94,21 @@ class HaloPlan:
         self.n_send = int(self.send_idx.numel())
         if self.n_send:
             assert int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < part.n_local
+        # all-gather form of the same exchange (the halo can then ride with another all-gather):
+        # every rank contributes its packed send list padded to `slab` entries; ghost k of owner o sits at
+        # o*slab + (offset of my block in o's send list) + (k's index in my request to o)
+        t = torch.tensor([self.n_send], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self.slab = max(int(t.item()), 1)
+        my_off = torch.cumsum(torch.tensor([0] + self.send_splits[:-1], dtype=torch.int64, device=dev), 0)
+        their_off = torch.empty_like(my_off)                          # their_off[o] = where my block starts in o's list
+        dist.all_to_all_single(their_off, my_off, group=group)
+        if self.n_ghost:
+            first = torch.cumsum(torch.tensor([0] + self.recv_splits[:-1], dtype=torch.int64, device=dev), 0)
+            idx_in_req = torch.arange(self.n_ghost, device=dev) - first[owners]
+            self.ghost_src = (owners * self.slab + their_off[owners] + idx_in_req).to(torch.int32)
+        else:
+            self.ghost_src = torch.zeros(0, dtype=torch.int32, device=dev)
 
 
 class HipOps:
@@ -226,6 +241,16 @@ class RcclComm:
         self._ck(self.L.ncclAllGather(src.data_ptr(), dst.data_ptr(), src.numel(), self.DOUBLE, self.comm,
                                       self._stream()), "ncclAllGather")
 
+    def all_gather2(self, dst_a, src_a, dst_b, src_b) -> None:
+        """Two all-gathers in one RCCL group (aggregated into a single launch)."""
+        s = self._stream()
+        self._ck(self.L.ncclGroupStart(), "ncclGroupStart")
+        self._ck(self.L.ncclAllGather(src_a.data_ptr(), dst_a.data_ptr(), src_a.numel(), self.DOUBLE, self.comm, s),
+                 "ncclAllGather")
+        self._ck(self.L.ncclAllGather(src_b.data_ptr(), dst_b.data_ptr(), src_b.numel(), self.DOUBLE, self.comm, s),
+                 "ncclAllGather")
+        self._ck(self.L.ncclGroupEnd(), "ncclGroupEnd")
+
     def all_to_all(self, recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits) -> None:
         """Grouped ncclSend/ncclRecv of contiguous slabs (doubles), zero-length pairs skipped."""
         s = self._stream()
@@ -275,6 +300,8 @@ class DistProblem:
         # algorithmic bytes of this rank's SpMV (SURVEY 8d formula on the local block)
         self.spmv_bytes = self.nnz_local * 12 + (part.n_local + 1) * 4 + 2 * part.n_local * 8
         self.send_buf = ops.empty(max(self.plan.n_send, 1))
+        self.slab_loc = ops.zeros(self.plan.slab)
+        self.slab_all = ops.zeros(self.plan.slab * part.world)
         # per-iteration collectives: direct RCCL when the ranks are GPUs of an 'nccl' group, else torch.distributed
         self.comm = None
         import os
@@ -308,6 +335,23 @@ class DistProblem:
         else:
             dist.all_gather_into_tensor(dst, src, group=self.group)
 
+    def gather_parts_and_halo(self, dst_parts: torch.Tensor, src_parts: torch.Tensor, v_ext: torch.Tensor) -> None:
+        """All-gather the chunk partials AND the halo of v in one step: pack v's entries the peers need, gather both
+        buffers (one RCCL group), unpack the received slabs into v_ext's halo tail."""
+        pl = self.plan
+        if pl.n_send:
+            self.ops.gather(pl.send_idx, v_ext, self.slab_loc)
+        self._gather2(dst_parts, src_parts, self.slab_all, self.slab_loc)
+        if pl.n_ghost:
+            self.ops.gather(pl.ghost_src, self.slab_all, v_ext[self.n_local:self.n_local + pl.n_ghost])
+
+    def _gather2(self, dst_a, src_a, dst_b, src_b) -> None:
+        if self.comm is not None:
+            self.comm.all_gather2(dst_a, src_a, dst_b, src_b)
+        else:
+            dist.all_gather_into_tensor(dst_a, src_a, group=self.group)
+            dist.all_gather_into_tensor(dst_b, src_b, group=self.group)
+
     def agree_min(self, value: int) -> int:
         if self.part.world == 1:
             return value
@@ -323,11 +367,12 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
     ops, part, group = prob.ops, prob.part, prob.group
     n, ch, G, per, world = part.n_local, part.ch, part.g, part.per, part.world
     maxiter = 10 * part.n_global if maxiter is None else int(maxiter)
-    x = ops.zeros(max(prob.n_ext, 1))                      # x and p carry the halo tail
+    n_ext = max(prob.n_ext, 1)
+    x = ops.zeros(n_ext)                                    # x, p and r carry the halo tail
     if x0_local is not None:
         x[:n] = x0_local
-    p = ops.zeros(max(prob.n_ext, 1))
-    r, Ap = ops.zeros(max(n, 1)), ops.zeros(max(n, 1))
+    p, r = ops.zeros(n_ext), ops.zeros(n_ext)
+    Ap = ops.zeros(max(n, 1))
     part_loc = ops.zeros(per)                               # this rank's chunk partials (zero padded)
     spare = ops.zeros(per)
     g_pAp, g_rr, g_bb = ops.zeros(world * per), ops.zeros(world * per), ops.zeros(world * per)
@@ -337,7 +382,9 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
     def gather_parts(dst):
         prob.gather_parts(dst, part_loc)
 
-    # r0 = b - A x0, <r0,r0>; <b,b>   (TSL:815-826)
+    # r0 = b - A x0, <r0,r0>; <b,b>   (TSL:815-826).  Halos of x and r0 are exchanged explicitly once;
+    # inside the loop the halo of r rides with the <r,r> partials and every rank forms the halo entries of
+    # p = r + beta p and x += alpha p itself (same operands, same bits as the owner).
     prob.halo_exchange(x)
     if n:
         ops.spmv(prob.A, x, r, MODE_RESID | MODE_DOT_YY, bsub=prob.b, part0=spare, part1=part_loc)
@@ -345,21 +392,24 @@ def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: 
     if n:
         ops.dot_parts(n, ch, prob.b, prob.b, part_loc)
     gather_parts(g_bb)
+    prob.halo_exchange(r)
     if n:
         ops.cg_start(n, ch, G, scal, g_rr, g_bb, r, p, tol, atol, maxiter)
+    if prob.plan.n_ghost:
+        p[n:n + prob.plan.n_ghost] = r[n:n + prob.plan.n_ghost]          # p0 = r0 on the halo as well
+    n_dir = prob.n_ext if n else 0
     it, stop_it = 0, None
     while it < maxiter:
         end = min(maxiter, it + check_every)
         while it < end:
-            prob.halo_exchange(p)
             if n:
                 ops.spmv(prob.A, p, Ap, MODE_DOT_W, w=p, part0=part_loc, part1=spare, stop=stop, it=it)
             gather_parts(g_pAp)
             if n:
                 ops.cg_update(n, ch, G, scal, it, g_pAp, Ap, r, part_loc)
-            gather_parts(g_rr)
+            prob.gather_parts_and_halo(g_rr, part_loc, r)
             if n:
-                ops.cg_direction(n, ch, G, scal, it, maxiter, g_pAp, g_rr, r, p, x)
+                ops.cg_direction(n_dir, ch, G, scal, it, maxiter, g_pAp, g_rr, r, p, x)
             it += 1
         stop_it = _agree_stop(prob, scal)
         if stop_it <= it:

@@ -50,6 +50,10 @@ class HostStagedProblem(DistProblem):
         dist.all_gather_into_tensor(d, src.cpu())
         dst.copy_(d)
 
+    def _gather2(self, dst_a, src_a, dst_b, src_b):
+        self.gather_parts(dst_a, src_a)
+        self.gather_parts(dst_b, src_b)
+
     def agree_min(self, value):
         t = torch.tensor([value], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -74,7 +78,7 @@ def main():
         dev = torch.device("cuda", 0)
         prob = HostStagedProblem.__new__(HostStagedProblem)
         ops = HipOps(dev)
-        for name in ("col_local", "send_idx"):
+        for name in ("col_local", "send_idx", "ghost_src"):
             setattr(plan, name, getattr(plan, name).to(dev))
         prob.part, prob.ops, prob.group, prob.plan = part, ops, None, plan
         prob.n_local, prob.n_ext, prob.nnz_local = part.n_local, part.n_local + plan.n_ghost, int(lval.numel())
@@ -83,6 +87,8 @@ def main():
             if part.n_local else None
         prob.spmv_bytes = 0
         prob.send_buf = ops.empty(max(plan.n_send, 1))
+        prob.slab_loc, prob.slab_all = ops.zeros(plan.slab), ops.zeros(plan.slab * world)
+        prob.comm = None
     else:
         prob = DistProblem(lc, lcol, lval, lb, part, OracleOps())
     x_loc, info, st = dist_cg(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)

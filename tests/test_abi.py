@@ -44,7 +44,7 @@ def test_python_geometry_matches_library_and_oracle(oracle):
 
 def test_structs_match_header_layout():
     from pytorch_sparse_solver import _hipk
-    assert ctypes.sizeof(_hipk.Params) == 48 and ctypes.sizeof(_hipk.Stats) == 88
+    assert ctypes.sizeof(_hipk.Params) == 48 and ctypes.sizeof(_hipk.Stats) == 96
 
 
 def test_cuda_tensor_path_fails_loudly_without_library(monkeypatch):
