@@ -48,9 +48,14 @@ class RowPartition:
     n_global: int
     world: int
     rank: int
+    force_ch: int = 0      # tests / experiments: emulate the chunk size of a larger global problem (2048 * 2^k)
 
     def __post_init__(self):
         self.ch, self.g = chunk_geometry(self.n_global)
+        if self.force_ch:
+            assert self.force_ch >= self.ch and self.force_ch % BASE_CHUNK == 0
+            self.ch = self.force_ch
+            self.g = max(1, (self.n_global + self.ch - 1) // self.ch)
         self.per = (self.g + self.world - 1) // self.world          # chunks per rank (last ranks may have fewer)
         self.c0 = min(self.g, self.rank * self.per)
         self.c1 = min(self.g, (self.rank + 1) * self.per)
@@ -449,11 +454,11 @@ class DistPoissonProblem(DistProblem):
     grid lines [r nx_per_rank, (r+1) nx_per_rank) -- requires ny * nx_per_rank to be chunk aligned, else
     the chunk-aligned partition of RowPartition is used as is."""
 
-    def __init__(self, nx_per_rank: int, ny: int, rank: int, world: int, device, group=None):
+    def __init__(self, nx_per_rank: int, ny: int, rank: int, world: int, device, group=None, force_ch: int = 0):
         from .utils.matrix_utils import stencil5_csr_components
         ops = HipOps(device)
         nx = nx_per_rank * world
-        part = RowPartition(nx * ny, world, rank)
+        part = RowPartition(nx * ny, world, rank, force_ch)
         crow, col, val = stencil5_csr_components(nx, ny, 4.0, -1.0, -1.0, -1.0, -1.0, row_begin=part.row0,
                                                  row_end=part.row1, device=device)
         b = torch.ones(part.n_local, dtype=torch.float64, device=device)
