@@ -338,3 +338,57 @@ def test_full_size_against_reference_fixture(hipk, r):
         assert st.matvecs == r["matvecs"] and rel_s <= 1e-10 and rel_n <= 1e-10
     else:
         assert rel_s <= 1e-3 and rel_n <= 1e-6
+
+
+# ---------------------------------------------------------------- breakdowns and degenerate inputs
+def _small_csr(A):
+    import scipy.sparse as sp
+    S = sp.csr_matrix(np.asarray(A, dtype=np.float64))
+    S.sort_indices()
+    At = torch.sparse_csr_tensor(torch.from_numpy(S.indptr.astype(np.int64)), torch.from_numpy(S.indices.astype(np.int64)),
+                                 torch.from_numpy(S.data), size=S.shape).to(DEV)
+    return S, At
+
+
+@pytest.mark.parametrize("code", ["-10", "-11"])
+def test_bicgstab_breakdown_paths(hipk, oracle, code):
+    """tests/golden/bicgstab_breakdown.json: tiny systems on which the reference's BiCGStab breaks down
+    (rho: k = -10, TSL:902-904; omega: k = -11, TSL:934-936); x and info recorded from the reference."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from pytorch_sparse_solver.module_a import bicgstab, get_last_stats
+    d = json.load(open(os.path.join(GOLDEN, "bicgstab_breakdown.json")))[code]
+    S, A = _small_csr(d["A"])
+    b = np.array(d["b"])
+    x, info = bicgstab(A, torch.from_numpy(b).to(DEV), tol=1e-12, maxiter=200)
+    st = get_last_stats()
+    ref = oracle.bicgstab(S.indptr, S.indices, S.data, b, tol=1e-12, maxiter=200)
+    assert st.breakdown == ref.breakdown == int(code)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert info == d["ref_info"] and np.allclose(x.cpu().numpy(), d["ref_x"], rtol=1e-12, atol=1e-14)
+
+
+def test_degenerate_inputs_match_oracle_and_reference_behaviour(hipk, oracle):
+    from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats, gmres
+    S, A = _small_csr([[4., -1, 0], [-1, 4, -1], [0, -1, 4]])
+    ones = torch.ones(3, dtype=torch.float64, device=DEV)
+    for fn in (cg, bicgstab, gmres):
+        x, info = fn(A, torch.zeros(3, dtype=torch.float64, device=DEV))          # b = 0: x = 0, info 0 (reference: same)
+        assert info == 0 and torch.equal(x, torch.zeros_like(x)) and get_last_stats().iterations == 0
+    for fn, ofn in ((cg, oracle.cg), (bicgstab, oracle.bicgstab)):
+        x, info = fn(A, ones, maxiter=0)                                            # no iterations allowed
+        ref = ofn(S.indptr, S.indices, S.data, np.ones(3), maxiter=0)
+        assert info == ref.info == -1 and torch.equal(x, torch.zeros_like(x)) and get_last_stats().matvecs == ref.matvecs == 2
+    xs = torch.linalg.solve(A.to_dense(), ones)
+    x, info = cg(A, ones, x0=xs)                                                    # exact start: stops before the first SpMV
+    assert info == 0 and get_last_stats().iterations == 0 and torch.equal(x, xs)
+    big = torch.ones(6, dtype=torch.float64, device=DEV)
+    x, info = cg(A, big[::2], tol=1e-10)                                            # strided right-hand side
+    assert info == 0 and torch.allclose(A.to_dense() @ x, ones, rtol=1e-9)
+    # NaN in b: the recurrence never passes the stop test; capped by maxiter, info -1 (isnan branch of TSL:1013)
+    bn = ones.clone()
+    bn[1] = float("nan")
+    x, info = cg(A, bn, maxiter=5)
+    assert info == -1 and get_last_stats().iterations == 5 and torch.isnan(x).any()
