@@ -70,6 +70,14 @@ __global__ void hipk_narrow_check_kernel(const I *__restrict__ crow_in, const I 
     }
 }
 
+// rows with more than `cap` entries -> list (order irrelevant: each row is independent)
+__global__ void hipk_huge_rows_kernel(const int *__restrict__ crow, int64_t n_rows, int cap, int *__restrict__ list,
+                                      int *__restrict__ count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
+        if (crow[r + 1] - crow[r] > cap) list[atomicAdd(count, 1)] = (int)r;
+}
+
 extern "C" int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                                const void *crow_dev, const void *col_dev, int idx_bytes,
                                const void *val_dev, int dtype, hipk_stream_t stream_) {
@@ -148,6 +156,31 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     }
     h->max_row_len = bad3[1];
     h->max_tile_nnz = bad3[2];
+    // short-rowed matrix with a few rows beyond the LDS product buffer: list them for the row-per-wavefront pre-pass
+    const int cap = (dtype == HIPK_F64) ? 1280 : 2048;
+    if (n_rows > 0 && h->max_row_len > cap && nnz / n_rows < 48) {
+        const int64_t max_huge = nnz / cap + 1;
+        int *cnt = nullptr;
+        int cnt_h = 0;
+        e = hipMalloc((void **)&h->huge_rows, sizeof(int) * (size_t)max_huge);
+        if (e == hipSuccess) e = hipMalloc((void **)&cnt, sizeof(int));
+        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(int), stream);
+        if (e == hipSuccess) {
+            int grid = (int)((n_rows + 255) / 256);
+            if (grid > 4096) grid = 4096;
+            hipk_huge_rows_kernel<<<grid, 256, 0, stream>>>(h->crow, n_rows, cap, h->huge_rows, cnt);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&cnt_h, cnt, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (cnt) (void)hipFree(cnt);
+        if (e != hipSuccess) {
+            hipk_set_error("hipk_csr_create (huge rows): %s", hipGetErrorString(e));
+            hipk_csr_destroy(h);
+            return HIPK_ERR_HIP;
+        }
+        h->n_huge = cnt_h;
+    }
     *out = h;
     return HIPK_OK;
 }
@@ -157,6 +190,7 @@ extern "C" int hipk_csr_destroy(hipk_csr_t h) {
     if (h->crow) (void)hipFree(h->crow);
     if (h->col) (void)hipFree(h->col);
     if (h->tile_part) (void)hipFree(h->tile_part);
+    if (h->huge_rows) (void)hipFree(h->huge_rows);
     if (h->host_poll) (void)hipHostFree(h->host_poll);
     delete h;
     return HIPK_OK;
@@ -179,6 +213,39 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     const int grid = ((ntiles + 7) >> 3) << 3;
     a.tpart0 = h->tile_part;
     a.tpart1 = h->tile_part + 4 * (size_t)ntiles;
+    // long-row matrices (mean row length >= 48, or rows that do not fit the LDS product buffer): row per wavefront
+    const bool rowwave = h->n_rows > 0 && h->nnz / h->n_rows >= 48;
+    if (!rowwave && h->n_huge > 0) {
+        // pre-pass: the few rows that exceed the LDS product buffer, one wavefront each, raw sums into y
+        hipk_spmv_args ah = a;
+        ah.row_list = h->huge_rows;
+        ah.n_list = h->n_huge;
+        const int hgrid = (h->n_huge + 3) / 4;
+        if (h->dtype == HIPK_F64)
+            hipk_spmv_rowwave_kernel<double><<<hgrid, HIPK_THREADS, 0, stream>>>(ah);
+        else
+            hipk_spmv_rowwave_kernel<float><<<hgrid, HIPK_THREADS, 0, stream>>>(ah);
+    }
+    if (rowwave) {
+        const int rgrid = (int)((a.n + 3) / 4);
+        if (prof) prof->before(stream);
+        if (h->dtype == HIPK_F64)
+            hipk_spmv_rowwave_kernel<double><<<rgrid, HIPK_THREADS, 0, stream>>>(a);
+        else
+            hipk_spmv_rowwave_kernel<float><<<rgrid, HIPK_THREADS, 0, stream>>>(a);
+        if (prof) prof->after(stream);
+        if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+            if (h->dtype == HIPK_F64)
+                hipk_rowdot_kernel<double><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
+            else
+                hipk_rowdot_kernel<float><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
+            hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
+                (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+                a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
+        }
+        HIPK_CHECK_HIP(hipGetLastError());
+        return HIPK_OK;
+    }
     if (prof) prof->before(stream);
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)

@@ -83,6 +83,8 @@ struct hipk_csr_s {
     // pinned host word block used by solves to poll the device stop word
     int64_t *host_poll;  // hipHostMalloc, 16 x int64
     double *tile_part;   // device, 2 x 4 x ceil(n_rows/256): per-wavefront sums of the fused dots (4 per tile)
+    int *huge_rows;      // device, owned or null: rows with more entries than the LDS product buffer, handled by a
+    int n_huge;          //   row-per-wavefront pre-pass when the matrix as a whole is short-rowed
     int max_row_len;     // structure analysis at creation
     int max_tile_nnz;    //   (tile = 256 consecutive rows)
 };

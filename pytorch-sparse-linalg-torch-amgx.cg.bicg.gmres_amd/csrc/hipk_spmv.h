@@ -46,6 +46,8 @@ struct hipk_spmv_args {
     int64_t it;
     double *tpart0;  // tile partials (handle-owned scratch), filled by the launcher
     double *tpart1;
+    const int *row_list;  // row-per-wavefront kernel: process only these rows (null: all rows)
+    int n_list;
 };
 
 #ifdef __HIPCC__
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
     const int *__restrict__ col = a.col;
     const T *__restrict__ val = (const T *)a.val;
     const T *__restrict__ x = (const T *)a.x;
-    T *__restrict__ y = (T *)a.y;
+    T *y = (T *)a.y;  // not restrict: the general path reads pre-pass results from y before overwriting them
     const int mode = a.mode;
 
     const int64_t r0 = (int64_t)tile * HIPK_TILE;
@@ -184,16 +186,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
                 re = lo;
             }
             if (re == ra) {
-                // one row with more than CAP entries: a single wavefront streams it from memory,
-                // lanes strided by 64, same summation tree as a long LDS row
-                if (wave == 0) {
-                    const int g1 = crowL[ra + 1];
-                    T s = (T)0;
-                    for (int j = g0 + lane; j < g1; j += 64) s = s + hipk_ld_nt(val + j) * x[col[j]];
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
-                    if (lane == 0) ystage[ra] = s;
-                }
+                // one row with more than CAP entries: its sum was computed by the row-per-wavefront pre-pass
+                // (hipk_spmv_rowwave_kernel over hipk_csr_s::huge_rows) and sits in y
+                if (t == 0) ystage[ra] = y[r0 + ra];
                 __syncthreads();
                 ra += 1;
                 continue;
@@ -261,6 +256,75 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
             for (int s = 32; s >= 1; s >>= 1) d1 = d1 + __shfl_down(d1, s);
             if (lane == 0) a.tpart1[(size_t)tile * 4 + wave] = d1;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long-row matrices (dense-as-CSR -- what the reference's own tests and benchmark feed, SURVEY fact 2 --,
+// FEM blocks, power-law hubs): ROW PER WAVEFRONT.  Lanes stride over the row with coalesced col/val loads
+// (4 steps in flight), accumulate in ascending order and fold with v[l] += v[l+s], s = 32..1: the long-row
+// summation of the spec, so results are bit-identical to the tile kernel's.  Rows of <= HIPK_LONG_ROW entries
+// are summed in CSR order by lane 0 (spec for short rows).
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_rowwave_kernel(hipk_spmv_args a) {
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * (HIPK_THREADS / 64) + (threadIdx.x >> 6);
+    const bool listed = a.row_list != nullptr;
+    if (slot >= (listed ? (int64_t)a.n_list : a.n)) return;
+    const int64_t row = listed ? (int64_t)a.row_list[slot] : slot;
+    const int *__restrict__ col = a.col;
+    const T *__restrict__ val = (const T *)a.val;
+    const T *__restrict__ x = (const T *)a.x;
+    const int lo = a.crow[row], hi = a.crow[row + 1];
+    T s = (T)0;
+    if (hi - lo <= HIPK_LONG_ROW) {
+        if (lane == 0)
+            for (int j = lo; j < hi; ++j) s = s + val[j] * x[col[j]];
+    } else {
+        int j = lo + lane;
+        for (; j + 192 < hi; j += 256) {  // four strided steps in flight, added in ascending order
+            const int c0 = col[j], c1 = col[j + 64], c2 = col[j + 128], c3 = col[j + 192];
+            const T v0 = hipk_ld_nt(val + j), v1 = hipk_ld_nt(val + j + 64), v2 = hipk_ld_nt(val + j + 128),
+                    v3 = hipk_ld_nt(val + j + 192);
+            const T p0 = v0 * x[c0], p1 = v1 * x[c1], p2 = v2 * x[c2], p3 = v3 * x[c3];
+            s = s + p0;
+            s = s + p1;
+            s = s + p2;
+            s = s + p3;
+        }
+        for (; j < hi; j += 64) s = s + hipk_ld_nt(val + j) * x[col[j]];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
+    }
+    if (lane == 0) {
+        if (!listed && (a.mode & HIPK_SPMV_RESID)) s = ((const T *)a.bsub)[row] - s;  // pre-pass: raw sum, the tile kernel finishes
+        ((T *)a.y)[row] = s;
+    }
+}
+
+// fused-dot epilogue of the row-per-wavefront path: the tile kernel's per-wavefront sums, computed from y
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_rowdot_kernel(hipk_spmv_args a) {
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x;
+    const int64_t r = (int64_t)tile * HIPK_TILE + t;
+    double d0 = 0.0, d1 = 0.0;
+    if (r < a.n) {
+        const T out = ((const T *)a.y)[r];
+        if (a.mode & HIPK_SPMV_DOT_W) d0 = (double)((const T *)a.w)[r] * (double)out;
+        if (a.mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+    }
+    if (a.mode & HIPK_SPMV_DOT_W) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) d0 = d0 + __shfl_down(d0, s);
+        if (lane == 0) a.tpart0[(size_t)tile * 4 + wave] = d0;
+    }
+    if (a.mode & HIPK_SPMV_DOT_YY) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) d1 = d1 + __shfl_down(d1, s);
+        if (lane == 0) a.tpart1[(size_t)tile * 4 + wave] = d1;
     }
 }
 
