@@ -104,6 +104,23 @@ int64_t hipk_csr_nnz(hipk_csr_t h);
 /* Algorithmic bytes of one SpMV: nnz*(sizeof(val)+4)+(n+1)*4+2*n*sizeof(val). */
 int64_t hipk_csr_spmv_bytes(hipk_csr_t h);
 
+/* Which SpMV kernel family the structure analysis of hipk_csr_create selected.  All of them produce the same
+ * bits (one summation spec, oracle/krylov_oracle.c).
+ *   TILE_FAST : 256-row tiles, every tile fits the LDS product buffer and no row exceeds 32 entries
+ *   TILE      : 256-row tiles with the general path (long rows, dense tiles, huge-row pre-pass)
+ *   ROWWAVE   : row per wavefront (mean row length >= 48: dense-as-CSR, FEM blocks)
+ *   CODED     : the matrix has at most 256 distinct (col - row, value) pairs and short rows (finite-difference /
+ *               finite-volume stencils, e.g. matrix_utils.py:193-257 and ldc_solver_common.py:90-135): the handle
+ *               keeps one byte per entry + one byte per row + the dictionary and streams those instead of
+ *               col/val/crow.  The values are SNAPSHOTTED at creation (`val` must not change anyway, see above). */
+enum hipk_spmv_path { HIPK_PATH_TILE_FAST = 0, HIPK_PATH_TILE = 1, HIPK_PATH_ROWWAVE = 2, HIPK_PATH_CODED = 3 };
+int hipk_csr_spmv_path(hipk_csr_t h);
+/* mode 0: automatic (default); 1: never use the coded form (A/B measurements, parity tests).
+ * Environment: HIPK_SPMV_CODED=0 at creation time skips building the coded form altogether. */
+int hipk_csr_set_path(hipk_csr_t h, int mode);
+/* Bytes one SpMV has to move in the format the selected path streams (= hipk_csr_spmv_bytes unless CODED). */
+int64_t hipk_csr_format_bytes(hipk_csr_t h);
+
 /* ---- reduction geometry ------------------------------------------------------
  * Every dot/norm is a two-level fixed tree: the vector is cut in `count` chunks
  * of `chunk` elements (chunk = 2048 * 2^k, count <= 2048); see DESIGN.md. */

@@ -5,6 +5,8 @@
 #include "hipk_common.h"
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
+#include "hipk_coded.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -76,6 +78,86 @@ __global__ void hipk_huge_rows_kernel(const int *__restrict__ crow, int64_t n_ro
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
         if (crow[r + 1] - crow[r] > cap) list[atomicAdd(count, 1)] = (int)r;
+}
+
+
+// Try to build the coded form (hipk_coded.h).  Failure of any kind just leaves the handle on the plain kernels.
+template <typename T>
+static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
+    hipk_dict_table *tb = nullptr;
+    hipError_t e = hipMalloc((void **)&tb, sizeof(hipk_dict_table));
+    if (e != hipSuccess) return e;
+    struct guard {
+        hipk_dict_table *p;
+        ~guard() { (void)hipFree(p); }
+    } g{tb};
+    e = hipMemsetAsync(tb, 0, sizeof(hipk_dict_table), stream);
+    if (e != hipSuccess) return e;
+    int grid = (int)((h->n_rows + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipk_dict_insert_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows, tb);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipk_dict_table *ht = new hipk_dict_table;
+    struct hguard {
+        hipk_dict_table *p;
+        ~hguard() { delete p; }
+    } hg{ht};
+    e = hipMemcpyAsync(ht, tb, sizeof(hipk_dict_table), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (ht->overflow || ht->count > HIPK_CODED_MAX || ht->count <= 0) return hipSuccess;
+    // number the occupied slots; the order is irrelevant to the results (a lookup returns the exact pair)
+    int off_h[HIPK_CODED_MAX];
+    T val_h[HIPK_CODED_MAX];
+    memset(off_h, 0, sizeof(off_h));
+    memset(val_h, 0, sizeof(val_h));
+    int nc = 0;
+    for (int s = 0; s < HIPK_DICT_SLOTS; ++s) {
+        ht->slot_code[s] = 0;
+        if (ht->key[s] == 0) continue;
+        if (nc >= HIPK_CODED_MAX) return hipSuccess;
+        ht->slot_code[s] = nc;
+        off_h[nc] = ht->off[s];
+        if (sizeof(T) == 8) {
+            memcpy(&val_h[nc], &ht->bits[s], 8);
+        } else {
+            const unsigned int b32 = (unsigned int)ht->bits[s];
+            memcpy(&val_h[nc], &b32, 4);
+        }
+        ++nc;
+    }
+    if (nc != ht->count) return hipSuccess;  // a claimed slot whose count was not yet added cannot happen after the sync
+    e = hipMemcpyAsync(tb->slot_code, ht->slot_code, sizeof(ht->slot_code), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->nnz + 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->rowlen, (size_t)h->n_rows + 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->dict_off, sizeof(int) * HIPK_CODED_MAX);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->dict_val, sizeof(T) * HIPK_CODED_MAX);
+    if (e == hipSuccess) e = hipMemsetAsync(h->code + h->nnz, 0, 32, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->dict_off, off_h, sizeof(off_h), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->dict_val, val_h, sizeof(val_h), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        hipk_dict_encode_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows, tb,
+                                                                     h->code, h->rowlen);
+        e = hipGetLastError();
+    }
+    int fail = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&fail, &tb->fail, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // also keeps off_h / val_h alive until the copies are done
+    if (e != hipSuccess) return e;
+    if (!fail) h->n_codes = nc;
+    return hipSuccess;
+}
+
+static void hipk_drop_coded(hipk_csr_s *h) {
+    if (h->code) (void)hipFree(h->code);
+    if (h->rowlen) (void)hipFree(h->rowlen);
+    if (h->dict_off) (void)hipFree(h->dict_off);
+    if (h->dict_val) (void)hipFree(h->dict_val);
+    h->code = h->rowlen = nullptr;
+    h->dict_off = nullptr;
+    h->dict_val = nullptr;
+    h->n_codes = 0;
 }
 
 extern "C" int hipk_csr_create(hipk_csr_t *out, int64_t n_rows, int64_t n_cols, int64_t nnz,
@@ -181,6 +263,18 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         }
         h->n_huge = cnt_h;
     }
+    // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
+    h->coded_rows = 1;
+    if (const char *cr = getenv("HIPK_SPMV_CODED_ROWS")) {
+        const int v = atoi(cr);
+        if (v == 1 || v == 2 || v == 4) h->coded_rows = v;
+    }
+    const char *env = getenv("HIPK_SPMV_CODED");
+    if (n_rows > 0 && nnz > 0 && h->max_row_len <= HIPK_LONG_ROW && !(env && env[0] == '0')) {
+        e = (dtype == HIPK_F64) ? hipk_build_coded<double>(h, stream) : hipk_build_coded<float>(h, stream);
+        if (e != hipSuccess) (void)hipGetLastError();  // e.g. out of memory: stay on the plain kernels
+        if (h->n_codes == 0) hipk_drop_coded(h);
+    }
     *out = h;
     return HIPK_OK;
 }
@@ -191,6 +285,7 @@ extern "C" int hipk_csr_destroy(hipk_csr_t h) {
     if (h->col) (void)hipFree(h->col);
     if (h->tile_part) (void)hipFree(h->tile_part);
     if (h->huge_rows) (void)hipFree(h->huge_rows);
+    hipk_drop_coded(h);
     if (h->host_poll) (void)hipHostFree(h->host_poll);
     delete h;
     return HIPK_OK;
@@ -202,6 +297,27 @@ extern "C" int64_t hipk_csr_spmv_bytes(hipk_csr_t h) {
     if (!h) return -1;
     const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
     return h->nnz * (sv + 4) + (h->n_rows + 1) * 4 + 2 * h->n_rows * sv;
+}
+
+extern "C" int hipk_csr_spmv_path(hipk_csr_t h) {
+    if (!h) return -1;
+    if (h->n_rows > 0 && h->nnz / h->n_rows >= 48) return HIPK_PATH_ROWWAVE;
+    if (h->n_codes > 0 && h->path_override != 1) return HIPK_PATH_CODED;
+    const int cap = (h->dtype == HIPK_F64) ? 1280 : 2048;
+    return (h->max_tile_nnz <= cap && h->max_row_len <= HIPK_LONG_ROW) ? HIPK_PATH_TILE_FAST : HIPK_PATH_TILE;
+}
+extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
+    HIPK_REQUIRE(h != nullptr, HIPK_ERR_ARG, "null handle");
+    HIPK_REQUIRE(mode == 0 || mode == 1, HIPK_ERR_ARG, "mode must be 0 (auto) or 1 (plain CSR kernels only)");
+    h->path_override = mode;
+    return HIPK_OK;
+}
+extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
+    if (!h) return -1;
+    const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
+    if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED)  // code + rowlen + two tile bounds per tile + x + y
+        return h->nnz + h->n_rows + ((h->n_rows + 255) / 256) * 8 + 2 * h->n_rows * sv;
+    return hipk_csr_spmv_bytes(h);
 }
 
 // ------------------------------------------------------------------ SpMV launch
@@ -239,6 +355,35 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 hipk_rowdot_kernel<double><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
             else
                 hipk_rowdot_kernel<float><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
+            hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
+                (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+                a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
+        }
+        HIPK_CHECK_HIP(hipGetLastError());
+        return HIPK_OK;
+    }
+    if (h->n_codes > 0 && h->path_override != 1) {
+        a.code = h->code;
+        a.rowlen = h->rowlen;
+        a.dict_off = h->dict_off;
+        a.dict_val = h->dict_val;
+        a.n_codes = h->n_codes;
+        a.code_cap = (h->max_tile_nnz + 32 + 15) & ~15;
+        const int R = h->coded_rows;
+        const int nsuper = (ntiles + R - 1) / R;
+        const int cgrid = ((nsuper + 7) >> 3) << 3;
+        const size_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
+        const size_t lds = HIPK_CODED_MAX * (sv + 4) + (size_t)R * 16 + (size_t)R * a.code_cap;
+        if (prof) prof->before(stream);
+#define HIPK_LAUNCH_CODED(T, RR) hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a)
+        if (h->dtype == HIPK_F64) {
+            if (R == 4) HIPK_LAUNCH_CODED(double, 4); else if (R == 2) HIPK_LAUNCH_CODED(double, 2); else HIPK_LAUNCH_CODED(double, 1);
+        } else {
+            if (R == 4) HIPK_LAUNCH_CODED(float, 4); else if (R == 2) HIPK_LAUNCH_CODED(float, 2); else HIPK_LAUNCH_CODED(float, 1);
+        }
+#undef HIPK_LAUNCH_CODED
+        if (prof) prof->after(stream);
+        if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
             hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                 (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
                 a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);

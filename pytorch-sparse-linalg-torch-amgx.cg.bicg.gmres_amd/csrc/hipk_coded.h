@@ -1,0 +1,264 @@
+// hipk_coded.h -- "coded" CSR SpMV: one byte per entry for matrices with few distinct (col - row, value) pairs.
+//
+// Finite-difference / finite-volume matrices on structured grids -- what the reference's own builders produce
+// (utils/matrix_utils.py:193-257 Poisson, examples ldc_solver_common.py:90-135 pressure matrix) -- repeat a handful
+// of (column offset, coefficient) pairs millions of times.  hipk_csr_create builds, on the device, a dictionary of
+// the distinct pairs; when there are at most 256 and no row has more than 32 entries the handle keeps
+//     code[nnz]   uint8   index of entry j's pair in the dictionary
+//     rowlen[n]   uint8   entries of row i
+//     dict_off / dict_val (<= 256 entries)
+// next to the plain CSR arrays, and SpMV streams 1 B per entry + 1 B per row instead of 12 B + 4 B (fp64):
+// 88 MB instead of 320 MB per product at N = 4M.  The arithmetic is the plain kernel's, bit for bit: the
+// dictionary returns the very same value bits and x[row + off] is x[col]; row sums are formed from rounded
+// products in CSR order (rows have <= 32 entries, the spec's short-row rule), so the oracle needs no counterpart.
+//
+// Kernel: one workgroup per R consecutive 256-row tiles, thread t owning rows t, t+256, ..  Per tile the code bytes
+// are copied to LDS with 16-byte loads while the row lengths are scanned (wave shuffles + 4 wave totals), one
+// barrier, then each thread walks its rows: lanes of a wavefront hold consecutive rows, so every x gather of a
+// stencil is a coalesced 512-byte read.
+#pragma once
+#include "hipk_spmv.h"
+
+#define HIPK_CODED_MAX 256   // dictionary entries (uint8 codes)
+#define HIPK_DICT_SLOTS 2048  // open-addressed build table (power of two, >= 8 x HIPK_CODED_MAX)
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------ dictionary construction (handle creation)
+struct hipk_dict_table {
+    unsigned long long key[HIPK_DICT_SLOTS];   // 0 = empty, else hash of the pair
+    unsigned long long bits[HIPK_DICT_SLOTS];  // payload: value bits (fp32 zero-extended)
+    int off[HIPK_DICT_SLOTS];                  // payload: col - row
+    int slot_code[HIPK_DICT_SLOTS];            // filled by the host between the two passes
+    int count;                                 // distinct pairs inserted
+    int overflow;                              // more than HIPK_CODED_MAX pairs: give up
+    int fail;                                  // encode pass: pair not found / hash collision
+};
+
+__device__ __forceinline__ unsigned long long hipk_pair_hash(int off, unsigned long long bits) {
+    unsigned long long h = bits ^ ((unsigned long long)(unsigned int)off * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 31;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    h *= 0x94D049BB133111EBull;
+    h ^= h >> 32;
+    return h ? h : 1ull;
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned long long hipk_value_bits(T v);
+template <>
+__device__ __forceinline__ unsigned long long hipk_value_bits<double>(double v) {
+    return (unsigned long long)__double_as_longlong(v);
+}
+template <>
+__device__ __forceinline__ unsigned long long hipk_value_bits<float>(float v) {
+    return (unsigned long long)__float_as_uint(v);
+}
+
+// pass 1: insert every distinct (col - row, value) pair.  A slot is claimed with one CAS; afterwards entries
+// find their pair with a plain load, so the 20 M entries of a stencil matrix cost 5 CAS operations in total.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const int *__restrict__ crow,
+                                                                        const int *__restrict__ col,
+                                                                        const T *__restrict__ val, int64_t n_rows,
+                                                                        hipk_dict_table *tb) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long last_h = 0;  // the previous pair of this thread is already in the table
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        if (__hip_atomic_load(&tb->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const int lo = crow[r], hi = crow[r + 1];
+        for (int j = lo; j < hi; ++j) {
+            const int off = col[j] - (int)r;
+            const unsigned long long bits = hipk_value_bits<T>(val[j]);
+            const unsigned long long h = hipk_pair_hash(off, bits);
+            if (h == last_h) continue;
+            unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
+            for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
+                unsigned long long k = __hip_atomic_load(&tb->key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == 0) {
+                    k = atomicCAS(&tb->key[s], 0ull, h);
+                    if (k == 0) {  // claimed: publish the payload (read only by the NEXT kernel)
+                        tb->bits[s] = bits;
+                        tb->off[s] = off;
+                        if (atomicAdd(&tb->count, 1) + 1 > HIPK_CODED_MAX) {
+                            __hip_atomic_store(&tb->overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return;
+                        }
+                        break;
+                    }
+                }
+                if (k == h) break;
+                s = (s + 1) & (HIPK_DICT_SLOTS - 1);
+            }
+            last_h = h;
+        }
+    }
+}
+
+// pass 2: code[j] = dictionary index of entry j (payload compared exactly: a hash collision or a value changed
+// between the passes sets `fail`), rowlen[r] = entries of row r.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_kernel(const int *__restrict__ crow,
+                                                                        const int *__restrict__ col,
+                                                                        const T *__restrict__ val, int64_t n_rows,
+                                                                        hipk_dict_table *tb,
+                                                                        unsigned char *__restrict__ code,
+                                                                        unsigned char *__restrict__ rowlen) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const int lo = crow[r], hi = crow[r + 1];
+        rowlen[r] = (unsigned char)(hi - lo);
+        for (int j = lo; j < hi; ++j) {
+            const int off = col[j] - (int)r;
+            const unsigned long long bits = hipk_value_bits<T>(val[j]);
+            const unsigned long long h = hipk_pair_hash(off, bits);
+            unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
+            int found = -1;
+            for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
+                const unsigned long long k = tb->key[s];
+                if (k == h) {
+                    found = (int)s;
+                    break;
+                }
+                if (k == 0) break;
+                s = (s + 1) & (HIPK_DICT_SLOTS - 1);
+            }
+            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off) {
+                tb->fail = 1;
+                code[j] = 0;
+            } else {
+                code[j] = (unsigned char)tb->slot_code[found];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the SpMV kernel
+// dynamic LDS layout: dval[256] T | doff[256] int | wtot[R][4] int | R code buffers of a.code_cap bytes
+template <typename T, int R>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv_args a) {
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int nsuper = (ntiles + R - 1) / R;
+    const int st = hipk_xcd_tile(blockIdx.x, nsuper);
+    if (st < 0) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *dval = (T *)smem;
+    int *doff = (int *)(smem + HIPK_CODED_MAX * sizeof(T));
+    int *wtot = doff + HIPK_CODED_MAX;
+    unsigned char *cbuf = (unsigned char *)(wtot + R * 4);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int *__restrict__ crow = a.crow;
+    const unsigned char *__restrict__ code = a.code;
+    const unsigned char *__restrict__ rowlen = a.rowlen;
+    const T *__restrict__ x = (const T *)a.x;
+    T *__restrict__ y = (T *)a.y;
+    const int mode = a.mode;
+
+    int64_t r0[R];
+    int nr[R], len[R], head[R];  // head: offset of the tile's first code inside its LDS buffer
+    T wrow[R], brow[R];
+    uint4 cv[R];
+    int nvec[R];
+    const unsigned char *cbase[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int tile = st * R + i;
+        r0[i] = (int64_t)tile * HIPK_TILE;
+        nr[i] = tile < ntiles ? (int)((a.n - r0[i] < HIPK_TILE) ? (a.n - r0[i]) : HIPK_TILE) : 0;
+        len[i] = 0;
+        wrow[i] = (T)0;
+        brow[i] = (T)0;
+        nvec[i] = 0;
+        head[i] = 0;
+        cbase[i] = code;
+        if (nr[i] > 0) {
+            // tile bounds: uniform addresses -> scalar loads
+            const int j0 = __builtin_amdgcn_readfirstlane(crow[r0[i]]);
+            const int j1 = __builtin_amdgcn_readfirstlane(crow[r0[i] + nr[i]]);
+            const int a0 = j0 & ~15;
+            head[i] = j0 - a0;
+            nvec[i] = (j1 - a0 + 15) >> 4;
+            cbase[i] = code + a0;
+            if (t < nr[i]) {
+                len[i] = rowlen[r0[i] + t];
+                if (mode & HIPK_SPMV_DOT_W) wrow[i] = ((const T *)a.w)[r0[i] + t];
+                if (mode & HIPK_SPMV_RESID) brow[i] = ((const T *)a.bsub)[r0[i] + t];
+            }
+            if (t < nvec[i]) cv[i] = ((const uint4 *)cbase[i])[t];
+        }
+    }
+    if (t < a.n_codes) {
+        dval[t] = ((const T *)a.dict_val)[t];
+        doff[t] = a.dict_off[t];
+    }
+    int excl[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        unsigned char *cb = cbuf + (size_t)i * a.code_cap;
+        if (t < nvec[i]) ((uint4 *)cb)[t] = cv[i];
+        for (int v = t + HIPK_THREADS; v < nvec[i]; v += HIPK_THREADS) ((uint4 *)cb)[v] = ((const uint4 *)cbase[i])[v];
+        int s = len[i];  // inclusive scan of the row lengths over the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(s, o);
+            if (lane >= o) s += u;
+        }
+        excl[i] = s - len[i];
+        if (lane == 63) wtot[i * 4 + wave] = s;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (nr[i] == 0) continue;
+        const unsigned char *cb = cbuf + (size_t)i * a.code_cap;
+        int lo = head[i] + excl[i];
+        for (int w = 0; w < wave; ++w) lo += wtot[i * 4 + w];
+        const int64_t row = r0[i] + t;
+        T s = (T)0;
+        const int n_ent = len[i];
+        for (int k0 = 0; k0 < n_ent; k0 += 8) {
+            T xv[8];
+            int cc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k0 + k < n_ent) {
+                    cc[k] = cb[lo + k0 + k];
+                    xv[k] = x[row + doff[cc[k]]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k0 + k < n_ent) {
+                    const T p = dval[cc[k]] * xv[k];
+                    s = s + p;
+                }
+            }
+        }
+        double d0 = 0.0, d1 = 0.0;
+        if (t < nr[i]) {
+            T out = s;
+            if (mode & HIPK_SPMV_RESID) out = brow[i] - out;
+            y[row] = out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow[i] * (double)out;
+            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+        }
+        const size_t tp = (size_t)(st * R + i) * 4 + wave;
+        if (mode & HIPK_SPMV_DOT_W) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
+            if (lane == 0) a.tpart0[tp] = d0;
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
+            if (lane == 0) a.tpart1[tp] = d1;
+        }
+    }
+}
+#endif

@@ -87,6 +87,14 @@ struct hipk_csr_s {
     int n_huge;          //   row-per-wavefront pre-pass when the matrix as a whole is short-rowed
     int max_row_len;     // structure analysis at creation
     int max_tile_nnz;    //   (tile = 256 consecutive rows)
+    // coded form (hipk_coded.h), present when the matrix has <= 256 distinct (col - row, value) pairs and short rows
+    unsigned char *code;    // device, nnz (+32 bytes of padding), owned
+    unsigned char *rowlen;  // device, n_rows, owned
+    int *dict_off;          // device, 256
+    void *dict_val;         // device, 256 values of `dtype`
+    int n_codes;            // 0: no coded form
+    int path_override;      // hipk_csr_set_path: 0 auto, 1 never use the coded form
+    int coded_rows;         // 256-row tiles per workgroup of the coded kernel (1, 2 or 4)
 };
 
 #ifdef __HIPCC__

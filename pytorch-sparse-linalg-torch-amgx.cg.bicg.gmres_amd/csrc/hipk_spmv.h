@@ -48,6 +48,13 @@ struct hipk_spmv_args {
     double *tpart1;
     const int *row_list;  // row-per-wavefront kernel: process only these rows (null: all rows)
     int n_list;
+    // coded path (hipk_coded.h): one byte per entry + one byte per row + a dictionary of (col - row, value) pairs
+    const unsigned char *code;
+    const unsigned char *rowlen;
+    const int *dict_off;
+    const void *dict_val;
+    int n_codes;
+    int code_cap;  // bytes of LDS per tile for the code bytes
 };
 
 #ifdef __HIPCC__

@@ -25,6 +25,7 @@ GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
 SYMBOLS = [
     "hipk_version", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
+    "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
     "hipk_cg_work_bytes", "hipk_cg_solve",
@@ -120,9 +121,11 @@ def lib():
     L.hipk_device_count.restype = i32
     L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]
     L.hipk_csr_destroy.argtypes = [vp]
-    for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes):
+    for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes, L.hipk_csr_format_bytes):
         f.argtypes = [vp]
         f.restype = i64
+    L.hipk_csr_spmv_path.argtypes = [vp]
+    L.hipk_csr_set_path.argtypes = [vp, i32]
     L.hipk_chunk_size.argtypes = [i64]
     L.hipk_chunk_count.argtypes = [i64]
     L.hipk_scratch_bytes.restype = ctypes.c_size_t
@@ -209,6 +212,20 @@ class CsrHandle:
 
     def spmv_bytes(self) -> int:
         return int(lib().hipk_csr_spmv_bytes(self._h))
+
+    PATHS = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded"}
+
+    def path(self) -> str:
+        """SpMV kernel family selected by the structure analysis (include/hipk.h, hipk_spmv_path)."""
+        return self.PATHS[int(lib().hipk_csr_spmv_path(self._h))]
+
+    def set_path(self, plain_only: bool) -> None:
+        """plain_only=True: never use the coded form (A/B measurements, parity tests)."""
+        _check(lib().hipk_csr_set_path(self._h, 1 if plain_only else 0), "hipk_csr_set_path")
+
+    def format_bytes(self) -> int:
+        """Bytes one SpMV moves in the format the selected path streams."""
+        return int(lib().hipk_csr_format_bytes(self._h))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

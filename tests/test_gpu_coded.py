@@ -1,0 +1,194 @@
+"""GPU parity of the CODED SpMV path (csrc/hipk_coded.h: one byte per entry for matrices with at most 256 distinct
+(col - row, value) pairs) -- against the oracle and against the plain CSR kernels on the SAME handle, bit for bit --
+and of the structure analysis that selects it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def banded(n, offsets, values_of, seed=0):
+    """CSR of a banded matrix: row i has an entry at column i + o for every offset o inside the matrix; the
+    value is values_of(i, k) for the k-th offset."""
+    offsets = np.sort(np.asarray(offsets))
+    rows = np.repeat(np.arange(n), len(offsets))
+    cols = rows + np.tile(offsets, n)
+    kk = np.tile(np.arange(len(offsets)), n)
+    keep = (cols >= 0) & (cols < n)
+    rows, cols, kk = rows[keep], cols[keep], kk[keep]
+    crow = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(crow, rows + 1, 1)
+    crow = np.cumsum(crow)
+    val = values_of(rows, kk).astype(np.float64)
+    return crow, cols.astype(np.int64), val
+
+
+def make_handle(hipk, crow, col, val, n, dtype=torch.float64):
+    return hipk.CsrHandle(torch.from_numpy(crow).to(DEV), torch.from_numpy(col).to(DEV),
+                          torch.from_numpy(val).to(DEV).to(dtype), (n, n))
+
+
+def both_paths(hipk, h, x):
+    assert h.path() == "coded"
+    y_coded = hipk.spmv(h, x).cpu().numpy()
+    h.set_path(plain_only=True)
+    assert h.path() in ("tile_fast", "tile")
+    y_plain = hipk.spmv(h, x).cpu().numpy()
+    h.set_path(plain_only=False)
+    return y_coded, y_plain
+
+
+@pytest.mark.parametrize("case", ["poisson_nx64", "convdiff_nx64", "ldc_nx32_step0", "poisson_nx8"])
+def test_fixture_stencils_take_the_coded_path_and_match(hipk, oracle, case):
+    d = load_case(case)
+    n = int(d["n"])
+    h = make_handle(hipk, d["crow"], d["col"], d["val"], n)
+    x = np.random.default_rng(1).standard_normal(n)
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))
+    ref = oracle.spmv(d["crow"], d["col"], d["val"], x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
+    assert h.format_bytes() < h.spmv_bytes()
+
+
+@pytest.mark.parametrize("rows_per_wg", ["1", "2", "4"])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 1023, 70_001])
+def test_coded_tile_boundaries_and_rows_per_workgroup(hipk, oracle, n, rows_per_wg, monkeypatch):
+    monkeypatch.setenv("HIPK_SPMV_CODED_ROWS", rows_per_wg)
+    crow, col, val = banded(n, [-300, -1, 0, 1, 300], lambda r, k: np.array([-1.0, -1.5, 4.0, -1.5, -1.0])[k])
+    h = make_handle(hipk, crow, col, val, n)
+    x = np.random.default_rng(n).standard_normal(n)
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))
+    ref = oracle.spmv(crow, col, val, x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
+
+
+def test_coded_wide_stencil_more_than_4096_codes_per_tile(hipk, oracle):
+    n = 5000
+    offs = list(range(-13, 14))                                   # 27 entries per row: 6912 codes per tile
+    crow, col, val = banded(n, offs, lambda r, k: (k - 13.0) / 7.0 + 3.0 * (k == 13))
+    h = make_handle(hipk, crow, col, val, n)
+    x = np.random.default_rng(3).standard_normal(n)
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))
+    ref = oracle.spmv(crow, col, val, x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
+
+
+def test_dictionary_capacity_256_pairs_yes_257_no(hipk, oracle):
+    n = 4096
+    # 4 offsets x 64 values per offset = 256 distinct pairs (interior rows carry all of them)
+    crow, col, val = banded(n, [-2, -1, 1, 2], lambda r, k: 1.0 + (r % 64) + 100.0 * k)
+    h = make_handle(hipk, crow, col, val, n)
+    assert h.path() == "coded"
+    x = np.random.default_rng(4).standard_normal(n)
+    assert np.array_equal(hipk.spmv(h, torch.from_numpy(x).to(DEV)).cpu().numpy(), oracle.spmv(crow, col, val, x))
+    val2 = val.copy()
+    val2[len(val2) // 2] = 12345.678                               # one more pair
+    h2 = make_handle(hipk, crow, col, val2, n)
+    assert h2.path() != "coded"
+    assert np.array_equal(hipk.spmv(h2, torch.from_numpy(x).to(DEV)).cpu().numpy(), oracle.spmv(crow, col, val2, x))
+
+
+def test_random_values_and_long_rows_are_not_coded(hipk):
+    n = 3000
+    crow, col, val = banded(n, [-1, 0, 1], lambda r, k: np.random.default_rng(0).standard_normal(len(r)))
+    assert make_handle(hipk, crow, col, val, n).path() == "tile_fast"
+    crow, col, val = banded(n, list(range(-20, 21)), lambda r, k: 1.0 + k)       # 41 entries per row > 32
+    assert make_handle(hipk, crow, col, val, n).path() == "tile"
+
+
+def test_signed_zero_and_nan_payload_are_distinct_pairs(hipk, oracle):
+    n = 2000
+    crow, col, val = banded(n, [-1, 0, 1], lambda r, k: np.array([0.0, 2.0, -0.0])[k])
+    assert np.signbit(val).any()
+    h = make_handle(hipk, crow, col, val, n)
+    assert h.path() == "coded"
+    x = np.random.default_rng(6).standard_normal(n)
+    x[::7] = -x[::7]
+    y = hipk.spmv(h, torch.from_numpy(x).to(DEV)).cpu().numpy()
+    ref = oracle.spmv(crow, col, val, x)
+    assert np.array_equal(np.signbit(y), np.signbit(ref)) and np.array_equal(y, ref)
+
+
+def test_environment_switch_disables_the_coded_form(hipk, monkeypatch):
+    d = load_case("poisson_nx64")
+    monkeypatch.setenv("HIPK_SPMV_CODED", "0")
+    h = make_handle(hipk, d["crow"], d["col"], d["val"], int(d["n"]))
+    assert h.path() == "tile_fast" and h.format_bytes() == h.spmv_bytes()
+
+
+def test_coded_fp32_storage(hipk, oracle):
+    d = load_case("convdiff_nx64")
+    n = int(d["n"])
+    v32 = d["val"].astype(np.float32)
+    h = make_handle(hipk, d["crow"], d["col"], d["val"], n, dtype=torch.float32)
+    x = np.random.default_rng(8).standard_normal(n).astype(np.float32)
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))
+    ref = oracle.spmv32(d["crow"], d["col"], v32, x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
+
+
+def test_coded_fused_dots_and_residual_form(hipk, oracle):
+    """spmv_ex modes on the coded path: <w, out>, <out, out>, out = b - A x; chunk partials equal the plain path's."""
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(300, 300, device=DEV)
+    h = hipk.handle_for(A)
+    n = 90_000
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    w = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    L = hipk.lib()
+    G = int(L.hipk_chunk_count(n))
+    s = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        assert h.path() == ("tile_fast" if plain else "coded")
+        y = torch.empty_like(x)
+        p0 = torch.zeros(G, dtype=torch.float64, device=DEV)
+        p1 = torch.zeros(G, dtype=torch.float64, device=DEV)
+        hipk._check(L.hipk_spmv_ex(h._h, x.data_ptr(), y.data_ptr(), 7, w.data_ptr(), b.data_ptr(), p0.data_ptr(),
+                                   p1.data_ptr(), None, 0, s), "hipk_spmv_ex")
+        outs[plain] = (y.cpu().numpy(), p0.cpu().numpy(), p1.cpu().numpy())
+    h.set_path(plain_only=False)
+    for a, c in zip(outs[False], outs[True]):
+        assert np.array_equal(a, c)
+    crow, col, val = (t.cpu().numpy() for t in (A.crow_indices(), A.col_indices(), A.values()))
+    y_ref = b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy())
+    assert np.array_equal(outs[False][0], y_ref)
+
+
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "gmres"])
+def test_whole_solves_identical_on_both_paths(hipk, solver):
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr
+    A = create_poisson_2d_csr(150, 150, device=DEV) if solver == "cg" else create_convdiff_2d_csr(150, 150, device=DEV)
+    h = hipk.handle_for(A)
+    n = A.shape[0]
+    b = torch.randn(n, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    res = {}
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        x = torch.zeros_like(b)
+        st = hipk.solve(solver, h, b, x, tol=1e-8, atol=0.0, maxiter=None if solver != "gmres" else 200, restart=20)
+        res[plain] = (x.cpu().numpy(), st.iterations, st.info, st.residual_norm)
+    h.set_path(plain_only=False)
+    assert np.array_equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
+    assert res[False][2] == 0
+
+
+@pytest.mark.parametrize("nx", [2000])
+def test_full_size_poisson_coded_equals_plain(hipk, nx):
+    """BASELINE config 2 matrix (N = 4M): both paths give the same bits; the coded form streams < 30 % of the bytes."""
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(nx, nx, device=DEV)
+    h = hipk.handle_for(A)
+    x = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    y_coded, y_plain = both_paths(hipk, h, x)
+    assert np.array_equal(y_coded, y_plain)
+    assert h.format_bytes() < 0.3 * h.spmv_bytes()
