@@ -137,7 +137,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_kernel(const in
 // dynamic LDS layout: dval[256] T | doff[256] int | wtot[R][4] int | R code buffers of a.code_cap bytes
 template <typename T, int R>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv_args a) {
-    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
     const int nsuper = (ntiles + R - 1) / R;
     const int st = hipk_xcd_tile(blockIdx.x, nsuper);
@@ -192,6 +191,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
             if (t < nvec[i]) cv[i] = ((const uint4 *)cbase[i])[t];
         }
     }
+    // the stop word is read only now: the tile's loads above are already in flight (they touch valid memory
+    // whatever the answer is), nothing has been stored yet
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     if (t < a.n_codes) {
         dval[t] = ((const T *)a.dict_val)[t];
         doff[t] = a.dict_off[t];

@@ -82,7 +82,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
     static_assert(CAP * sizeof(T) >= 512 * sizeof(double), "prod[] doubles as reduction scratch");
     static_assert(HIPK_TILE == HIPK_THREADS, "one row per thread");
 
-    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
     const int tile = hipk_xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
@@ -109,8 +108,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
         if (mode & HIPK_SPMV_DOT_W) wrow = ((const T *)a.w)[r0 + t];
         if (mode & HIPK_SPMV_RESID) brow = ((const T *)a.bsub)[r0 + t];
     }
-    if (t < nr) crowL[t] = crow[r0 + t];
-    if (t == 0) crowL[nr] = crow[r0 + nr];  // nr can be 256: one more pointer than threads
+    int crow_t = 0, crow_e = 0;
+    if (t < nr) crow_t = crow[r0 + t];
+    if (t == 0) crow_e = crow[r0 + nr];  // nr can be 256: one more pointer than threads
+    // the stop word is read with the tile's first loads already in flight; nothing has been stored yet
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    if (t < nr) crowL[t] = crow_t;
+    if (t == 0) crowL[nr] = crow_e;
     __syncthreads();
     const int j0 = crowL[0];
     const int cnt = crowL[nr] - j0;
