@@ -8,6 +8,8 @@
 #include "hipk_coded.h"
 #include <stdlib.h>
 
+#include <vector>
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
@@ -129,23 +131,84 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
     }
     if (nc != ht->count) return hipSuccess;  // a claimed slot whose count was not yet added cannot happen after the sync
     e = hipMemcpyAsync(tb->slot_code, ht->slot_code, sizeof(ht->slot_code), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->nnz + 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->rowlen, (size_t)h->n_rows + 16);
     if (e == hipSuccess) e = hipMalloc((void **)&h->dict_off, sizeof(int) * HIPK_CODED_MAX);
     if (e == hipSuccess) e = hipMalloc((void **)&h->dict_val, sizeof(T) * HIPK_CODED_MAX);
-    if (e == hipSuccess) e = hipMemsetAsync(h->code + h->nnz, 0, 32, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h->dict_off, off_h, sizeof(off_h), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h->dict_val, val_h, sizeof(val_h), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) {
-        hipk_dict_encode_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows, tb,
-                                                                     h->code, h->rowlen);
+    if (e != hipSuccess) return e;
+
+    // layout of the code bytes: sliced-ELL planes when the padding stays small, else CSR order + row lengths
+    const char *lay = getenv("HIPK_SPMV_CODED_LAYOUT");
+    const bool want_sell = !(lay && strcmp(lay, "csr") == 0) && nc < HIPK_SELL_PAD + 1 && nc <= HIPK_SELL_PAD;
+    const int ntiles = (int)((h->n_rows + HIPK_TILE - 1) / HIPK_TILE);
+    std::vector<int> toff;
+    bool sell = false;
+    if (want_sell) {
+        int *tw = nullptr;
+        e = hipMalloc((void **)&tw, sizeof(int) * (size_t)(ntiles + 1));
+        if (e != hipSuccess) return e;
+        hipk_tile_width_kernel<<<ntiles, HIPK_THREADS, 0, stream>>>(h->crow, h->n_rows, tw);
+        toff.resize((size_t)ntiles + 1);
         e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(toff.data(), tw, sizeof(int) * (size_t)ntiles, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            (void)hipFree(tw);
+            return e;
+        }
+        int64_t planes = 0;
+        int wmin = INT32_MAX, wmax = 0;
+        for (int i = 0; i < ntiles; ++i) {
+            const int w = toff[i];
+            wmin = w < wmin ? w : wmin;
+            wmax = w > wmax ? w : wmax;
+            toff[i] = (int)planes;
+            planes += w;
+        }
+        toff[ntiles] = (int)planes;
+        // nearly uniform widths (a stencil's first/last grid line is narrower): pad every tile to the widest,
+        // so that a tile's planes are found without the offset table (one dependent load less per workgroup)
+        const int64_t planes_u = (int64_t)ntiles * wmax;
+        if (wmin != wmax && planes_u <= planes + planes / 50 + 8) {
+            for (int i = 0; i <= ntiles; ++i) toff[i] = i * wmax;
+            planes = planes_u;
+            wmin = wmax;
+        }
+        sell = planes * HIPK_TILE <= 2 * h->nnz + 65536 && planes < (int64_t)INT32_MAX / HIPK_TILE * 64;
+        if (sell) {
+            h->tile_off = tw;
+            h->sell_w = (wmin == wmax) ? wmax : 0;
+            h->sell_bytes = planes * HIPK_TILE;
+            e = hipMemcpyAsync(tw, toff.data(), sizeof(int) * (size_t)(ntiles + 1), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->sell_bytes + 256);
+            if (e == hipSuccess) e = hipMemsetAsync(h->code, HIPK_SELL_PAD, (size_t)h->sell_bytes + 256, stream);
+            if (e == hipSuccess) {
+                hipk_dict_encode_sell_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val,
+                                                                                  h->n_rows, tb, h->tile_off, h->code);
+                e = hipGetLastError();
+            }
+        } else {
+            (void)hipFree(tw);
+        }
+    }
+    if (!sell) {
+        if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->nnz + 32);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->rowlen, (size_t)h->n_rows + 16);
+        if (e == hipSuccess) e = hipMemsetAsync(h->code + h->nnz, 0, 32, stream);
+        if (e == hipSuccess) {
+            hipk_dict_encode_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows,
+                                                                         tb, h->code, h->rowlen);
+            e = hipGetLastError();
+        }
     }
     int fail = 1;
     if (e == hipSuccess) e = hipMemcpyAsync(&fail, &tb->fail, sizeof(int), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // also keeps off_h / val_h alive until the copies are done
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // also keeps the host staging arrays alive until the copies are done
     if (e != hipSuccess) return e;
-    if (!fail) h->n_codes = nc;
+    if (!fail) {
+        h->n_codes = nc;
+        h->coded_layout = sell ? 2 : 1;
+    }
     return hipSuccess;
 }
 
@@ -154,6 +217,9 @@ static void hipk_drop_coded(hipk_csr_s *h) {
     if (h->rowlen) (void)hipFree(h->rowlen);
     if (h->dict_off) (void)hipFree(h->dict_off);
     if (h->dict_val) (void)hipFree(h->dict_val);
+    if (h->tile_off) (void)hipFree(h->tile_off);
+    h->tile_off = nullptr;
+    h->coded_layout = 0;
     h->code = h->rowlen = nullptr;
     h->dict_off = nullptr;
     h->dict_val = nullptr;
@@ -315,8 +381,11 @@ extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
 extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
     if (!h) return -1;
     const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
-    if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED)  // code + rowlen + two tile bounds per tile + x + y
-        return h->nnz + h->n_rows + ((h->n_rows + 255) / 256) * 8 + 2 * h->n_rows * sv;
+    if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED) {
+        if (h->coded_layout == 2)  // byte planes (+ two plane offsets per tile unless uniform) + x + y
+            return h->sell_bytes + (h->sell_w > 0 ? 0 : ((h->n_rows + 255) / 256) * 8) + 2 * h->n_rows * sv;
+        return h->nnz + h->n_rows + ((h->n_rows + 255) / 256) * 8 + 2 * h->n_rows * sv;  // code + rowlen + bounds
+    }
     return hipk_csr_spmv_bytes(h);
 }
 
@@ -374,8 +443,17 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         const int cgrid = ((nsuper + 7) >> 3) << 3;
         const size_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
         const size_t lds = HIPK_CODED_MAX * (sv + 4) + (size_t)R * 16 + (size_t)R * a.code_cap;
+        a.tile_off = h->tile_off;
+        a.sell_w = h->sell_w;
+        const bool sell = h->coded_layout == 2;
         if (prof) prof->before(stream);
-#define HIPK_LAUNCH_CODED(T, RR) hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a)
+#define HIPK_LAUNCH_CODED(T, RR)                                                   \
+    do {                                                                           \
+        if (sell)                                                                  \
+            hipk_spmv_sell_kernel<T, RR><<<cgrid, HIPK_THREADS, 0, stream>>>(a);   \
+        else                                                                       \
+            hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a); \
+    } while (0)
         if (h->dtype == HIPK_F64) {
             if (R == 4) HIPK_LAUNCH_CODED(double, 4); else if (R == 2) HIPK_LAUNCH_CODED(double, 2); else HIPK_LAUNCH_CODED(double, 1);
         } else {

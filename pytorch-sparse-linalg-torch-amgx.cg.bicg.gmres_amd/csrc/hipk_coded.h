@@ -263,4 +263,186 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
         }
     }
 }
+
+// ================================================================== sliced-ELL layout of the codes
+// The CSR-ordered code bytes above still make a workgroup wait three times in a row (tile bounds -> code bytes ->
+// x gather).  Storing the codes of a 256-row tile as W byte planes (W = longest row of the tile; plane k holds
+// the k-th entry of every row, byte t = row t; shorter rows are padded with HIPK_SELL_PAD) removes the first
+// wait, the row-length scan and the LDS staging: thread t reads byte t of each plane -- coalesced -- and goes
+// straight to the dictionary and the x gather.  Padding is skipped by predicate, never multiplied, so the sums
+// are formed from exactly the CSR entries in CSR order.  Cost: (W_tile * 256 - tile nnz) padding bytes; the
+// layout is built only when the planes take at most 2 x nnz bytes.
+#define HIPK_SELL_PAD 255  // dictionary limited to 255 entries in this layout
+
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int *__restrict__ crow, int64_t n_rows,
+                                                                       int *__restrict__ tile_w) {
+    __shared__ int wmax[HIPK_THREADS / 64];
+    const int64_t r = (int64_t)blockIdx.x * HIPK_TILE + threadIdx.x;
+    int len = (r < n_rows) ? crow[r + 1] - crow[r] : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int u = __shfl_down(len, o);
+        len = u > len ? u : len;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = wmax[0];
+        for (int w = 1; w < HIPK_THREADS / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+        tile_w[blockIdx.x] = m;
+    }
+}
+
+// codes of row r, entry k -> plane k of r's tile (planes are prefilled with HIPK_SELL_PAD)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
+    const int *__restrict__ crow, const int *__restrict__ col, const T *__restrict__ val, int64_t n_rows,
+    hipk_dict_table *tb, const int *__restrict__ tile_off, unsigned char *__restrict__ code) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const int lo = crow[r], hi = crow[r + 1];
+        unsigned char *plane = code + (size_t)tile_off[r >> 8] * HIPK_TILE + (r & 255);
+        for (int j = lo; j < hi; ++j) {
+            const int off = col[j] - (int)r;
+            const unsigned long long bits = hipk_value_bits<T>(val[j]);
+            const unsigned long long h = hipk_pair_hash(off, bits);
+            unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
+            int found = -1;
+            for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
+                const unsigned long long k = tb->key[s];
+                if (k == h) {
+                    found = (int)s;
+                    break;
+                }
+                if (k == 0) break;
+                s = (s + 1) & (HIPK_DICT_SLOTS - 1);
+            }
+            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off)
+                tb->fail = 1;
+            else
+                plane[(size_t)(j - lo) * HIPK_TILE] = (unsigned char)tb->slot_code[found];
+        }
+    }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_kernel(hipk_spmv_args a) {
+    constexpr int B = 8;  // entries handled per batch (all of a 5- or 7-point stencil row)
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int nsuper = (ntiles + R - 1) / R;
+    const int st = hipk_xcd_tile(blockIdx.x, nsuper);
+    if (st < 0) return;
+
+    __shared__ T dval[HIPK_CODED_MAX];
+    __shared__ int doff[HIPK_CODED_MAX];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const unsigned char *__restrict__ code = a.code;
+    const T *__restrict__ x = (const T *)a.x;
+    T *__restrict__ y = (T *)a.y;
+    const int mode = a.mode;
+
+    T dv = (T)0;
+    int dofs = 0;
+    if (t < a.n_codes) {
+        dv = ((const T *)a.dict_val)[t];
+        dofs = a.dict_off[t];
+    }
+    int64_t r0[R];
+    int nr[R], W[R];
+    const unsigned char *plane[R];
+    unsigned char c[R][B];
+    T wrow[R], brow[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int tile = st * R + i;
+        r0[i] = (int64_t)tile * HIPK_TILE;
+        nr[i] = tile < ntiles ? (int)((a.n - r0[i] < HIPK_TILE) ? (a.n - r0[i]) : HIPK_TILE) : 0;
+        W[i] = 0;
+        plane[i] = code;
+        wrow[i] = (T)0;
+        brow[i] = (T)0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) c[i][k] = HIPK_SELL_PAD;
+        if (nr[i] > 0) {
+            if (a.sell_w > 0) {  // every tile has the same width: no offset table
+                W[i] = a.sell_w;
+                plane[i] = code + (size_t)tile * a.sell_w * HIPK_TILE + t;
+            } else {
+                const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tile]);
+                const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tile + 1]);
+                W[i] = o1 - o0;
+                plane[i] = code + (size_t)o0 * HIPK_TILE + t;
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (k < W[i]) c[i][k] = plane[i][(size_t)k * HIPK_TILE];
+            if (t < nr[i]) {
+                if (mode & HIPK_SPMV_DOT_W) wrow[i] = ((const T *)a.w)[r0[i] + t];
+                if (mode & HIPK_SPMV_RESID) brow[i] = ((const T *)a.bsub)[r0[i] + t];
+            }
+        }
+    }
+    // stop word: read with the loads above in flight; nothing stored yet
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    if (t < a.n_codes) {
+        dval[t] = dv;
+        doff[t] = dofs;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (nr[i] == 0) continue;
+        const int64_t row = r0[i] + t;
+        T s = (T)0;
+        {
+            T xv[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (c[i][k] != HIPK_SELL_PAD) xv[k] = x[row + doff[c[i][k]]];
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (c[i][k] != HIPK_SELL_PAD) {
+                    const T p = dval[c[i][k]] * xv[k];
+                    s = s + p;
+                }
+        }
+        for (int k0 = B; k0 < W[i]; k0 += B) {  // wider stencils: further batches of planes
+            unsigned char cc[B];
+            T xv[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) cc[k] = (k0 + k < W[i]) ? plane[i][(size_t)(k0 + k) * HIPK_TILE] : HIPK_SELL_PAD;
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (cc[k] != HIPK_SELL_PAD) xv[k] = x[row + doff[cc[k]]];
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (cc[k] != HIPK_SELL_PAD) {
+                    const T p = dval[cc[k]] * xv[k];
+                    s = s + p;
+                }
+        }
+        double d0 = 0.0, d1 = 0.0;
+        if (t < nr[i]) {
+            T out = s;
+            if (mode & HIPK_SPMV_RESID) out = brow[i] - out;
+            y[row] = out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow[i] * (double)out;
+            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+        }
+        const size_t tp = (size_t)(st * R + i) * 4 + wave;
+        if (mode & HIPK_SPMV_DOT_W) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
+            if (lane == 0) a.tpart0[tp] = d0;
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
+            if (lane == 0) a.tpart1[tp] = d1;
+        }
+    }
+}
 #endif

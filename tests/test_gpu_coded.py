@@ -56,10 +56,12 @@ def test_fixture_stencils_take_the_coded_path_and_match(hipk, oracle, case):
     assert h.format_bytes() < h.spmv_bytes()
 
 
+@pytest.mark.parametrize("layout", ["sell", "csr"])
 @pytest.mark.parametrize("rows_per_wg", ["1", "2", "4"])
 @pytest.mark.parametrize("n", [1, 255, 256, 257, 1023, 70_001])
-def test_coded_tile_boundaries_and_rows_per_workgroup(hipk, oracle, n, rows_per_wg, monkeypatch):
+def test_coded_tile_boundaries_and_rows_per_workgroup(hipk, oracle, n, rows_per_wg, layout, monkeypatch):
     monkeypatch.setenv("HIPK_SPMV_CODED_ROWS", rows_per_wg)
+    monkeypatch.setenv("HIPK_SPMV_CODED_LAYOUT", layout)
     crow, col, val = banded(n, [-300, -1, 0, 1, 300], lambda r, k: np.array([-1.0, -1.5, 4.0, -1.5, -1.0])[k])
     h = make_handle(hipk, crow, col, val, n)
     x = np.random.default_rng(n).standard_normal(n)
@@ -68,7 +70,9 @@ def test_coded_tile_boundaries_and_rows_per_workgroup(hipk, oracle, n, rows_per_
     assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
 
 
-def test_coded_wide_stencil_more_than_4096_codes_per_tile(hipk, oracle):
+@pytest.mark.parametrize("layout", ["sell", "csr"])
+def test_coded_wide_stencil_more_than_4096_codes_per_tile(hipk, oracle, layout, monkeypatch):
+    monkeypatch.setenv("HIPK_SPMV_CODED_LAYOUT", layout)
     n = 5000
     offs = list(range(-13, 14))                                   # 27 entries per row: 6912 codes per tile
     crow, col, val = banded(n, offs, lambda r, k: (k - 13.0) / 7.0 + 3.0 * (k == 13))
@@ -92,6 +96,27 @@ def test_dictionary_capacity_256_pairs_yes_257_no(hipk, oracle):
     h2 = make_handle(hipk, crow, col, val2, n)
     assert h2.path() != "coded"
     assert np.array_equal(hipk.spmv(h2, torch.from_numpy(x).to(DEV)).cpu().numpy(), oracle.spmv(crow, col, val2, x))
+
+
+def test_ragged_rows_with_few_pairs_fall_back_to_the_csr_layout(hipk, oracle):
+    """Row lengths 0..32 with one value per offset: the byte planes would be mostly padding (> 2 x nnz), so the
+    codes stay in CSR order; results unchanged."""
+    n = 6000
+    rng = np.random.default_rng(12)
+    lens = np.where(rng.random(n) < 0.9, rng.integers(0, 3, n), 32)
+    crow = np.zeros(n + 1, dtype=np.int64)
+    crow[1:] = np.cumsum(lens)
+    col = np.concatenate([(np.arange(l) * 7 + r) % n for r, l in enumerate(lens)])
+    order = np.concatenate([np.argsort(col[crow[r]:crow[r + 1]], kind="stable") + crow[r] for r in range(n)])
+    col = col[order]
+    off = col - np.repeat(np.arange(n), lens)
+    val = 1.0 + (off % 5)
+    h = make_handle(hipk, crow, col.astype(np.int64), val.astype(np.float64), n)
+    assert h.path() == "coded"
+    x = rng.standard_normal(n)
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))
+    ref = oracle.spmv(crow, col, val, x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
 
 
 def test_random_values_and_long_rows_are_not_coded(hipk):
@@ -122,7 +147,9 @@ def test_environment_switch_disables_the_coded_form(hipk, monkeypatch):
     assert h.path() == "tile_fast" and h.format_bytes() == h.spmv_bytes()
 
 
-def test_coded_fp32_storage(hipk, oracle):
+@pytest.mark.parametrize("layout", ["sell", "csr"])
+def test_coded_fp32_storage(hipk, oracle, layout, monkeypatch):
+    monkeypatch.setenv("HIPK_SPMV_CODED_LAYOUT", layout)
     d = load_case("convdiff_nx64")
     n = int(d["n"])
     v32 = d["val"].astype(np.float32)

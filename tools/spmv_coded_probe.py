@@ -48,9 +48,11 @@ def cg_rate(h):
 
 
 rows = []
-for label, env_rows, plain in (("plain", "1", True), ("coded R=1", "1", False), ("coded R=2", "2", False),
-                               ("coded R=4", "4", False)):
+for label, env_rows, plain, layout in (("plain", "1", True, "sell"), ("coded csr R=1", "1", False, "csr"),
+                                       ("coded sell R=1", "1", False, "sell"), ("coded sell R=2", "2", False, "sell"),
+                                       ("coded sell R=4", "4", False, "sell")):
     os.environ["HIPK_SPMV_CODED_ROWS"] = env_rows
+    os.environ["HIPK_SPMV_CODED_LAYOUT"] = layout
     t0 = time.perf_counter()
     h = _hipk.CsrHandle(crow, col, val, A.shape)
     torch.cuda.synchronize()
