@@ -331,6 +331,13 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     }
     // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
     h->coded_rows = 1;
+    h->sell_loop = 1;  // persistent sliced-ELL kernel, grid = sell_loop x 8 workgroups per CU (0: one tile per workgroup)
+    if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 0 ? 0 : (atoi(sl) > 4 ? 4 : atoi(sl));
+    {
+        hipDeviceProp_t prop;
+        h->n_cu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+    }
     if (const char *cr = getenv("HIPK_SPMV_CODED_ROWS")) {
         const int v = atoi(cr);
         if (v == 1 || v == 2 || v == 4) h->coded_rows = v;
@@ -446,6 +453,30 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         a.tile_off = h->tile_off;
         a.sell_w = h->sell_w;
         const bool sell = h->coded_layout == 2;
+        if (sell && h->sell_loop) {
+            // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
+            int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
+            const hipError_t oe = (h->dtype == HIPK_F64)
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hipk_spmv_sell_loop_kernel<double>, HIPK_THREADS, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hipk_spmv_sell_loop_kernel<float>, HIPK_THREADS, 0);
+            if (oe != hipSuccess || occ < 1) occ = 4;
+            int lgrid = h->n_cu * occ * h->sell_loop;
+            if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
+            lgrid = ((lgrid + 7) >> 3) << 3;
+            if (prof) prof->before(stream);
+            if (h->dtype == HIPK_F64)
+                hipk_spmv_sell_loop_kernel<double><<<lgrid, HIPK_THREADS, 0, stream>>>(a);
+            else
+                hipk_spmv_sell_loop_kernel<float><<<lgrid, HIPK_THREADS, 0, stream>>>(a);
+            if (prof) prof->after(stream);
+            if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+                hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
+                    (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
+                    a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
+            }
+            HIPK_CHECK_HIP(hipGetLastError());
+            return HIPK_OK;
+        }
         if (prof) prof->before(stream);
 #define HIPK_LAUNCH_CODED(T, RR)                                                   \
     do {                                                                           \

@@ -445,4 +445,131 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_kernel(hipk_spmv_
         }
     }
 }
+
+// Persistent form of the sliced-ELL kernel.  The one-tile-per-workgroup kernel above is bound by what every
+// workgroup does ONCE -- kernel arguments, dictionary -> LDS, barrier, stop word -- plus two dependent waits per
+// tile (code planes, x gather): ~3 us per wavefront for ~5 KB of traffic.  Here the grid is the number of
+// resident workgroups (8 per CU); each walks its share of the tiles of its XCD's eighth of the matrix with the
+// NEXT tile's code bytes (and epilogue operands) already requested while the current tile's x gathers are in
+// flight, so a tile costs one exposed wait instead of the whole start-up chain.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
+    constexpr int B = 8;
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int per = (ntiles + 7) >> 3;       // tiles per XCD eighth
+    const int gp = (int)gridDim.x >> 3;      // workgroups per XCD (grid is a multiple of 8)
+    const int xcd = blockIdx.x & 7;
+    int idx = blockIdx.x >> 3;               // position inside the eighth; advances by gp
+
+    __shared__ T dval[HIPK_CODED_MAX];
+    __shared__ int doff[HIPK_CODED_MAX];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const unsigned char *__restrict__ code = a.code;
+    const T *__restrict__ x = (const T *)a.x;
+    T *__restrict__ y = (T *)a.y;
+    const int mode = a.mode;
+
+    T dv = (T)0;
+    int dofs = 0;
+    if (t < a.n_codes) {
+        dv = ((const T *)a.dict_val)[t];
+        dofs = a.dict_off[t];
+    }
+    // request tile `tl`'s first B planes and epilogue operands
+    unsigned char cn[B];
+    T wn = (T)0, bn = (T)0;
+    int Wn = 0;
+    const unsigned char *pn = code;
+    auto request = [&](int tl) {
+        const int64_t r0 = (int64_t)tl * HIPK_TILE;
+        if (a.sell_w > 0) {
+            Wn = a.sell_w;
+            pn = code + (size_t)tl * a.sell_w * HIPK_TILE + t;
+        } else {
+            const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tl]);
+            const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tl + 1]);
+            Wn = o1 - o0;
+            pn = code + (size_t)o0 * HIPK_TILE + t;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) cn[k] = (k < Wn) ? pn[(size_t)k * HIPK_TILE] : (unsigned char)HIPK_SELL_PAD;
+        wn = (T)0;
+        bn = (T)0;
+        if (r0 + t < a.n) {
+            if (mode & HIPK_SPMV_DOT_W) wn = ((const T *)a.w)[r0 + t];
+            if (mode & HIPK_SPMV_RESID) bn = ((const T *)a.bsub)[r0 + t];
+        }
+    };
+    int tile = (idx < per) ? xcd * per + idx : ntiles;
+    if (tile < ntiles) request(tile);
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    if (t < a.n_codes) {
+        dval[t] = dv;
+        doff[t] = dofs;
+    }
+    __syncthreads();
+
+    while (tile < ntiles) {
+        unsigned char c[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) c[k] = cn[k];
+        const T wrow = wn, brow = bn;
+        const int W = Wn;
+        const unsigned char *plane = pn;
+        const int64_t r0 = (int64_t)tile * HIPK_TILE;
+        const int64_t row = r0 + t;
+        T xv[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (c[k] != HIPK_SELL_PAD) xv[k] = x[row + doff[c[k]]];
+        // next tile of this workgroup: its bytes travel while the gathers above are outstanding
+        idx += gp;
+        const int next = (idx < per) ? xcd * per + idx : ntiles;
+        if (next < ntiles) request(next);
+        T s = (T)0;
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (c[k] != HIPK_SELL_PAD) {
+                const T p = dval[c[k]] * xv[k];
+                s = s + p;
+            }
+        for (int k0 = B; k0 < W; k0 += B) {  // wider stencils: further batches of planes
+            unsigned char cc[B];
+            T xw[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) cc[k] = (k0 + k < W) ? plane[(size_t)(k0 + k) * HIPK_TILE] : (unsigned char)HIPK_SELL_PAD;
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (cc[k] != HIPK_SELL_PAD) xw[k] = x[row + doff[cc[k]]];
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (cc[k] != HIPK_SELL_PAD) {
+                    const T p = dval[cc[k]] * xw[k];
+                    s = s + p;
+                }
+        }
+        double d0 = 0.0, d1 = 0.0;
+        if (row < a.n) {
+            T out = s;
+            if (mode & HIPK_SPMV_RESID) out = brow - out;
+            y[row] = out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow * (double)out;
+            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+        }
+        const size_t tp = (size_t)tile * 4 + wave;
+        if (mode & HIPK_SPMV_DOT_W) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
+            if (lane == 0) a.tpart0[tp] = d0;
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
+            if (lane == 0) a.tpart1[tp] = d1;
+        }
+        tile = next;
+    }
+}
 #endif

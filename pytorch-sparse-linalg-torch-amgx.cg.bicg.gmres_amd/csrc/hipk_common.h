@@ -99,6 +99,8 @@ struct hipk_csr_s {
     int *tile_off;          // device, ntiles + 1 (sliced-ELL)
     int sell_w;             // uniform tile width or 0
     int64_t sell_bytes;     // bytes of the planes
+    int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)
+    int n_cu;               // compute units of the device
 };
 
 #ifdef __HIPCC__
