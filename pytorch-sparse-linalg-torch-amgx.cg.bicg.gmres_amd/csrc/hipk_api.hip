@@ -453,21 +453,22 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         a.tile_off = h->tile_off;
         a.sell_w = h->sell_w;
         const bool sell = h->coded_layout == 2;
-        if (sell && h->sell_loop) {
+        if (sell && h->sell_loop && h->n_rows <= h->n_cols && (uint64_t)h->n_cols * sv < (1ull << 32)) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
+            // exact plane count for the common stencil widths, run-time width otherwise
+            void (*kern)(hipk_spmv_args) = nullptr;
+#define HIPK_PICK_LOOP(T)                                                                              \
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5> : h->sell_w == 7 ? hipk_spmv_sell_loop_kernel<T, 7> \
+     : h->sell_w == 3 ? hipk_spmv_sell_loop_kernel<T, 3> : hipk_spmv_sell_loop_kernel<T, 0>)
+            kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double) : HIPK_PICK_LOOP(float);
+#undef HIPK_PICK_LOOP
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
-            const hipError_t oe = (h->dtype == HIPK_F64)
-                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hipk_spmv_sell_loop_kernel<double>, HIPK_THREADS, 0)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hipk_spmv_sell_loop_kernel<float>, HIPK_THREADS, 0);
-            if (oe != hipSuccess || occ < 1) occ = 4;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
             int lgrid = h->n_cu * occ * h->sell_loop;
             if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
             lgrid = ((lgrid + 7) >> 3) << 3;
             if (prof) prof->before(stream);
-            if (h->dtype == HIPK_F64)
-                hipk_spmv_sell_loop_kernel<double><<<lgrid, HIPK_THREADS, 0, stream>>>(a);
-            else
-                hipk_spmv_sell_loop_kernel<float><<<lgrid, HIPK_THREADS, 0, stream>>>(a);
+            kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);
             if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
                 hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(

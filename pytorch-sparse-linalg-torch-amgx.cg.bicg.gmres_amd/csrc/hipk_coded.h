@@ -449,12 +449,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_kernel(hipk_spmv_
 // Persistent form of the sliced-ELL kernel.  The one-tile-per-workgroup kernel above is bound by what every
 // workgroup does ONCE -- kernel arguments, dictionary -> LDS, barrier, stop word -- plus two dependent waits per
 // tile (code planes, x gather): ~3 us per wavefront for ~5 KB of traffic.  Here the grid is the number of
-// resident workgroups (8 per CU); each walks its share of the tiles of its XCD's eighth of the matrix with the
-// NEXT tile's code bytes (and epilogue operands) already requested while the current tile's x gathers are in
-// flight, so a tile costs one exposed wait instead of the whole start-up chain.
-template <typename T>
+// resident workgroups; each walks its share of the tiles of its XCD's eighth of the matrix with the NEXT
+// tile's code bytes (and epilogue operands) already requested while the current tile's x gathers are in flight.
+// The loop body is branch free: padding codes read dictionary slot 255 (offset 0, value 0) and are kept out of
+// the sum by a select, never by arithmetic; WB > 0 instantiates the exact plane count of a uniform-width matrix
+// (5 for a 5-point stencil), WB == 0 takes the width at run time in batches of 8 planes.
+// Requires n_rows <= n_cols (padding lanes read x[min(row, n_rows-1)]) and n_cols * sizeof(T) < 4 GiB
+// (32-bit byte offsets: one shift + one add per gather).
+template <typename T, int WB>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
-    constexpr int B = 8;
+    constexpr int B = WB > 0 ? WB : 8;
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
     const int per = (ntiles + 7) >> 3;       // tiles per XCD eighth
     const int gp = (int)gridDim.x >> 3;      // workgroups per XCD (grid is a multiple of 8)
@@ -467,9 +471,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     const int lane = t & 63;
     const int wave = t >> 6;
     const unsigned char *__restrict__ code = a.code;
-    const T *__restrict__ x = (const T *)a.x;
+    const char *__restrict__ xb = (const char *)a.x;
     T *__restrict__ y = (T *)a.y;
     const int mode = a.mode;
+    const int n32 = (int)a.n;
 
     T dv = (T)0;
     int dofs = 0;
@@ -477,16 +482,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         dv = ((const T *)a.dict_val)[t];
         dofs = a.dict_off[t];
     }
-    // request tile `tl`'s first B planes and epilogue operands
     unsigned char cn[B];
     T wn = (T)0, bn = (T)0;
     int Wn = 0;
     const unsigned char *pn = code;
-    auto request = [&](int tl) {
-        const int64_t r0 = (int64_t)tl * HIPK_TILE;
-        if (a.sell_w > 0) {
-            Wn = a.sell_w;
-            pn = code + (size_t)tl * a.sell_w * HIPK_TILE + t;
+    auto request = [&](int tl) {  // tile tl's first B planes and epilogue operands
+        const int r0 = tl * HIPK_TILE;
+        if (WB > 0) {
+            Wn = WB;
+            pn = code + (size_t)tl * (WB * HIPK_TILE) + t;
         } else {
             const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tl]);
             const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tl + 1]);
@@ -494,10 +498,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             pn = code + (size_t)o0 * HIPK_TILE + t;
         }
 #pragma unroll
-        for (int k = 0; k < B; ++k) cn[k] = (k < Wn) ? pn[(size_t)k * HIPK_TILE] : (unsigned char)HIPK_SELL_PAD;
+        for (int k = 0; k < B; ++k) {
+            cn[k] = HIPK_SELL_PAD;
+            if (WB > 0 || k < Wn) cn[k] = pn[k * HIPK_TILE];  // Wn is wavefront-uniform: scalar branch
+        }
         wn = (T)0;
         bn = (T)0;
-        if (r0 + t < a.n) {
+        if (r0 + t < n32) {
             if (mode & HIPK_SPMV_DOT_W) wn = ((const T *)a.w)[r0 + t];
             if (mode & HIPK_SPMV_RESID) bn = ((const T *)a.bsub)[r0 + t];
         }
@@ -505,10 +512,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     int tile = (idx < per) ? xcd * per + idx : ntiles;
     if (tile < ntiles) request(tile);
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
-    if (t < a.n_codes) {
-        dval[t] = dv;
-        doff[t] = dofs;
-    }
+    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
+    doff[t] = dofs;
     __syncthreads();
 
     while (tile < ntiles) {
@@ -518,40 +523,49 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         const T wrow = wn, brow = bn;
         const int W = Wn;
         const unsigned char *plane = pn;
-        const int64_t r0 = (int64_t)tile * HIPK_TILE;
-        const int64_t row = r0 + t;
+        const int row = tile * HIPK_TILE + t;
+        const int rowx = row < n32 ? row : n32 - 1;
         T xv[B];
 #pragma unroll
-        for (int k = 0; k < B; ++k)
-            if (c[k] != HIPK_SELL_PAD) xv[k] = x[row + doff[c[k]]];
+        for (int k = 0; k < B; ++k) {
+            const unsigned bo = (unsigned)(rowx + doff[c[k]]) * (unsigned)sizeof(T);
+            xv[k] = *(const T *)(xb + bo);
+        }
         // next tile of this workgroup: its bytes travel while the gathers above are outstanding
         idx += gp;
         const int next = (idx < per) ? xcd * per + idx : ntiles;
         if (next < ntiles) request(next);
         T s = (T)0;
 #pragma unroll
-        for (int k = 0; k < B; ++k)
-            if (c[k] != HIPK_SELL_PAD) {
-                const T p = dval[c[k]] * xv[k];
-                s = s + p;
-            }
-        for (int k0 = B; k0 < W; k0 += B) {  // wider stencils: further batches of planes
-            unsigned char cc[B];
-            T xw[B];
+        for (int k = 0; k < B; ++k) {
+            const T p = dval[c[k]] * xv[k];
+            const T s1 = s + p;
+            s = (c[k] != HIPK_SELL_PAD) ? s1 : s;
+        }
+        if (WB == 0) {
+            for (int k0 = B; k0 < W; k0 += B) {  // wider stencils: further batches of planes
+                unsigned char cc[B];
+                T xw[B];
 #pragma unroll
-            for (int k = 0; k < B; ++k) cc[k] = (k0 + k < W) ? plane[(size_t)(k0 + k) * HIPK_TILE] : (unsigned char)HIPK_SELL_PAD;
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (cc[k] != HIPK_SELL_PAD) xw[k] = x[row + doff[cc[k]]];
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (cc[k] != HIPK_SELL_PAD) {
-                    const T p = dval[cc[k]] * xw[k];
-                    s = s + p;
+                for (int k = 0; k < B; ++k) {
+                    cc[k] = HIPK_SELL_PAD;
+                    if (k0 + k < W) cc[k] = plane[(size_t)(k0 + k) * HIPK_TILE];
                 }
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const unsigned bo = (unsigned)(rowx + doff[cc[k]]) * (unsigned)sizeof(T);
+                    xw[k] = *(const T *)(xb + bo);
+                }
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const T p = dval[cc[k]] * xw[k];
+                    const T s1 = s + p;
+                    s = (cc[k] != HIPK_SELL_PAD) ? s1 : s;
+                }
+            }
         }
         double d0 = 0.0, d1 = 0.0;
-        if (row < a.n) {
+        if (row < n32) {
             T out = s;
             if (mode & HIPK_SPMV_RESID) out = brow - out;
             y[row] = out;
