@@ -139,7 +139,9 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
 
     // layout of the code bytes: sliced-ELL planes when the padding stays small, else CSR order + row lengths
     const char *lay = getenv("HIPK_SPMV_CODED_LAYOUT");
-    const bool want_sell = !(lay && strcmp(lay, "csr") == 0) && nc < HIPK_SELL_PAD + 1 && nc <= HIPK_SELL_PAD;
+    // (the persistent sliced-ELL kernel needs n_rows <= n_cols and 32-bit byte offsets into x)
+    const bool want_sell = !(lay && strcmp(lay, "csr") == 0) && nc <= HIPK_SELL_PAD && h->n_rows <= h->n_cols &&
+                           (uint64_t)h->n_cols * sizeof(T) < (1ull << 32);
     const int ntiles = (int)((h->n_rows + HIPK_TILE - 1) / HIPK_TILE);
     std::vector<int> toff;
     bool sell = false;
@@ -159,15 +161,15 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
         int64_t planes = 0;
         int wmin = INT32_MAX, wmax = 0;
         for (int i = 0; i < ntiles; ++i) {
-            const int w = toff[i];
+            const int w = hipk_sell_units(toff[i]);  // tile size in units of 256 B
             wmin = w < wmin ? w : wmin;
             wmax = w > wmax ? w : wmax;
             toff[i] = (int)planes;
             planes += w;
         }
         toff[ntiles] = (int)planes;
-        // nearly uniform widths (a stencil's first/last grid line is narrower): pad every tile to the widest,
-        // so that a tile's planes are found without the offset table (one dependent load less per workgroup)
+        // nearly uniform sizes (a stencil's first/last grid line is narrower): pad every tile to the largest,
+        // so that a tile is found without the offset table (one dependent load less per workgroup)
         const int64_t planes_u = (int64_t)ntiles * wmax;
         if (wmin != wmax && planes_u <= planes + planes / 50 + 8) {
             for (int i = 0; i <= ntiles; ++i) toff[i] = i * wmax;
@@ -330,17 +332,12 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         h->n_huge = cnt_h;
     }
     // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
-    h->coded_rows = 1;
-    h->sell_loop = 1;  // persistent sliced-ELL kernel, grid = sell_loop x 8 workgroups per CU (0: one tile per workgroup)
-    if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 0 ? 0 : (atoi(sl) > 4 ? 4 : atoi(sl));
+    h->sell_loop = 1;  // persistent sliced-ELL kernel: grid = sell_loop x the resident workgroups
+    if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 1 ? 1 : (atoi(sl) > 4 ? 4 : atoi(sl));
     {
         hipDeviceProp_t prop;
         h->n_cu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
-    }
-    if (const char *cr = getenv("HIPK_SPMV_CODED_ROWS")) {
-        const int v = atoi(cr);
-        if (v == 1 || v == 2 || v == 4) h->coded_rows = v;
     }
     const char *env = getenv("HIPK_SPMV_CODED");
     if (n_rows > 0 && nnz > 0 && h->max_row_len <= HIPK_LONG_ROW && !(env && env[0] == '0')) {
@@ -445,7 +442,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         a.dict_val = h->dict_val;
         a.n_codes = h->n_codes;
         a.code_cap = (h->max_tile_nnz + 32 + 15) & ~15;
-        const int R = h->coded_rows;
+        const int R = 1;
         const int nsuper = (ntiles + R - 1) / R;
         const int cgrid = ((nsuper + 7) >> 3) << 3;
         const size_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
@@ -453,13 +450,13 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         a.tile_off = h->tile_off;
         a.sell_w = h->sell_w;
         const bool sell = h->coded_layout == 2;
-        if (sell && h->sell_loop && h->n_rows <= h->n_cols && (uint64_t)h->n_cols * sv < (1ull << 32)) {
+        if (sell) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
-            // exact plane count for the common stencil widths, run-time width otherwise
+            // exact tile size for the common stencil widths, run-time size otherwise
             void (*kern)(hipk_spmv_args) = nullptr;
 #define HIPK_PICK_LOOP(T)                                                                              \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5> : h->sell_w == 7 ? hipk_spmv_sell_loop_kernel<T, 7> \
-     : h->sell_w == 3 ? hipk_spmv_sell_loop_kernel<T, 3> : hipk_spmv_sell_loop_kernel<T, 0>)
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8> \
+     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4> : hipk_spmv_sell_loop_kernel<T, 0>)
             kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double) : HIPK_PICK_LOOP(float);
 #undef HIPK_PICK_LOOP
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
@@ -479,18 +476,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             return HIPK_OK;
         }
         if (prof) prof->before(stream);
-#define HIPK_LAUNCH_CODED(T, RR)                                                   \
-    do {                                                                           \
-        if (sell)                                                                  \
-            hipk_spmv_sell_kernel<T, RR><<<cgrid, HIPK_THREADS, 0, stream>>>(a);   \
-        else                                                                       \
-            hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a); \
-    } while (0)
-        if (h->dtype == HIPK_F64) {
-            if (R == 4) HIPK_LAUNCH_CODED(double, 4); else if (R == 2) HIPK_LAUNCH_CODED(double, 2); else HIPK_LAUNCH_CODED(double, 1);
-        } else {
-            if (R == 4) HIPK_LAUNCH_CODED(float, 4); else if (R == 2) HIPK_LAUNCH_CODED(float, 2); else HIPK_LAUNCH_CODED(float, 1);
-        }
+#define HIPK_LAUNCH_CODED(T, RR) hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a)
+        if (h->dtype == HIPK_F64)
+            HIPK_LAUNCH_CODED(double, 1);
+        else
+            HIPK_LAUNCH_CODED(float, 1);
 #undef HIPK_LAUNCH_CODED
         if (prof) prof->after(stream);
         if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {

@@ -266,13 +266,22 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
 
 // ================================================================== sliced-ELL layout of the codes
 // The CSR-ordered code bytes above still make a workgroup wait three times in a row (tile bounds -> code bytes ->
-// x gather).  Storing the codes of a 256-row tile as W byte planes (W = longest row of the tile; plane k holds
-// the k-th entry of every row, byte t = row t; shorter rows are padded with HIPK_SELL_PAD) removes the first
-// wait, the row-length scan and the LDS staging: thread t reads byte t of each plane -- coalesced -- and goes
-// straight to the dictionary and the x gather.  Padding is skipped by predicate, never multiplied, so the sums
-// are formed from exactly the CSR entries in CSR order.  Cost: (W_tile * 256 - tile nnz) padding bytes; the
-// layout is built only when the planes take at most 2 x nnz bytes.
+// x gather) and cost a scan, an LDS copy and a barrier per tile.  The sliced-ELL layout stores the codes of a
+// 256-row tile column-wise: with W = the longest row of the tile, entry k of row t lives in
+//     dword plane k/4 (1 KB: one little-endian dword per row, byte k%4)           for k < 4 D
+//     byte plane k - 4 D (256 B: one byte per row), after the D dword planes       for the remaining Bp <= 2
+// where D = W/4 and Bp = W%4, except that W%4 == 3 takes one more dword plane instead of three byte planes.
+// A 5-point stencil tile is one dword plane + one byte plane = 1280 B: two coalesced loads per thread bring
+// a row's five codes.  Rows shorter than W are padded with HIPK_SELL_PAD, which is skipped by a select, never
+// multiplied, so row sums are formed from exactly the CSR entries in CSR order.  A tile's size is U = 4 D + Bp
+// units of 256 B (tile_off = prefix sum of U); the layout is built only when it takes at most 2 x nnz bytes.
 #define HIPK_SELL_PAD 255  // dictionary limited to 255 entries in this layout
+
+static inline int hipk_sell_units(int w) {  // host: units of 256 B of a tile whose longest row has w entries
+    const int d = w / 4 + ((w % 4 == 3) ? 1 : 0);
+    const int bp = (w % 4 == 3) ? 0 : w % 4;
+    return 4 * d + bp;
+}
 
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int *__restrict__ crow, int64_t n_rows,
                                                                        int *__restrict__ tile_w) {
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int
     }
 }
 
-// codes of row r, entry k -> plane k of r's tile (planes are prefilled with HIPK_SELL_PAD)
+// code of row r, entry k -> its byte in r's tile (the planes are prefilled with HIPK_SELL_PAD)
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
     const int *__restrict__ crow, const int *__restrict__ col, const T *__restrict__ val, int64_t n_rows,
@@ -301,7 +310,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const int lo = crow[r], hi = crow[r + 1];
-        unsigned char *plane = code + (size_t)tile_off[r >> 8] * HIPK_TILE + (r & 255);
+        const int o0 = tile_off[r >> 8], units = tile_off[(r >> 8) + 1] - o0;
+        const int D = units >> 2;
+        unsigned char *tilep = code + (size_t)o0 * HIPK_TILE;
+        const int t = (int)(r & 255);
         for (int j = lo; j < hi; ++j) {
             const int off = col[j] - (int)r;
             const unsigned long long bits = hipk_value_bits<T>(val[j]);
@@ -317,148 +329,32 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
                 if (k == 0) break;
                 s = (s + 1) & (HIPK_DICT_SLOTS - 1);
             }
-            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off)
+            const int k = j - lo;
+            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off || k >= 4 * D + (units & 3)) {
                 tb->fail = 1;
-            else
-                plane[(size_t)(j - lo) * HIPK_TILE] = (unsigned char)tb->slot_code[found];
-        }
-    }
-}
-
-template <typename T, int R>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_kernel(hipk_spmv_args a) {
-    constexpr int B = 8;  // entries handled per batch (all of a 5- or 7-point stencil row)
-    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
-    const int nsuper = (ntiles + R - 1) / R;
-    const int st = hipk_xcd_tile(blockIdx.x, nsuper);
-    if (st < 0) return;
-
-    __shared__ T dval[HIPK_CODED_MAX];
-    __shared__ int doff[HIPK_CODED_MAX];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const unsigned char *__restrict__ code = a.code;
-    const T *__restrict__ x = (const T *)a.x;
-    T *__restrict__ y = (T *)a.y;
-    const int mode = a.mode;
-
-    T dv = (T)0;
-    int dofs = 0;
-    if (t < a.n_codes) {
-        dv = ((const T *)a.dict_val)[t];
-        dofs = a.dict_off[t];
-    }
-    int64_t r0[R];
-    int nr[R], W[R];
-    const unsigned char *plane[R];
-    unsigned char c[R][B];
-    T wrow[R], brow[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int tile = st * R + i;
-        r0[i] = (int64_t)tile * HIPK_TILE;
-        nr[i] = tile < ntiles ? (int)((a.n - r0[i] < HIPK_TILE) ? (a.n - r0[i]) : HIPK_TILE) : 0;
-        W[i] = 0;
-        plane[i] = code;
-        wrow[i] = (T)0;
-        brow[i] = (T)0;
-#pragma unroll
-        for (int k = 0; k < B; ++k) c[i][k] = HIPK_SELL_PAD;
-        if (nr[i] > 0) {
-            if (a.sell_w > 0) {  // every tile has the same width: no offset table
-                W[i] = a.sell_w;
-                plane[i] = code + (size_t)tile * a.sell_w * HIPK_TILE + t;
             } else {
-                const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tile]);
-                const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tile + 1]);
-                W[i] = o1 - o0;
-                plane[i] = code + (size_t)o0 * HIPK_TILE + t;
+                const size_t pos = (k < 4 * D) ? (size_t)(k >> 2) * 1024 + (size_t)t * 4 + (k & 3)
+                                               : (size_t)D * 1024 + (size_t)(k - 4 * D) * HIPK_TILE + t;
+                tilep[pos] = (unsigned char)tb->slot_code[found];
             }
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (k < W[i]) c[i][k] = plane[i][(size_t)k * HIPK_TILE];
-            if (t < nr[i]) {
-                if (mode & HIPK_SPMV_DOT_W) wrow[i] = ((const T *)a.w)[r0[i] + t];
-                if (mode & HIPK_SPMV_RESID) brow[i] = ((const T *)a.bsub)[r0[i] + t];
-            }
-        }
-    }
-    // stop word: read with the loads above in flight; nothing stored yet
-    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
-    if (t < a.n_codes) {
-        dval[t] = dv;
-        doff[t] = dofs;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        if (nr[i] == 0) continue;
-        const int64_t row = r0[i] + t;
-        T s = (T)0;
-        {
-            T xv[B];
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (c[i][k] != HIPK_SELL_PAD) xv[k] = x[row + doff[c[i][k]]];
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (c[i][k] != HIPK_SELL_PAD) {
-                    const T p = dval[c[i][k]] * xv[k];
-                    s = s + p;
-                }
-        }
-        for (int k0 = B; k0 < W[i]; k0 += B) {  // wider stencils: further batches of planes
-            unsigned char cc[B];
-            T xv[B];
-#pragma unroll
-            for (int k = 0; k < B; ++k) cc[k] = (k0 + k < W[i]) ? plane[i][(size_t)(k0 + k) * HIPK_TILE] : HIPK_SELL_PAD;
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (cc[k] != HIPK_SELL_PAD) xv[k] = x[row + doff[cc[k]]];
-#pragma unroll
-            for (int k = 0; k < B; ++k)
-                if (cc[k] != HIPK_SELL_PAD) {
-                    const T p = dval[cc[k]] * xv[k];
-                    s = s + p;
-                }
-        }
-        double d0 = 0.0, d1 = 0.0;
-        if (t < nr[i]) {
-            T out = s;
-            if (mode & HIPK_SPMV_RESID) out = brow[i] - out;
-            y[row] = out;
-            if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow[i] * (double)out;
-            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
-        }
-        const size_t tp = (size_t)(st * R + i) * 4 + wave;
-        if (mode & HIPK_SPMV_DOT_W) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
-            if (lane == 0) a.tpart0[tp] = d0;
-        }
-        if (mode & HIPK_SPMV_DOT_YY) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
-            if (lane == 0) a.tpart1[tp] = d1;
         }
     }
 }
 
-// Persistent form of the sliced-ELL kernel.  The one-tile-per-workgroup kernel above is bound by what every
-// workgroup does ONCE -- kernel arguments, dictionary -> LDS, barrier, stop word -- plus two dependent waits per
-// tile (code planes, x gather): ~3 us per wavefront for ~5 KB of traffic.  Here the grid is the number of
-// resident workgroups; each walks its share of the tiles of its XCD's eighth of the matrix with the NEXT
-// tile's code bytes (and epilogue operands) already requested while the current tile's x gathers are in flight.
-// The loop body is branch free: padding codes read dictionary slot 255 (offset 0, value 0) and are kept out of
-// the sum by a select, never by arithmetic; WB > 0 instantiates the exact plane count of a uniform-width matrix
-// (5 for a 5-point stencil), WB == 0 takes the width at run time in batches of 8 planes.
-// Requires n_rows <= n_cols (padding lanes read x[min(row, n_rows-1)]) and n_cols * sizeof(T) < 4 GiB
-// (32-bit byte offsets: one shift + one add per gather).
-template <typename T, int WB>
+// Persistent kernel.  A one-tile-per-workgroup kernel is bound by what every workgroup does ONCE (kernel
+// arguments, dictionary -> LDS, barrier, stop word) plus two dependent waits per tile (codes, x gather): ~3 us
+// per wavefront for ~5 KB of traffic.  Here the grid is the number of resident workgroups; each walks its share
+// of the tiles of its XCD's eighth of the matrix with the NEXT tile's codes (two packed dwords = 8 entries) and
+// epilogue operands already requested while the current tile's x gathers are in flight.  The loop body is branch
+// free: padding codes read dictionary slot 255 (offset 0, value 0) and are kept out of the sum by a select.
+// UNITS > 0 instantiates the exact tile size of a uniform matrix (5: 5-point stencil; 4: width 3-4; 8: width 7-8),
+// UNITS == 0 reads tile_off and walks further groups of four codes at run time.
+// Requires n_rows <= n_cols (padding lanes read x[min(row, n_rows-1)]) and n_cols * sizeof(T) < 4 GiB (32-bit byte
+// offsets: one shift + one add per gather).
+template <typename T, int UNITS>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
-    constexpr int B = WB > 0 ? WB : 8;
+    constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
+    static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
     const int per = (ntiles + 7) >> 3;       // tiles per XCD eighth
     const int gp = (int)gridDim.x >> 3;      // workgroups per XCD (grid is a multiple of 8)
@@ -482,26 +378,36 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         dv = ((const T *)a.dict_val)[t];
         dofs = a.dict_off[t];
     }
-    unsigned char cn[B];
+    // group g of a tile with D dword planes and Bp byte planes: four codes packed in a dword, padding = 0xFF
+    auto load_group = [&](const unsigned char *tp, int D, int Bp, int g) -> unsigned {
+        if (g < D) return ((const unsigned *)tp)[g * HIPK_TILE + t];
+        unsigned w = 0xFFFFFFFFu;
+        if (g == D) {
+            const unsigned char *bp = tp + (size_t)D * 1024 + t;
+            if (Bp >= 1) w = (w & 0xFFFFFF00u) | bp[0];
+            if (Bp >= 2) w = (w & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
+        }
+        return w;
+    };
+    unsigned cn[G0];
     T wn = (T)0, bn = (T)0;
-    int Wn = 0;
+    int Dn = 0, Bn = 0;
     const unsigned char *pn = code;
-    auto request = [&](int tl) {  // tile tl's first B planes and epilogue operands
+    auto request = [&](int tl) {  // tile tl's first G0 groups and epilogue operands
         const int r0 = tl * HIPK_TILE;
-        if (WB > 0) {
-            Wn = WB;
-            pn = code + (size_t)tl * (WB * HIPK_TILE) + t;
+        if (UNITS > 0) {
+            Dn = UNITS >> 2;
+            Bn = UNITS & 3;
+            pn = code + (size_t)tl * (UNITS * HIPK_TILE);
         } else {
             const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tl]);
             const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tl + 1]);
-            Wn = o1 - o0;
-            pn = code + (size_t)o0 * HIPK_TILE + t;
+            Dn = (o1 - o0) >> 2;
+            Bn = (o1 - o0) & 3;
+            pn = code + (size_t)o0 * HIPK_TILE;
         }
 #pragma unroll
-        for (int k = 0; k < B; ++k) {
-            cn[k] = HIPK_SELL_PAD;
-            if (WB > 0 || k < Wn) cn[k] = pn[k * HIPK_TILE];  // Wn is wavefront-uniform: scalar branch
-        }
+        for (int g = 0; g < G0; ++g) cn[g] = load_group(pn, Dn, Bn, g);
         wn = (T)0;
         bn = (T)0;
         if (r0 + t < n32) {
@@ -517,18 +423,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     __syncthreads();
 
     while (tile < ntiles) {
-        unsigned char c[B];
+        unsigned c[G0];
 #pragma unroll
-        for (int k = 0; k < B; ++k) c[k] = cn[k];
+        for (int g = 0; g < G0; ++g) c[g] = cn[g];
         const T wrow = wn, brow = bn;
-        const int W = Wn;
-        const unsigned char *plane = pn;
+        const int D = Dn, Bp = Bn;
+        const unsigned char *tp = pn;
         const int row = tile * HIPK_TILE + t;
         const int rowx = row < n32 ? row : n32 - 1;
-        T xv[B];
+        constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
+        T xv[NE];
 #pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const unsigned bo = (unsigned)(rowx + doff[c[k]]) * (unsigned)sizeof(T);
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
             xv[k] = *(const T *)(xb + bo);
         }
         // next tile of this workgroup: its bytes travel while the gathers above are outstanding
@@ -537,30 +445,29 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         if (next < ntiles) request(next);
         T s = (T)0;
 #pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const T p = dval[c[k]] * xv[k];
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const T p = dval[ck] * xv[k];
             const T s1 = s + p;
-            s = (c[k] != HIPK_SELL_PAD) ? s1 : s;
+            s = (ck != HIPK_SELL_PAD) ? s1 : s;
         }
-        if (WB == 0) {
-            for (int k0 = B; k0 < W; k0 += B) {  // wider stencils: further batches of planes
-                unsigned char cc[B];
-                T xw[B];
+        if (UNITS == 0) {
+            const int groups = D + (Bp > 0 ? 1 : 0);
+            for (int g = G0; g < groups; ++g) {  // wider stencils: further groups of four codes
+                const unsigned cw = load_group(tp, D, Bp, g);
+                T xw[4];
 #pragma unroll
-                for (int k = 0; k < B; ++k) {
-                    cc[k] = HIPK_SELL_PAD;
-                    if (k0 + k < W) cc[k] = plane[(size_t)(k0 + k) * HIPK_TILE];
-                }
-#pragma unroll
-                for (int k = 0; k < B; ++k) {
-                    const unsigned bo = (unsigned)(rowx + doff[cc[k]]) * (unsigned)sizeof(T);
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned ck = (cw >> (k * 8)) & 0xFFu;
+                    const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
                     xw[k] = *(const T *)(xb + bo);
                 }
 #pragma unroll
-                for (int k = 0; k < B; ++k) {
-                    const T p = dval[cc[k]] * xw[k];
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned ck = (cw >> (k * 8)) & 0xFFu;
+                    const T p = dval[ck] * xw[k];
                     const T s1 = s + p;
-                    s = (cc[k] != HIPK_SELL_PAD) ? s1 : s;
+                    s = (ck != HIPK_SELL_PAD) ? s1 : s;
                 }
             }
         }
@@ -572,16 +479,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
-        const size_t tp = (size_t)tile * 4 + wave;
+        const size_t tpi = (size_t)tile * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
-            if (lane == 0) a.tpart0[tp] = d0;
+            if (lane == 0) a.tpart0[tpi] = d0;
         }
         if (mode & HIPK_SPMV_DOT_YY) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
-            if (lane == 0) a.tpart1[tp] = d1;
+            if (lane == 0) a.tpart1[tpi] = d1;
         }
         tile = next;
     }

@@ -94,11 +94,10 @@ struct hipk_csr_s {
     void *dict_val;         // device, 256 values of `dtype`
     int n_codes;            // 0: no coded form
     int path_override;      // hipk_csr_set_path: 0 auto, 1 never use the coded form
-    int coded_rows;         // 256-row tiles per workgroup of the coded kernel (1, 2 or 4)
-    int coded_layout;       // 1: codes in CSR order (+ rowlen); 2: sliced-ELL byte planes (tile_off / sell_w)
+    int coded_layout;       // 1: codes in CSR order (+ rowlen); 2: sliced-ELL planes (tile_off / sell_w)
     int *tile_off;          // device, ntiles + 1 (sliced-ELL)
-    int sell_w;             // uniform tile width or 0
-    int64_t sell_bytes;     // bytes of the planes
+    int sell_w;             // uniform tile size in units of 256 B, or 0
+    int64_t sell_bytes;     // bytes of all tiles
     int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)
     int n_cu;               // compute units of the device
 };

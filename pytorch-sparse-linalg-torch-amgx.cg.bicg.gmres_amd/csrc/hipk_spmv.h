@@ -55,8 +55,8 @@ struct hipk_spmv_args {
     const void *dict_val;
     int n_codes;
     int code_cap;  // bytes of LDS per tile for the code bytes
-    const int *tile_off;  // sliced-ELL layout: prefix sum of the tile widths (planes of 256 bytes), ntiles + 1
-    int sell_w;           //   > 0: every tile has this width (tile_off unused)
+    const int *tile_off;  // sliced-ELL layout: prefix sum of the tile sizes (units of 256 bytes), ntiles + 1
+    int sell_w;           //   > 0: every tile has this size
 };
 
 #ifdef __HIPCC__

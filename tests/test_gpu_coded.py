@@ -56,14 +56,14 @@ def test_fixture_stencils_take_the_coded_path_and_match(hipk, oracle, case):
     assert h.format_bytes() < h.spmv_bytes()
 
 
-@pytest.mark.parametrize("layout", ["sell", "sell-tile", "csr"])
-@pytest.mark.parametrize("rows_per_wg", ["1", "2", "4"])
+@pytest.mark.parametrize("layout", ["sell", "sell-x2", "csr"])
+@pytest.mark.parametrize("offsets", [[-300, -1, 0, 1, 300], [-1, 0, 1], [-40, -7, -1, 0, 1, 7, 40], [0, 5, 9, 11, 50, 51]])
 @pytest.mark.parametrize("n", [1, 255, 256, 257, 1023, 70_001, 1_200_011])
-def test_coded_tile_boundaries_and_rows_per_workgroup(hipk, oracle, n, rows_per_wg, layout, monkeypatch):
-    monkeypatch.setenv("HIPK_SPMV_CODED_ROWS", rows_per_wg)
+def test_coded_tile_boundaries_layouts_and_widths(hipk, oracle, n, offsets, layout, monkeypatch):
     monkeypatch.setenv("HIPK_SPMV_CODED_LAYOUT", layout.split("-")[0])
-    monkeypatch.setenv("HIPK_SPMV_SELL_LOOP", "0" if layout == "sell-tile" else "1")   # persistent / tile per workgroup
-    crow, col, val = banded(n, [-300, -1, 0, 1, 300], lambda r, k: np.array([-1.0, -1.5, 4.0, -1.5, -1.0])[k])
+    monkeypatch.setenv("HIPK_SPMV_SELL_LOOP", "2" if layout == "sell-x2" else "1")   # grid = 2 x resident workgroups
+    vals = np.array([-1.0, -1.5, 4.0, -1.25, -1.75, 0.5, 3.0])
+    crow, col, val = banded(n, offsets, lambda r, k: vals[k])
     h = make_handle(hipk, crow, col, val, n)
     x = np.random.default_rng(n).standard_normal(n)
     y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV))

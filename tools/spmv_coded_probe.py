@@ -48,11 +48,8 @@ def cg_rate(h):
 
 
 rows = []
-for label, env_rows, plain, layout, loop in (("plain", "1", True, "sell", "0"), ("coded csr R=1", "1", False, "csr", "0"),
-                                             ("coded sell R=1", "1", False, "sell", "0"),
-                                             ("coded sell loop x1", "1", False, "sell", "1"),
-                                             ("coded sell loop x2", "1", False, "sell", "2")):
-    os.environ["HIPK_SPMV_CODED_ROWS"] = env_rows
+for label, plain, layout, loop in (("plain", True, "sell", "1"), ("coded csr", False, "csr", "1"),
+                                   ("coded sell loop x1", False, "sell", "1"), ("coded sell loop x2", False, "sell", "2")):
     os.environ["HIPK_SPMV_CODED_LAYOUT"] = layout
     os.environ["HIPK_SPMV_SELL_LOOP"] = loop
     t0 = time.perf_counter()
