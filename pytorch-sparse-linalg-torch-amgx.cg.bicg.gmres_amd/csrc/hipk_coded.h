@@ -389,72 +389,84 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
         return w;
     };
-    unsigned cn[G0];
-    T wn = (T)0, bn = (T)0;
-    int Dn = 0, Bn = 0;
-    const unsigned char *pn = code;
-    auto request = [&](int tl) {  // tile tl's first G0 groups and epilogue operands
+    struct req_t {  // what a tile needs before its x gathers can be issued
+        unsigned c[G0];
+        T w, b;
+        int D, Bp;
+        const unsigned char *tp;
+    };
+    constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
+    auto request = [&](int tl, req_t &q) {  // tile tl's first G0 groups and epilogue operands
         const int r0 = tl * HIPK_TILE;
         if (UNITS > 0) {
-            Dn = UNITS >> 2;
-            Bn = UNITS & 3;
-            pn = code + (size_t)tl * (UNITS * HIPK_TILE);
+            q.D = UNITS >> 2;
+            q.Bp = UNITS & 3;
+            q.tp = code + (size_t)tl * (UNITS * HIPK_TILE);
         } else {
             const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tl]);
             const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tl + 1]);
-            Dn = (o1 - o0) >> 2;
-            Bn = (o1 - o0) & 3;
-            pn = code + (size_t)o0 * HIPK_TILE;
+            q.D = (o1 - o0) >> 2;
+            q.Bp = (o1 - o0) & 3;
+            q.tp = code + (size_t)o0 * HIPK_TILE;
         }
 #pragma unroll
-        for (int g = 0; g < G0; ++g) cn[g] = load_group(pn, Dn, Bn, g);
-        wn = (T)0;
-        bn = (T)0;
+        for (int g = 0; g < G0; ++g) q.c[g] = load_group(q.tp, q.D, q.Bp, g);
+        q.w = (T)0;
+        q.b = (T)0;
         if (r0 + t < n32) {
-            if (mode & HIPK_SPMV_DOT_W) wn = ((const T *)a.w)[r0 + t];
-            if (mode & HIPK_SPMV_RESID) bn = ((const T *)a.bsub)[r0 + t];
+            if (mode & HIPK_SPMV_DOT_W) q.w = ((const T *)a.w)[r0 + t];
+            if (mode & HIPK_SPMV_RESID) q.b = ((const T *)a.bsub)[r0 + t];
         }
     };
-    int tile = (idx < per) ? xcd * per + idx : ntiles;
-    if (tile < ntiles) request(tile);
+    auto gather = [&](const req_t &q, int tl, T(&xv)[NE]) {
+        const int row = tl * HIPK_TILE + t;
+        const int rowx = row < n32 ? row : n32 - 1;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (q.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
+            xv[k] = *(const T *)(xb + bo);
+        }
+    };
+    auto next_tile = [&]() -> int {  // advances this workgroup's position in its XCD's eighth
+        idx += gp;
+        return (idx < per) ? xcd * per + idx : ntiles;
+    };
+
+    // three tiles in flight per workgroup: codes of tile j+2, x gathers of tile j+1, arithmetic of tile j.  The
+    // gathers include the compulsory HBM misses of x (every line is first touched by some tile), so they need
+    // a full iteration of lead just like the code bytes.
+    req_t rc, rn, rnn;
+    T xc[NE], xn[NE];
+    int tc = (idx < per) ? xcd * per + idx : ntiles;
+    if (tc < ntiles) request(tc, rc);
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
     doff[t] = dofs;
     __syncthreads();
+    int tn = (tc < ntiles) ? next_tile() : ntiles;
+    if (tn < ntiles) request(tn, rn);
+    if (tc < ntiles) gather(rc, tc, xc);
 
-    while (tile < ntiles) {
-        unsigned c[G0];
-#pragma unroll
-        for (int g = 0; g < G0; ++g) c[g] = cn[g];
-        const T wrow = wn, brow = bn;
-        const int D = Dn, Bp = Bn;
-        const unsigned char *tp = pn;
-        const int row = tile * HIPK_TILE + t;
-        const int rowx = row < n32 ? row : n32 - 1;
-        constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
-        T xv[NE];
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
-            xv[k] = *(const T *)(xb + bo);
-        }
-        // next tile of this workgroup: its bytes travel while the gathers above are outstanding
-        idx += gp;
-        const int next = (idx < per) ? xcd * per + idx : ntiles;
-        if (next < ntiles) request(next);
+    while (tc < ntiles) {
+        const int tnn = (tn < ntiles) ? next_tile() : ntiles;
+        if (tnn < ntiles) request(tnn, rnn);
+        if (tn < ntiles) gather(rn, tn, xn);
+
+        const int row = tc * HIPK_TILE + t;
         T s = (T)0;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const T p = dval[ck] * xv[k];
+            const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const T p = dval[ck] * xc[k];
             const T s1 = s + p;
             s = (ck != HIPK_SELL_PAD) ? s1 : s;
         }
         if (UNITS == 0) {
-            const int groups = D + (Bp > 0 ? 1 : 0);
+            const int groups = rc.D + (rc.Bp > 0 ? 1 : 0);
+            const int rowx = row < n32 ? row : n32 - 1;
             for (int g = G0; g < groups; ++g) {  // wider stencils: further groups of four codes
-                const unsigned cw = load_group(tp, D, Bp, g);
+                const unsigned cw = load_group(rc.tp, rc.D, rc.Bp, g);
                 T xw[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -474,12 +486,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         double d0 = 0.0, d1 = 0.0;
         if (row < n32) {
             T out = s;
-            if (mode & HIPK_SPMV_RESID) out = brow - out;
+            if (mode & HIPK_SPMV_RESID) out = rc.b - out;
             y[row] = out;
-            if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow * (double)out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)rc.w * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
-        const size_t tpi = (size_t)tile * 4 + wave;
+        const size_t tpi = (size_t)tc * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
@@ -490,7 +502,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
             if (lane == 0) a.tpart1[tpi] = d1;
         }
-        tile = next;
+        rc = rn;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) xc[k] = xn[k];
+        rn = rnn;
+        tc = tn;
+        tn = tnn;
     }
 }
 #endif
