@@ -332,6 +332,8 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         h->n_huge = cnt_h;
     }
     // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
+    h->sell_chunked = 1;  // allow the chunk-per-workgroup form of the persistent kernel (HIPK_SPMV_SELL_CHUNKED=0: never)
+    if (const char *sc = getenv("HIPK_SPMV_SELL_CHUNKED")) h->sell_chunked = atoi(sc) != 0;
     h->sell_loop = 1;  // persistent sliced-ELL kernel: grid = sell_loop x the resident workgroups
     if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 1 ? 1 : (atoi(sl) > 4 ? 4 : atoi(sl));
     {
@@ -453,21 +455,31 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         if (sell) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
             // exact tile size for the common stencil widths, run-time size otherwise
+            const int tpc = a.ch / 256;
             void (*kern)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_LOOP(T)                                                                              \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8> \
-     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4> : hipk_spmv_sell_loop_kernel<T, 0>)
-            kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double) : HIPK_PICK_LOOP(float);
-#undef HIPK_PICK_LOOP
+#define HIPK_PICK_LOOP(T, C)                                                                                 \
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C> \
+     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C> : hipk_spmv_sell_loop_kernel<T, 0, C>)
+            kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
-            int lgrid = h->n_cu * occ * h->sell_loop;
-            if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
-            lgrid = ((lgrid + 7) >> 3) << 3;
+            const int slots = h->n_cu * occ;
+            // one workgroup per reduction chunk when the chunks about fill the machine in one round
+            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && 2 * a.g >= slots;
+            int lgrid;
+            if (chunked) {
+                kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
+                lgrid = hipk_xcd_grid(a.g);
+            } else {
+                lgrid = slots * h->sell_loop;
+                if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
+                lgrid = ((lgrid + 7) >> 3) << 3;
+            }
+#undef HIPK_PICK_LOOP
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);
-            if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+            if (!chunked && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
                 hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                     (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
                     a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);

@@ -351,7 +351,14 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // UNITS == 0 reads tile_off and walks further groups of four codes at run time.
 // Requires n_rows <= n_cols (padding lanes read x[min(row, n_rows-1)]) and n_cols * sizeof(T) < 4 GiB (32-bit byte
 // offsets: one shift + one add per gather).
-template <typename T, int UNITS>
+//
+// CHUNKED = false: workgroup b walks tiles idx, idx + gp, .. of its XCD's eighth and stores the four wavefront sums
+//   of each tile's fused dot; hipk_tile_combine_kernel folds them into chunk partials afterwards.
+// CHUNKED = true (large systems: about as many reduction chunks as resident workgroups): one workgroup per
+//   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
+//   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
+#define HIPK_SELL_MAX_TPC 64  // tiles per chunk the chunked form holds in LDS (chunks up to 16384 rows)
+template <typename T, int UNITS, bool CHUNKED>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
     static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
@@ -360,6 +367,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     const int gp = (int)gridDim.x >> 3;      // workgroups per XCD (grid is a multiple of 8)
     const int xcd = blockIdx.x & 7;
     int idx = blockIdx.x >> 3;               // position inside the eighth; advances by gp
+    const int tpc = a.ch / HIPK_TILE;        // tiles per reduction chunk
+    const int chunk = CHUNKED ? hipk_xcd_chunk(blockIdx.x, a.g) : 0;
+    if (CHUNKED && chunk < 0) return;
+    const int t_first = chunk * tpc;
+    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;  // CHUNKED: this workgroup's tiles
+    __shared__ double wsum0[CHUNKED ? HIPK_SELL_MAX_TPC * 4 : 1];
+    __shared__ double wsum1[CHUNKED ? HIPK_SELL_MAX_TPC * 4 : 1];
 
     __shared__ T dval[HIPK_CODED_MAX];
     __shared__ int doff[HIPK_CODED_MAX];
@@ -428,30 +442,35 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             xv[k] = *(const T *)(xb + bo);
         }
     };
-    auto next_tile = [&]() -> int {  // advances this workgroup's position in its XCD's eighth
+    int cur = CHUNKED ? t_first : 0;
+    auto first_tile = [&]() -> int {
+        if (CHUNKED) return (t_first < t_end) ? t_first : ntiles;
+        return (idx < per && xcd * per + idx < ntiles) ? xcd * per + idx : ntiles;
+    };
+    auto next_tile = [&]() -> int {  // this workgroup's next tile, ntiles when it has none left
+        if (CHUNKED) {
+            ++cur;
+            return (cur < t_end) ? cur : ntiles;
+        }
         idx += gp;
-        return (idx < per) ? xcd * per + idx : ntiles;
+        return (idx < per && xcd * per + idx < ntiles) ? xcd * per + idx : ntiles;
     };
 
-    // three tiles in flight per workgroup: codes of tile j+2, x gathers of tile j+1, arithmetic of tile j.  The
-    // gathers include the compulsory HBM misses of x (every line is first touched by some tile), so they need
-    // a full iteration of lead just like the code bytes.
-    req_t rc, rn, rnn;
-    T xc[NE], xn[NE];
-    int tc = (idx < per) ? xcd * per + idx : ntiles;
+    // two tiles in flight per workgroup: the next tile's codes and epilogue operands travel while the current
+    // tile's x gathers are outstanding (a third stage -- gathers one tile ahead -- measured no better)
+    req_t rc, rn;
+    T xc[NE];
+    int tc = first_tile();
     if (tc < ntiles) request(tc, rc);
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
     doff[t] = dofs;
     __syncthreads();
-    int tn = (tc < ntiles) ? next_tile() : ntiles;
-    if (tn < ntiles) request(tn, rn);
-    if (tc < ntiles) gather(rc, tc, xc);
 
     while (tc < ntiles) {
-        const int tnn = (tn < ntiles) ? next_tile() : ntiles;
-        if (tnn < ntiles) request(tnn, rnn);
-        if (tn < ntiles) gather(rn, tn, xn);
+        gather(rc, tc, xc);
+        const int tn = next_tile();
+        if (tn < ntiles) request(tn, rn);
 
         const int row = tc * HIPK_TILE + t;
         T s = (T)0;
@@ -491,23 +510,39 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             if (mode & HIPK_SPMV_DOT_W) d0 = (double)rc.w * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
+        // fused dots: per-wavefront sums (shuffle tree 32..1) -> LDS (CHUNKED) or the tile-partial scratch
+        const int slot = CHUNKED ? (tc - t_first) * 4 + wave : 0;
         const size_t tpi = (size_t)tc * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
-            if (lane == 0) a.tpart0[tpi] = d0;
+            if (lane == 0) {
+                if (CHUNKED) wsum0[slot] = d0; else a.tpart0[tpi] = d0;
+            }
         }
         if (mode & HIPK_SPMV_DOT_YY) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
-            if (lane == 0) a.tpart1[tpi] = d1;
+            if (lane == 0) {
+                if (CHUNKED) wsum1[slot] = d1; else a.tpart1[tpi] = d1;
+            }
         }
         rc = rn;
-#pragma unroll
-        for (int k = 0; k < NE; ++k) xc[k] = xn[k];
-        rn = rnn;
         tc = tn;
-        tn = tnn;
+    }
+    if (CHUNKED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
+        __syncthreads();
+        if (wave == 0) {  // the combine kernel's fold, on the LDS copy of this chunk's wavefront sums
+            const int cnt = t_end - t_first;
+            if (mode & HIPK_SPMV_DOT_W) {
+                const double r = hipk_wave_fold(wsum0, cnt, lane);
+                if (lane == 0) a.part0[chunk] = r;
+            }
+            if (mode & HIPK_SPMV_DOT_YY) {
+                const double r = hipk_wave_fold(wsum1, cnt, lane);
+                if (lane == 0) a.part1[chunk] = r;
+            }
+        }
     }
 }
 #endif

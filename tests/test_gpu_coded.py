@@ -210,13 +210,48 @@ def test_whole_solves_identical_on_both_paths(hipk, solver):
     assert res[False][2] == 0
 
 
-@pytest.mark.parametrize("nx", [2000])
-def test_full_size_poisson_coded_equals_plain(hipk, nx):
-    """BASELINE config 2 matrix (N = 4M): both paths give the same bits; the coded form streams < 30 % of the bytes."""
+def _spmv_ex_all_modes(hipk, h, x, w, b):
+    L = hipk.lib()
+    G = int(L.hipk_chunk_count(x.numel()))
+    y = torch.empty_like(x)
+    p0 = torch.zeros(G, dtype=torch.float64, device=DEV)
+    p1 = torch.zeros(G, dtype=torch.float64, device=DEV)
+    hipk._check(L.hipk_spmv_ex(h._h, x.data_ptr(), y.data_ptr(), 7, w.data_ptr(), b.data_ptr(), p0.data_ptr(),
+                               p1.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream), "hipk_spmv_ex")
+    return y.cpu().numpy(), p0.cpu().numpy(), p1.cpu().numpy()
+
+
+@pytest.mark.parametrize("chunked", ["1", "0"])
+def test_full_size_poisson_coded_equals_plain(hipk, chunked, monkeypatch):
+    """BASELINE config 2 matrix (N = 4M): y and the chunk partials of both fused dots are the same bits on the plain
+    path, on the persistent coded kernel with a combine launch (chunked=0) and on its chunk-per-workgroup form
+    that folds the partials itself (chunked=1); the coded form streams < 30 % of the bytes."""
     from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    monkeypatch.setenv("HIPK_SPMV_SELL_CHUNKED", chunked)
+    nx = 2000
     A = create_poisson_2d_csr(nx, nx, device=DEV)
-    h = hipk.handle_for(A)
-    x = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
-    y_coded, y_plain = both_paths(hipk, h, x)
-    assert np.array_equal(y_coded, y_plain)
-    assert h.format_bytes() < 0.3 * h.spmv_bytes()
+    h = hipk.CsrHandle(A.crow_indices(), A.col_indices(), A.values(), A.shape)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x, w, b = (torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
+    assert h.path() == "coded" and h.format_bytes() < 0.3 * h.spmv_bytes()
+    coded = _spmv_ex_all_modes(hipk, h, x, w, b)
+    h.set_path(plain_only=True)
+    plain = _spmv_ex_all_modes(hipk, h, x, w, b)
+    for a, c in zip(coded, plain):
+        assert np.array_equal(a, c)
+
+
+def test_chunked_form_with_a_ragged_last_chunk_and_larger_chunks(hipk, oracle):
+    """n = 5M + 77 rows: chunk size 4096 (16 tiles per chunk), last chunk and last tile partial."""
+    n = 5_000_077
+    crow, col, val = banded(n, [-1500, -1, 0, 1, 1500], lambda r, k: np.array([-1.0, -1.0, 4.0, -1.0, -1.0])[k])
+    h = make_handle(hipk, crow, col, val, n)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x, w, b = (torch.randn(n, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
+    assert h.path() == "coded"
+    coded = _spmv_ex_all_modes(hipk, h, x, w, b)
+    h.set_path(plain_only=True)
+    plain = _spmv_ex_all_modes(hipk, h, x, w, b)
+    for a, c in zip(coded, plain):
+        assert np.array_equal(a, c)
+    assert np.array_equal(coded[0], b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy()))
