@@ -8,8 +8,10 @@ surface, TSL:1019) on synthetic input already resident in HBM:
   * N > 1: the row-partitioned solver (one rank per GPU, RCCL halo exchange + partial-sum
     all-gather); weak scaling: every rank owns a 2000 x 2000 slab (grid (2000 N) x 2000), so the
     per-GPU work is fixed.  `value` = (ranks x iterations) / time = 4M-row CG iterations/s.
-One JSON line is printed by rank 0.  Extra objects: `roofline` (fused SpMV+dot kernel, HIP
-events around its launches inside the solver loop, algorithmic bytes of SURVEY 8d) and
+One JSON line is printed by rank 0.  Extra objects: `kernels` (the three kernels of the CG iteration,
+HIP events around their launches inside the solver loop, algorithmic bytes), `roofline` (the
+longest of them), `spmv` (the SpMV GB/s of the metric; the Poisson matrix takes the coded path --
+one byte per entry -- so the general CSR kernels are measured beside it on the same matrix) and
 `cpu_baseline` (the oracle's C restatement on the host cores, bounded sample).
 """
 import argparse
@@ -28,6 +30,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 NX = 2000
+PMC_FILE = "r01h_pmc_kernels.json"   # per-kernel HBM traffic from the committed rocprofv3 --pmc passes
 
 
 def parse():
@@ -149,41 +152,92 @@ def main():
         dt = tt.item()
     x, info, st = last
 
-    # ---- roofline leg: the fused SpMV+dot kernel timed with HIP events around its launches
-    # inside the solver loop (params.profile), same inputs, right after the timed region.
+    # ---- roofline leg: each kernel of the CG iteration timed with HIP events around its launches INSIDE the
+    # solver loop (params.profile selects the kernel; empty-event-pair overhead subtracted), same inputs, right
+    # after the timed region.  `roofline` is the dominant (longest) kernel; `kernels` lists all three.
     roof = None
     spmv_standalone = None
+    kernels = None
+    spmv_report = None
     if world == 1:
-        xx = torch.zeros_like(b)
-        pst = _hipk.solve("cg", h, b, xx, tol=args.tol, atol=0.0, maxiter=256, profile=True)
-        ach = spmv_bytes / (pst.spmv_ms_avg * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from the committed PMC passes (collected separately with rocprofv3 --pmc)
+        n = nx * nx
+        sv = 8
+        pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_spmv.json")))
             if nx == NX:
-                traffic = pmc["traffic_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials), "
-                                          "timed inside the CG loop",
-                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": "profiles/r01g_pmc_spmv.json (2*FETCH_SIZE + WRITE_SIZE)",
-                "avg_launch_us": pst.spmv_ms_avg * 1e3, "launches_timed": pst.spmv_profiled,
-                "event_pair_overhead_us_subtracted": pst.event_overhead_ms * 1e3,
-                "algorithmic_bytes_per_launch": spmv_bytes}
-        g = torch.Generator(device=dev).manual_seed(0)
-        xr = torch.randn(nx * nx, dtype=torch.float64, device=dev, generator=g)
-        yr = torch.empty_like(xr)
-        for _ in range(20):
-            _hipk.spmv(h, xr, out=yr)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(200):
-            _hipk.spmv(h, xr, out=yr)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 200
-        spmv_standalone = {"us": ms * 1e3, "GB/s": spmv_bytes / (ms * 1e-3) / 1e9, "reps": 200}
+
+        def in_loop(which, handle=h):
+            xx = torch.zeros_like(b)
+            pst = _hipk.solve("cg", handle, b, xx, tol=args.tol, atol=0.0, maxiter=256, profile=which)
+            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled, pst.event_overhead_ms * 1e3
+
+        path = h.path()
+        spmv_name = {"coded": "hipk_spmv_sell_loop_kernel<double,5,true> (coded SpMV + fused <p,Ap> chunk partials)",
+                     "tile_fast": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, path)
+        legs = [("spmv", 1, spmv_name, spmv_bytes, "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
+                ("cg_update", 2, "hipk_cg_update_kernel<double> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
+                 "read Ap, r; write r = 24 n"),
+                ("cg_direction", 3, "hipk_cg_direction_kernel<double> (x += alpha p, p = r + beta p)", 5 * n * sv,
+                 "read r, p, x; write p, x = 40 n")]
+        kernels = []
+        for key, which, name, nbytes, what in legs:
+            us, cnt, over = in_loop(which)
+            kernels.append({"key": key, "kernel": name, "avg_launch_us": us, "launches_timed": cnt,
+                            "algorithmic_bytes_per_launch": nbytes, "bytes_are": what,
+                            "achieved_GBps": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBPS,
+                            "event_pair_overhead_us_subtracted": over,
+                            "traffic": (pmc.get(key) or {}).get("traffic_bytes_per_launch")})
+        dom = max(kernels, key=lambda k: k["avg_launch_us"])
+        roof = {"bound": "hbm", "kernel": dom["kernel"] + ", timed inside the CG loop", "achieved": dom["achieved_GBps"],
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": dom["traffic"],
+                "traffic_source": f"profiles/{PMC_FILE} (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                "avg_launch_us": dom["avg_launch_us"], "launches_timed": dom["launches_timed"],
+                "event_pair_overhead_us_subtracted": dom["event_pair_overhead_us_subtracted"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "why_this_kernel": "longest kernel of the iteration (see `kernels` for all three)"}
+
+        def standalone(handle):
+            g = torch.Generator(device=dev).manual_seed(0)
+            xr = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            yr = torch.empty_like(xr)
+            for _ in range(20):
+                _hipk.spmv(handle, xr, out=yr)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                _hipk.spmv(handle, xr, out=yr)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 200 * 1e3
+
+        us = standalone(h)
+        spmv_standalone = {"us": us, "GB/s": spmv_bytes / us / 1e3, "reps": 200, "path": path}
+        # SpMV GB/s of the metric: SURVEY-formula bytes over the in-loop kernel time.  On the coded path this is an
+        # EFFECTIVE figure (the kernel streams format_bytes, not the CSR arrays); the general CSR kernels on the
+        # same matrix are measured next to it.
+        spmv_report = {"path": path, "in_loop_us": kernels[0]["avg_launch_us"],
+                       "effective_GBps_on_csr_bytes": kernels[0]["achieved_GBps"],
+                       "csr_algorithmic_bytes": spmv_bytes, "format_bytes_streamed": h.format_bytes(),
+                       "GBps_on_format_bytes": h.format_bytes() / kernels[0]["avg_launch_us"] / 1e3}
+        if path == "coded":
+            h.set_path(plain_only=True)
+            try:
+                pus, pcnt, _ = in_loop(1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, _, pst2 = one_solve()
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - t1
+                spmv_report["plain_csr_kernels_same_matrix"] = {
+                    "path": h.path(), "in_loop_us": pus, "GBps": spmv_bytes / pus / 1e3,
+                    "frac_of_hbm_peak": spmv_bytes / pus / 1e3 / HBM_PEAK_GBPS, "standalone_us": standalone(h),
+                    "cg_iters_per_sec": pst2.iterations / pdt,
+                    "traffic": (pmc.get("spmv_plain") or {}).get("traffic_bytes_per_launch")}
+            finally:
+                h.set_path(plain_only=False)
 
     if world > 1:
         # roofline leg at N > 1: this rank's local SpMV (no communication), HIP events on the launch stream
@@ -200,7 +254,8 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 100
         ach = prob.spmv_bytes / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "hipk_spmv_kernel<double,1280,*> on rank 0's row block, stand-alone",
+        lpath = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded"}.get(int(_hipk.lib().hipk_csr_spmv_path(prob.A["h"])), "?")
+        roof = {"bound": "hbm", "kernel": f"SpMV of rank 0's row block ({lpath} path), stand-alone, SURVEY 8d bytes",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                 "avg_launch_us": ms * 1e3, "launches_timed": 100, "algorithmic_bytes_per_launch": prob.spmv_bytes}
 
@@ -217,6 +272,8 @@ def main():
                        "iterations_per_solve": st.iterations, "info": info,
                        "relres": st.residual_norm / st.b_norm, "step": "one full cg() solve via the public API"},
             "spmv_standalone": spmv_standalone,
+            "spmv": spmv_report,
+            "kernels": kernels,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

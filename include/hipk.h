@@ -61,7 +61,8 @@ typedef struct {
     int32_t gmres_method;  /* hipk_gmres_method                                                            */
     int32_t check_every;   /* host polls the device stop word every this many iterations (<=0: default)    */
     int32_t gpu_tolerances;/* 1: GMRES uses the `device.type=='cuda'` tolerance branch (TSL:737-740)       */
-    int32_t profile;       /* 1: bracket every SpMV launch with events and report stats.spmv_ms_avg        */
+    int32_t profile;       /* 1: bracket every SpMV launch with events and report stats.spmv_ms_avg;
+                              CG only: 2 = the update kernel, 3 = the direction kernel instead              */
     int32_t reserved;
 } hipk_params;
 

@@ -283,10 +283,15 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         const int64_t end = (it + check < maxiter) ? it + check : maxiter;
         for (; it < end; ++it) {
             sa.it = it;
-            if ((rc = hipk_launch_spmv(A, sa, stream, &prof)) != HIPK_OK) return rc;
+            // params.profile selects which kernel the event pairs bracket: 1 SpMV, 2 update, 3 direction
+            if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
+            if (prm->profile == 2) prof.before(stream);
             hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
+            if (prm->profile == 2) prof.after(stream);
+            if (prm->profile == 3) prof.before(stream);
             hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
                                                                             part_b, r, p, x);
+            if (prm->profile == 3) prof.after(stream);
         }
         HIPK_CHECK_HIP(hipGetLastError());
         HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));

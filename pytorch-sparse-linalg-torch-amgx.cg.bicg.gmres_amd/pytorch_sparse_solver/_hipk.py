@@ -372,7 +372,7 @@ def solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, *, tol: f
     prm.gmres_method = {"batched": GMRES_BATCHED, "incremental": GMRES_INCREMENTAL}[solve_method]
     prm.check_every = int(check_every)
     prm.gpu_tolerances = 1  # device.type == 'cuda' on ROCm as well (TSL:737)
-    prm.profile = 1 if profile else 0
+    prm.profile = int(profile)   # True/1: SpMV launches; CG only: 2 update kernel, 3 direction kernel
     L = lib()
     code = _dtype_code(h.dtype)
     if method == "gmres":
