@@ -80,7 +80,7 @@ typedef struct {
     double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
     double spmv_ms_avg;     /* average SpMV kernel time when params.profile=1 (event-pair overhead removed) */
     int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
-    double event_overhead_ms; /* elapsed time of an EMPTY event pair on the stream (calibration), already subtracted */
+    double event_overhead_ms; /* what an event pair adds to the kernel it brackets (null-kernel calibration), already subtracted */
 } hipk_stats;
 
 int hipk_version(void);
