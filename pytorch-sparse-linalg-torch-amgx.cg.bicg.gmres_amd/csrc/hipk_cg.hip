@@ -274,7 +274,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
     struct req_t {  // a tile's codes and its own rows of r, p, x
         unsigned c[G0];
         T ri, pi, xi;
-        T re, pe;  // lanes 0 / 63: r and p of row - 1 / row + 1 (the wavefront's outer neighbours)
         int D, Bp;
         const unsigned char *tp;
     };
@@ -300,15 +299,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
             q.ri = r[row];
             q.pi = p_old[row];
             q.xi = x[row];
-        }
-        q.re = (T)0;
-        q.pe = (T)0;
-        if (lane == 0 || lane == 63) {
-            const int rowx = row < n32 ? row : n32 - 1;
-            int e = (lane == 0) ? rowx - 1 : rowx + 1;
-            e = e < 0 ? 0 : (e > n32 - 1 ? n32 - 1 : e);
-            q.re = r[e];
-            q.pe = p_old[e];
         }
     };
 
@@ -339,31 +329,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
         const int rowx = row < n32 ? row : n32 - 1;
         T rj[NE], pj[NE];
         if (!terminal) {
-            // operands r_j, p_j: own values / lane shifts where the wavefront's k-th offset is uniformly 0 or +-1
-            // (see hipk_spmv_sell_loop_kernel), gathers otherwise.  Rows past the end hold zeros in ri / pi and
-            // never feed a lane that uses them (their own codes are padding; a real row's neighbour exists).
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
                 const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const int off = doff[ck];
-                const int off0 = __builtin_amdgcn_readfirstlane(off);
-                const bool uni = __all(off == off0) != 0;
-                if (uni && off0 == 0) {
-                    rj[k] = rc.ri;
-                    pj[k] = rc.pi;
-                } else if (uni && off0 == 1) {
-                    const T vr = __shfl_down(rc.ri, 1), vp = __shfl_down(rc.pi, 1);
-                    rj[k] = (lane == 63) ? rc.re : vr;
-                    pj[k] = (lane == 63) ? rc.pe : vp;
-                } else if (uni && off0 == -1) {
-                    const T vr = __shfl_up(rc.ri, 1), vp = __shfl_up(rc.pi, 1);
-                    rj[k] = (lane == 0) ? rc.re : vr;
-                    pj[k] = (lane == 0) ? rc.pe : vp;
-                } else {
-                    const unsigned bo = (unsigned)(rowx + off) * (unsigned)sizeof(T);
-                    rj[k] = *(const T *)(rb + bo);
-                    pj[k] = *(const T *)(pb + bo);
-                }
+                const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
+                rj[k] = *(const T *)(rb + bo);
+                pj[k] = *(const T *)(pb + bo);
             }
         }
         ++step;

@@ -406,7 +406,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     struct req_t {  // what a tile needs before its x gathers can be issued
         unsigned c[G0];
         T w, b;
-        T xc, xe;  // x[row] and, in lanes 0 / 63, x[row - 1] / x[row + 1] (the wavefront's two outer neighbours)
         int D, Bp;
         const unsigned char *tp;
     };
@@ -432,41 +431,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             if (mode & HIPK_SPMV_DOT_W) q.w = ((const T *)a.w)[r0 + t];
             if (mode & HIPK_SPMV_RESID) q.b = ((const T *)a.bsub)[r0 + t];
         }
-        const int rowx = (r0 + t < n32) ? r0 + t : n32 - 1;
-        q.xc = *(const T *)(xb + (unsigned)rowx * (unsigned)sizeof(T));
-        q.xe = (T)0;
-        if (lane == 0 || lane == 63) {
-            int e = (lane == 0) ? rowx - 1 : rowx + 1;
-            e = e < 0 ? 0 : (e > n32 - 1 ? n32 - 1 : e);
-            q.xe = *(const T *)(xb + (unsigned)e * (unsigned)sizeof(T));
-        }
     };
-    // The x operands of a tile.  Lanes of a wavefront hold consecutive rows, so when every lane's k-th entry has
-    // the SAME column offset (interior of a stencil) and that offset is 0 or +-1, the operand is the lane's own
-    // x[row] or its neighbour's, moved by a lane shift (outer neighbours: xe) instead of being fetched again:
-    // the three x-direction gathers of a 5-point row collapse into the one coalesced load of `request`.
-    // Everything else (other offsets, mixed wavefronts at grid-line ends, padding) is gathered.
     auto gather = [&](const req_t &q, int tl, T(&xv)[NE]) {
         const int row = tl * HIPK_TILE + t;
         const int rowx = row < n32 ? row : n32 - 1;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const unsigned ck = (q.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const int off = doff[ck];
-            const int off0 = __builtin_amdgcn_readfirstlane(off);
-            const bool uni = __all(off == off0) != 0;
-            if (uni && off0 == 0) {
-                xv[k] = q.xc;
-            } else if (uni && off0 == 1) {
-                const T v = __shfl_down(q.xc, 1);
-                xv[k] = (lane == 63) ? q.xe : v;
-            } else if (uni && off0 == -1) {
-                const T v = __shfl_up(q.xc, 1);
-                xv[k] = (lane == 0) ? q.xe : v;
-            } else {
-                const unsigned bo = (unsigned)(rowx + off) * (unsigned)sizeof(T);
-                xv[k] = *(const T *)(xb + bo);
-            }
+            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
+            xv[k] = *(const T *)(xb + bo);
         }
     };
     // CHUNKED: the workgroups advance in lockstep, so if all of them walked their chunk from its first tile, at
