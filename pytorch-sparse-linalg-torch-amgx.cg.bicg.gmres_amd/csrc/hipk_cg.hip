@@ -302,11 +302,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
         }
     };
 
-    // staggered walk through the chunk's tiles (see hipk_spmv_sell_loop_kernel: HBM channel spread)
-    const int cnt_t = t_end - t_first;
-    const int start = cnt_t > 0 ? chunk % cnt_t : 0;
     req_t rc, rn;
-    int tc = (cnt_t > 0) ? t_first + start : ntiles;
+    int tc = (t_first < t_end) ? t_first : ntiles;
     if (tc < ntiles) request(tc, rc);
     if (a.it > a.scal->stop_it) return;  // a previous launch was the terminal pass
     double pAp, rr;
@@ -323,7 +320,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
     doff[t] = dofs;
     __syncthreads();
 
-    int step = 0;
+    int cur = t_first;
     while (tc < ntiles) {
         const int row = tc * HIPK_TILE + t;
         const int rowx = row < n32 ? row : n32 - 1;
@@ -337,12 +334,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_
                 pj[k] = *(const T *)(pb + bo);
             }
         }
-        ++step;
-        int tn = ntiles;
-        if (step < cnt_t) {
-            const int li = start + step;
-            tn = t_first + (li >= cnt_t ? li - cnt_t : li);
-        }
+        ++cur;
+        const int tn = (cur < t_end) ? cur : ntiles;
         if (tn < ntiles) request(tn, rn);
 
         // own rows: x += alpha p (TSL:847), p' = r + beta p (TSL:852)

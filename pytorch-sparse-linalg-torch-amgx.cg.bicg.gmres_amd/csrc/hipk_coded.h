@@ -442,22 +442,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             xv[k] = *(const T *)(xb + bo);
         }
     };
-    // CHUNKED: the workgroups advance in lockstep, so if all of them walked their chunk from its first tile, at
-    // any moment every access of the chip would fall on tile k of some chunk -- 2 KB out of every 16 KB, a
-    // fraction of the HBM channels.  Workgroup c therefore starts at tile c mod cnt of its chunk and wraps.
-    const int cnt_t = t_end - t_first;
-    int step = 0;
-    const int start = (CHUNKED && cnt_t > 0) ? chunk % cnt_t : 0;
+    int cur = CHUNKED ? t_first : 0;
     auto first_tile = [&]() -> int {
-        if (CHUNKED) return (cnt_t > 0) ? t_first + start : ntiles;
+        if (CHUNKED) return (t_first < t_end) ? t_first : ntiles;
         return (idx < per && xcd * per + idx < ntiles) ? xcd * per + idx : ntiles;
     };
     auto next_tile = [&]() -> int {  // this workgroup's next tile, ntiles when it has none left
         if (CHUNKED) {
-            ++step;
-            if (step >= cnt_t) return ntiles;
-            const int li = start + step;
-            return t_first + (li >= cnt_t ? li - cnt_t : li);
+            ++cur;
+            return (cur < t_end) ? cur : ntiles;
         }
         idx += gp;
         return (idx < per && xcd * per + idx < ntiles) ? xcd * per + idx : ntiles;
