@@ -20,8 +20,6 @@
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
-#include "hipk_coded.h"
-#include <stdlib.h>
 
 struct hipk_cg_scal {
     double gamma[2];   // <r,r> ping-pong by iteration parity
@@ -193,215 +191,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     }
 }
 
-// ------------------------------------------------------------------ fused direction + SpMV (coded matrices)
-// On the coded path (hipk_coded.h) the SpMV no longer dominates the iteration, the vector passes do.  For
-// iterations k >= 1 the direction pass of iteration k-1 and the SpMV of iteration k run as ONE persistent kernel,
-// one workgroup per reduction chunk:
-//     alpha = gamma_{k-1} / <p,Ap>_{k-1},  beta = <r,r> / gamma_{k-1}      (every workgroup, same fold, same bits)
-//     x_i += alpha p_i ;  p'_i = r_i + beta p_i                              own rows (TSL:847, 852)
-//     Ap_i = sum_j a_ij p'_j  with  p'_j = r_j + beta p_j  formed again from the gathered r_j, p_j
-//     partial of <p', Ap>                                                     (TSL:845-846)
-// p' is written to the OTHER p buffer (neighbouring workgroups still gather the old p).  Compared with the separate
-// kernels this drops one read and one write of p (and a launch): 48 n + codes instead of 56 n + codes bytes.
-// Every p'_j is computed from the same operands with the same two roundings wherever it is needed, so the
-// iterates are bit-identical to the unfused kernels' (and the oracle's).
-// Termination (TSL:841): the workgroups see <r,r> themselves; when k >= maxiter or <r,r> <= atol2 the launch only
-// completes x (terminal pass) and publishes stop_it = k.
-struct hipk_cgf_args {
-    const unsigned char *code;
-    const int *tile_off;
-    const int *dict_off;
-    const void *dict_val;
-    int sell_w, n_codes;
-    int64_t n;
-    int ch, g;
-    hipk_cg_scal *scal;
-    int64_t it, maxiter;
-    const double *part_pAp_prev;
-    const double *part_rr;
-    double *part_pAp_out;
-    const void *r;
-    const void *p_old;
-    void *p_new;
-    void *x;
-    void *Ap;
-};
-
-template <typename T, int UNITS>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_dirspmv_kernel(hipk_cgf_args a) {
-    constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;
-    constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));
-    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
-    const int tpc = a.ch / HIPK_TILE;
-    const int chunk = hipk_xcd_chunk(blockIdx.x, a.g);
-    if (chunk < 0) return;
-    const int t_first = chunk * tpc;
-    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;
-
-    __shared__ T dval[HIPK_CODED_MAX];
-    __shared__ int doff[HIPK_CODED_MAX];
-    __shared__ double wsum0[HIPK_SELL_MAX_TPC * 4];
-    __shared__ double sbuf[2 * HIPK_THREADS];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const unsigned char *__restrict__ code = a.code;
-    const char *__restrict__ rb = (const char *)a.r;
-    const char *__restrict__ pb = (const char *)a.p_old;
-    const T *__restrict__ r = (const T *)a.r;
-    const T *__restrict__ p_old = (const T *)a.p_old;
-    T *__restrict__ p_new = (T *)a.p_new;
-    T *__restrict__ x = (T *)a.x;
-    T *__restrict__ Ap = (T *)a.Ap;
-    const int n32 = (int)a.n;
-
-    T dv = (T)0;
-    int dofs = 0;
-    if (t < a.n_codes) {
-        dv = ((const T *)a.dict_val)[t];
-        dofs = a.dict_off[t];
-    }
-    auto load_group = [&](const unsigned char *tp, int D, int Bp, int g) -> unsigned {
-        if (g < D) return ((const unsigned *)tp)[g * HIPK_TILE + t];
-        unsigned w = 0xFFFFFFFFu;
-        if (g == D) {
-            const unsigned char *bp = tp + (size_t)D * 1024 + t;
-            if (Bp >= 1) w = (w & 0xFFFFFF00u) | bp[0];
-            if (Bp >= 2) w = (w & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
-        }
-        return w;
-    };
-    struct req_t {  // a tile's codes and its own rows of r, p, x
-        unsigned c[G0];
-        T ri, pi, xi;
-        int D, Bp;
-        const unsigned char *tp;
-    };
-    auto request = [&](int tl, req_t &q) {
-        const int row = tl * HIPK_TILE + t;
-        if (UNITS > 0) {
-            q.D = UNITS >> 2;
-            q.Bp = UNITS & 3;
-            q.tp = code + (size_t)tl * (UNITS * HIPK_TILE);
-        } else {
-            const int o0 = __builtin_amdgcn_readfirstlane(a.tile_off[tl]);
-            const int o1 = __builtin_amdgcn_readfirstlane(a.tile_off[tl + 1]);
-            q.D = (o1 - o0) >> 2;
-            q.Bp = (o1 - o0) & 3;
-            q.tp = code + (size_t)o0 * HIPK_TILE;
-        }
-#pragma unroll
-        for (int g = 0; g < G0; ++g) q.c[g] = load_group(q.tp, q.D, q.Bp, g);
-        q.ri = (T)0;
-        q.pi = (T)0;
-        q.xi = (T)0;
-        if (row < n32) {
-            q.ri = r[row];
-            q.pi = p_old[row];
-            q.xi = x[row];
-        }
-    };
-
-    req_t rc, rn;
-    int tc = (t_first < t_end) ? t_first : ntiles;
-    if (tc < ntiles) request(tc, rc);
-    if (a.it > a.scal->stop_it) return;  // a previous launch was the terminal pass
-    double pAp, rr;
-    hipk_reduce_parts2(a.part_pAp_prev, a.part_rr, a.g, pAp, rr, sbuf);
-    const double gamma = a.scal->gamma[(a.it - 1) & 1];
-    const T alpha = (T)(gamma / pAp);  // TSL:846 of iteration k-1, the bits hipk_cg_update_kernel derived
-    const T beta = (T)(rr / gamma);    // TSL:851
-    const bool terminal = a.it >= a.maxiter || rr <= a.scal->atol2;  // TSL:841, evaluated before the SpMV of iteration k
-    if (chunk == 0 && t == 0) {
-        a.scal->gamma[a.it & 1] = rr;  // TSL:853
-        if (terminal) a.scal->stop_it = a.it;  // readers compare `it > stop_it` / `it >= stop_it`: this launch is unaffected
-    }
-    dval[t] = dv;
-    doff[t] = dofs;
-    __syncthreads();
-
-    int cur = t_first;
-    while (tc < ntiles) {
-        const int row = tc * HIPK_TILE + t;
-        const int rowx = row < n32 ? row : n32 - 1;
-        T rj[NE], pj[NE];
-        if (!terminal) {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
-                rj[k] = *(const T *)(rb + bo);
-                pj[k] = *(const T *)(pb + bo);
-            }
-        }
-        ++cur;
-        const int tn = (cur < t_end) ? cur : ntiles;
-        if (tn < ntiles) request(tn, rn);
-
-        // own rows: x += alpha p (TSL:847), p' = r + beta p (TSL:852)
-        const T m0 = alpha * rc.pi;
-        const T xnew = rc.xi + m0;
-        const T mb = beta * rc.pi;
-        const T pnew = rc.ri + mb;
-        if (row < n32) {
-            x[row] = xnew;
-            if (!terminal) p_new[row] = pnew;
-        }
-        if (!terminal) {
-            T s = (T)0;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const T m = beta * pj[k];
-                const T pn = rj[k] + m;
-                const T pr = dval[ck] * pn;
-                const T s1 = s + pr;
-                s = (ck != HIPK_SELL_PAD) ? s1 : s;
-            }
-            if (UNITS == 0) {
-                const int groups = rc.D + (rc.Bp > 0 ? 1 : 0);
-                for (int g = G0; g < groups; ++g) {
-                    const unsigned cw = load_group(rc.tp, rc.D, rc.Bp, g);
-                    T rw[4], pw[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned ck = (cw >> (k * 8)) & 0xFFu;
-                        const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
-                        rw[k] = *(const T *)(rb + bo);
-                        pw[k] = *(const T *)(pb + bo);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned ck = (cw >> (k * 8)) & 0xFFu;
-                        const T m = beta * pw[k];
-                        const T pn = rw[k] + m;
-                        const T pr = dval[ck] * pn;
-                        const T s1 = s + pr;
-                        s = (ck != HIPK_SELL_PAD) ? s1 : s;
-                    }
-                }
-            }
-            double d0 = 0.0;
-            if (row < n32) {
-                Ap[row] = s;
-                d0 = (double)pnew * (double)s;
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
-            if (lane == 0) wsum0[(tc - t_first) * 4 + wave] = d0;
-        }
-        rc = rn;
-        tc = tn;
-    }
-    if (!terminal) {
-        __syncthreads();
-        if (wave == 0) {
-            const double v = hipk_wave_fold(wsum0, t_end - t_first, lane);
-            if (lane == 0) a.part_pAp_out[chunk] = v;
-        }
-    }
-}
-
 // res2 = sum parts0, xx = sum parts1 -> scal
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_scal *__restrict__ scal, int g,
                                                                      const double *__restrict__ part_res,
@@ -419,7 +208,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_sca
 extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
-    return 256 + hipk_scratch_bytes() + 4 * vec;  // scalars | partial sums | r, p, Ap, second p buffer (fused path)
+    return 256 + hipk_scratch_bytes() + 3 * vec;
 }
 
 template <typename T>
@@ -436,8 +225,6 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     T *r = (T *)(work + 256 + hipk_scratch_bytes());
     T *p = (T *)((char *)r + vec);
     T *Ap = (T *)((char *)p + vec);
-    T *p2 = (T *)((char *)Ap + vec);              // fused path: p ping-pongs between p and p2
-    double *part_d = parts + 3 * HIPK_MAX_PARTS;  // fused path: <p,Ap> partials ping-pong between part_a and part_d
 
     const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;  // TSL:982-984
     // torch.square(torch.tensor(tol)): python floats become fp32 tensors (TSL:816-817)
@@ -486,82 +273,11 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     sa.part1 = part_c;
     sa.stop_it = &scal->stop_it;
 
-    // fused direction+SpMV kernel (coded matrices whose reduction chunks fill the machine in one round)
-    void (*fkern)(hipk_cgf_args) = nullptr;
-    {
-        const char *env = getenv("HIPK_CG_FUSED");
-        const bool want = !(env && env[0] == '0') && A->n_codes > 0 && A->coded_layout == 2 && A->path_override != 1 &&
-                          gm.ch / HIPK_TILE <= HIPK_SELL_MAX_TPC;
-        if (want) {
-            void (*k)(hipk_cgf_args) = A->sell_w == 5   ? hipk_cg_dirspmv_kernel<T, 5>
-                                       : A->sell_w == 8 ? hipk_cg_dirspmv_kernel<T, 8>
-                                       : A->sell_w == 4 ? hipk_cg_dirspmv_kernel<T, 4>
-                                                        : hipk_cg_dirspmv_kernel<T, 0>;
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, HIPK_THREADS, 0) != hipSuccess) occ = 0;
-            const int slots = A->n_cu * occ;
-            if (occ > 0 && gm.g <= slots && 2 * gm.g >= slots) fkern = k;
-        }
-    }
-    hipk_cgf_args fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.code = A->code;
-    fa.tile_off = A->tile_off;
-    fa.dict_off = A->dict_off;
-    fa.dict_val = A->dict_val;
-    fa.sell_w = A->sell_w;
-    fa.n_codes = A->n_codes;
-    fa.n = n;
-    fa.ch = gm.ch;
-    fa.g = gm.g;
-    fa.scal = scal;
-    fa.maxiter = maxiter;
-    fa.part_rr = part_b;
-    fa.r = r;
-    fa.x = x;
-    fa.Ap = Ap;
-
     hipk_poller poll(A->host_poll);
     HIPK_CHECK_HIP(poll.create());
     int64_t it = 0, stop = INT64_MAX;
     HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
-    if (fkern) {
-        // iteration k: [k = 0: SpMV of p0 | k >= 1: direction(k-1) + SpMV(k)] -> update(k); one extra fused launch
-        // after the last iteration completes x (terminal pass).  p_k lives in buffer k & 1, <p,Ap>_k in part k & 1.
-        T *pbuf[2] = {p, p2};
-        double *pap[2] = {part_a, part_d};
-        const int fgrid = hipk_xcd_grid(gm.g);
-        while (it <= maxiter) {
-            HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
-            if (stop <= it) break;
-            const int64_t end = (it + check <= maxiter) ? it + check : maxiter + 1;
-            for (; it < end; ++it) {
-                if (it == 0) {
-                    sa.it = 0;
-                    sa.part0 = pap[0];
-                    if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
-                } else {
-                    fa.it = it;
-                    fa.part_pAp_prev = pap[(it - 1) & 1];
-                    fa.part_pAp_out = pap[it & 1];
-                    fa.p_old = pbuf[(it - 1) & 1];
-                    fa.p_new = pbuf[it & 1];
-                    if (prm->profile == 1) prof.before(stream);
-                    fkern<<<fgrid, HIPK_THREADS, 0, stream>>>(fa);
-                    if (prm->profile == 1) prof.after(stream);
-                }
-                if (it < maxiter) {
-                    if (prm->profile == 2) prof.before(stream);
-                    hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, pap[it & 1], Ap, r,
-                                                                                 part_b);
-                    if (prm->profile == 2) prof.after(stream);
-                }
-            }
-            HIPK_CHECK_HIP(hipGetLastError());
-            HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
-        }
-    }
-    while (!fkern && it < maxiter) {
+    while (it < maxiter) {
         HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
         if (stop <= it) break;
         const int64_t end = (it + check < maxiter) ? it + check : maxiter;

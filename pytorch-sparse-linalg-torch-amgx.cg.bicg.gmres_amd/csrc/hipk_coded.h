@@ -283,7 +283,7 @@ static inline int hipk_sell_units(int w) {  // host: units of 256 B of a tile wh
     return 4 * d + bp;
 }
 
-static __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int *__restrict__ crow, int64_t n_rows,
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int *__restrict__ crow, int64_t n_rows,
                                                                        int *__restrict__ tile_w) {
     __shared__ int wmax[HIPK_THREADS / 64];
     const int64_t r = (int64_t)blockIdx.x * HIPK_TILE + threadIdx.x;

@@ -255,68 +255,3 @@ def test_chunked_form_with_a_ragged_last_chunk_and_larger_chunks(hipk, oracle):
     for a, c in zip(coded, plain):
         assert np.array_equal(a, c)
     assert np.array_equal(coded[0], b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy()))
-
-
-# ------------------------------------------------------------------ fused direction+SpMV kernel of CG (hipk_cg.hip)
-def _cg_both(hipk, h, b, monkeypatch, x0=None, **kw):
-    """The same solve with the fused kernel (default on large coded systems) and with HIPK_CG_FUSED=0."""
-    out = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("HIPK_CG_FUSED", fused)
-        x = torch.zeros_like(b) if x0 is None else x0.clone()
-        st = hipk.solve("cg", h, b, x, **kw)
-        out[fused] = (x.cpu().numpy(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs)
-    return out["1"], out["0"]
-
-
-@pytest.mark.parametrize("kw", [dict(tol=1e-6, atol=0.0, maxiter=None), dict(tol=1e-12, atol=0.0, maxiter=10),
-                                dict(tol=1e-12, atol=0.0, maxiter=1), dict(tol=1e-12, atol=0.0, maxiter=0),
-                                dict(tol=1e-3, atol=0.0, maxiter=None), dict(tol=0.0, atol=50.0, maxiter=None)],
-                         ids=["tol1e-6", "maxiter10", "maxiter1", "maxiter0", "tol1e-3", "atol50"])
-def test_fused_cg_is_bit_identical_to_the_separate_kernels(hipk, monkeypatch, kw):
-    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
-    nx = 2000
-    A = create_poisson_2d_csr(nx, nx, device=DEV)
-    h = hipk.handle_for(A)
-    assert h.path() == "coded"
-    b = torch.ones(nx * nx, dtype=torch.float64, device=DEV)
-    fused, plain = _cg_both(hipk, h, b, monkeypatch, **kw)
-    assert np.array_equal(fused[0], plain[0]) and fused[1:] == plain[1:]
-    if kw["maxiter"] is None:
-        assert fused[3] == 0
-    else:
-        assert fused[1] == kw["maxiter"]
-
-
-def test_fused_cg_matches_the_plain_csr_path_and_the_reference_count(hipk, monkeypatch):
-    """N = 4M, tol 1e-6: 3297 iterations / 3299 operator applications as the reference itself (tests/golden/big_index.json),
-    same bits as the general CSR kernels with separate update/direction passes."""
-    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
-    nx = 2000
-    A = create_poisson_2d_csr(nx, nx, device=DEV)
-    h = hipk.handle_for(A)
-    b = torch.ones(nx * nx, dtype=torch.float64, device=DEV)
-    x = torch.zeros_like(b)
-    st = hipk.solve("cg", h, b, x, tol=1e-6, atol=0.0, maxiter=None)
-    h.set_path(plain_only=True)
-    try:
-        x2 = torch.zeros_like(b)
-        st2 = hipk.solve("cg", h, b, x2, tol=1e-6, atol=0.0, maxiter=None)
-    finally:
-        h.set_path(plain_only=False)
-    assert (st.iterations, st.matvecs, st.info) == (3297, 3299, 0) == (st2.iterations, st2.matvecs, st2.info)
-    assert torch.equal(x, x2) and st.residual_norm == st2.residual_norm
-
-
-def test_fused_cg_nonzero_x0_larger_chunks_and_fp32(hipk, monkeypatch):
-    n = 5_000_077                                                  # chunk size 4096, ragged last chunk and tile
-    crow, col, val = banded(n, [-1500, -1, 0, 1, 1500], lambda r, k: np.array([-1.0, -1.0, 4.5, -1.0, -1.0])[k])
-    g = torch.Generator(device=DEV).manual_seed(5)
-    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-4)):
-        h = make_handle(hipk, crow, col, val, n, dtype=dtype)
-        assert h.path() == "coded"
-        b = torch.randn(n, dtype=dtype, device=DEV, generator=g)
-        x0 = torch.randn(n, dtype=dtype, device=DEV, generator=g)
-        fused, plain = _cg_both(hipk, h, b, monkeypatch, x0=x0, tol=tol, atol=0.0, maxiter=400)
-        assert np.array_equal(fused[0], plain[0]) and fused[1:] == plain[1:]
-        assert fused[1] > 5
