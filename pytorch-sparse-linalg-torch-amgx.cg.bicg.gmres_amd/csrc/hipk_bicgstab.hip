@@ -83,6 +83,8 @@ template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rr,
     const double *__restrict__ part_rhr, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ p) {
+    hipk_pre<T, 2> pre;  // r and q travel while the stop word is read and the partials are folded
+    pre.issue(n, ch, blockIdx.x, {r, q});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rs, rho_new;
@@ -103,18 +105,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     }
     const T beta = (T)(rho_new / rho * alpha / omega);  // TSL:906, left to right
     const T om = (T)omega;
-    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T rv[VEC], qv[VEC], pv[VEC];
-        hipk_ld<T>(r, i, nv, rv);
-        hipk_ld<T>(q, i, nv, qv);
+        T pv[VEC];
         hipk_ld<T>((const T *)p, i, nv, pv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {  // TSL:907
-            const T t1 = om * qv[k];
+            const T t1 = om * v[1][k];
             const T t2 = pv[k] - t1;
             const T t3 = beta * t2;
-            pv[k] = rv[k] + t3;
+            pv[k] = v[0][k] + t3;
         }
         hipk_st<T>(p, i, nv, pv);
     });
@@ -125,6 +125,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
     const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
     double *__restrict__ part_ss) {
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, blockIdx.x, {r, q});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rho_new, rq;
@@ -145,18 +147,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     }
     const T al = (T)alpha_new;
     double acc = 0.0;
-    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T rv[VEC], qv[VEC];
-        hipk_ld<T>(r, i, nv, rv);
-        hipk_ld<T>(q, i, nv, qv);
+        T sv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const T m = al * qv[k];
-            rv[k] = rv[k] - m;  // TSL:917
-            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);
+            const T m = al * v[1][k];
+            sv[k] = v[0][k] - m;  // TSL:917
+            if (k < nv) acc = fma((double)sv[k], (double)sv[k], acc);
         }
-        hipk_st<T>(s, i, nv, rv);
+        hipk_st<T>(s, i, nv, sv);
     });
     acc = hipk_block_sum(acc, sbuf);
     if (threadIdx.x == 0) part_ss[blockIdx.x] = acc;
@@ -168,6 +168,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
     const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ rhat,
     T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr) {
+    hipk_pre<T, 1> pre;  // s up front; p, x, rhat, t follow after the fold (two early operands already cost the
+    pre.issue(n, ch, blockIdx.x, {s});  // kernel its 8 workgroups per CU: 71 VGPRs)
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     const double ss = hipk_reduce_parts(part_ss, g, sbuf);
@@ -188,11 +190,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     }
     const T al = (T)alpha_new, om = (T)omega_new;
     double acc0 = 0.0, acc1 = 0.0;
-    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+    pre.run([&](int64_t i, int nv, T(&v)[1][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T pv[VEC], sv[VEC], xv[VEC], hv[VEC], rv[VEC];
+        T(&sv)[VEC] = v[0];
+        T pv[VEC], xv[VEC], hv[VEC], rv[VEC];
         hipk_ld<T>(p, i, nv, pv);
-        hipk_ld<T>(s, i, nv, sv);
         hipk_ld<T>((const T *)x, i, nv, xv);
         hipk_ld<T>(rhat, i, nv, hv);
         if (exit_early) {  // TSL:942-950 with exit_early true

@@ -78,6 +78,54 @@ __device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
         f(i, nv);
     }
 }
+
+// Chunk loop whose first HIPK_BASE_CHUNK elements of NV operands are requested EARLY: the per-iteration vector
+// kernels run as one wave of workgroups (a chunk each), so everything a workgroup does before its first vector
+// load -- stop word, partial sums, the fold's barriers -- would be exposed in full.  Usage:
+//     hipk_pre<T, NV> pre;  pre.issue(n, ch, c, {a, b});      // loads in flight
+//     ... stop test, fold of the partials ...
+//     pre.run([&](int64_t i, int nv, T (&v)[NV][VEC]) { ... });   // same element order as hipk_chunk_loop
+// Larger chunks continue with ordinary loads.  NV = 2 keeps the kernels at 8 workgroups per CU.
+template <typename T, int NV>
+struct hipk_pre {
+    static constexpr int VEC = hipk_vec<T>::VEC;
+    static constexpr int N = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // register-resident steps per thread
+    T v[N][NV][VEC];
+    int nvs[N];
+    int64_t i0, step, end;
+    const T *ptr[NV];
+
+    __device__ __forceinline__ void issue(int64_t n, int ch, int c, const T *const (&p)[NV]) {
+        const int64_t base = (int64_t)c * ch;
+        end = (base + ch < n) ? base + ch : n;
+        step = (int64_t)VEC * HIPK_THREADS;
+        i0 = base + (int64_t)VEC * threadIdx.x;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) ptr[a] = p[a];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int64_t i = i0 + k * step;
+            nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
+            if (nvs[k] > 0) {
+#pragma unroll
+                for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nvs[k], v[k][a]);
+            }
+        }
+    }
+    template <typename F>
+    __device__ __forceinline__ void run(F f) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (nvs[k] > 0) f(i0 + k * step, nvs[k], v[k]);
+        for (int64_t i = i0 + N * step; i < end; i += step) {
+            const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
+            T w[NV][VEC];
+#pragma unroll
+            for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nv, w[a]);
+            f(i, nv, w);
+        }
+    }
+};
 #endif
 
 // out_dev[0] = fixed-order sum of part[0..g)   (single workgroup)

@@ -61,64 +61,32 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
 // The two per-iteration vector kernels run as ONE wave of workgroups (a chunk each, <= 2048 of them on 2048
 // slots), so whatever a workgroup does before its first vector load is exposed in full: the stop word, the
 // partial sums and the fold's barriers.  Both kernels therefore request the first HIPK_BASE_CHUNK elements of
-// their operands BEFORE reading the stop word and folding the partials (no store happens until the stop test
-// has passed); larger chunks continue with the plain loop.  Order of operations per element is unchanged.
-template <typename T>
-struct hipk_pre {
-    static constexpr int VEC = hipk_vec<T>::VEC;
-    static constexpr int N = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // register-resident steps per thread
-};
-
+// two operands BEFORE reading the stop word and folding the partials (hipk_pre, hipk_blas1.h; no store happens
+// until the stop test has passed).  Order of operations per element is unchanged.
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
     const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr) {
-    constexpr int VEC = hipk_pre<T>::VEC, PRE = hipk_pre<T>::N;
     const int c = blockIdx.x;
-    const int64_t base = (int64_t)c * ch;
-    const int64_t end = (base + ch < n) ? base + ch : n;
-    const int64_t step = (int64_t)VEC * HIPK_THREADS;
-    const int64_t i0 = base + (int64_t)VEC * threadIdx.x;
-    T av[PRE][VEC], rv[PRE][VEC];
-    int nvs[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const int64_t i = i0 + k * step;
-        nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
-        if (nvs[k] > 0) {
-            hipk_ld<T>(Ap, i, nvs[k], av[k]);
-            hipk_ld<T>((const T *)r, i, nvs[k], rv[k]);
-        }
-    }
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, c, {Ap, (const T *)r});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[HIPK_THREADS];
     const double pAp = hipk_reduce_parts(part_pAp, g, sbuf);
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846
     double acc = 0.0;
-    auto body = [&](T (&a)[VEC], T (&rr)[VEC], int nv) {
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const T m1 = alpha * a[k];
-            rr[k] = rr[k] - m1;  // TSL:848
-            if (k < nv) acc = fma((double)rr[k], (double)rr[k], acc);  // TSL:850
+            const T m1 = alpha * v[0][k];
+            rv[k] = v[1][k] - m1;  // TSL:848
+            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);  // TSL:850
         }
-    };
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        if (nvs[k] > 0) {
-            body(av[k], rv[k], nvs[k]);
-            hipk_st<T>(r, i0 + k * step, nvs[k], rv[k]);
-        }
-    }
-    for (int64_t i = i0 + PRE * step; i < end; i += step) {
-        const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
-        T a1[VEC], r1[VEC];
-        hipk_ld<T>(Ap, i, nv, a1);
-        hipk_ld<T>((const T *)r, i, nv, r1);
-        body(a1, r1, nv);
-        hipk_st<T>(r, i, nv, r1);
-    }
+        hipk_st<T>(r, i, nv, rv);
+    });
     acc = hipk_block_sum(acc, sbuf);
     if (threadIdx.x == 0) part_rr[c] = acc;
 }
@@ -128,25 +96,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
     T *__restrict__ p, T *__restrict__ x) {
-    constexpr int VEC = hipk_pre<T>::VEC, PRE = hipk_pre<T>::N;
     const int c = blockIdx.x;
-    const int64_t base = (int64_t)c * ch;
-    const int64_t end = (base + ch < n) ? base + ch : n;
-    const int64_t step = (int64_t)VEC * HIPK_THREADS;
-    const int64_t i0 = base + (int64_t)VEC * threadIdx.x;
     // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
     // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
-    T rv[PRE][VEC], pv[PRE][VEC];
-    int nvs[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const int64_t i = i0 + k * step;
-        nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
-        if (nvs[k] > 0) {
-            hipk_ld<T>(r, i, nvs[k], rv[k]);
-            hipk_ld<T>((const T *)p, i, nvs[k], pv[k]);
-        }
-    }
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, c, {r, (const T *)p});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double pAp, rr;
@@ -154,35 +108,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
-    auto body = [&](const T (&r1)[VEC], T (&p1)[VEC], T (&x1)[VEC]) {
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T xv[VEC], pv[VEC];
+        hipk_ld<T>((const T *)x, i, nv, xv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const T m0 = alpha * p1[k];
-            x1[k] = x1[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
-            const T m = beta * p1[k];
-            p1[k] = r1[k] + m;   // TSL:852
+            const T m0 = alpha * v[1][k];
+            xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
+            const T m = beta * v[1][k];
+            pv[k] = v[0][k] + m;  // TSL:852
         }
-    };
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        if (nvs[k] > 0) {
-            T xk[VEC];
-            hipk_ld<T>((const T *)x, i0 + k * step, nvs[k], xk);
-            body(rv[k], pv[k], xk);
-            hipk_st<T>(x, i0 + k * step, nvs[k], xk);
-            hipk_st<T>(p, i0 + k * step, nvs[k], pv[k]);
-        }
-    }
-    for (int64_t i = i0 + PRE * step; i < end; i += step) {
-        const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
-        T r1[VEC], p1[VEC], x1[VEC];
-        hipk_ld<T>(r, i, nv, r1);
-        hipk_ld<T>((const T *)p, i, nv, p1);
-        hipk_ld<T>((const T *)x, i, nv, x1);
-        body(r1, p1, x1);
-        hipk_st<T>(x, i, nv, x1);
-        hipk_st<T>(p, i, nv, p1);
-    }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(p, i, nv, pv);
+    });
     if (c == 0 && threadIdx.x == 0) {
         scal->gamma[(it + 1) & 1] = rr;  // TSL:853
         // TSL:841 for the NEXT pass: stop when k+1 >= maxiter or rs <= atol2.
