@@ -74,7 +74,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const in
             if (h == last_h) continue;
             unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
             for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
-                unsigned long long k = __hip_atomic_load(&tb->key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // plain (cacheable) look-up: a stale "empty" only costs a CAS, which returns the true owner
+                unsigned long long k = ((volatile const unsigned long long *)tb->key)[s];
                 if (k == 0) {
                     k = atomicCAS(&tb->key[s], 0ull, h);
                     if (k == 0) {  // claimed: publish the payload (read only by the NEXT kernel)

@@ -124,30 +124,30 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
 
     if (FAST || cnt <= CAP) {
         // ---------------- fast path: the whole tile in one shot
-        int cc[NI];
-        T vv[NI];
-        // all column indices first, then all values: vmcnt retires in order, so the x gathers can start as soon as
-        // the indices are back while the value loads are still in flight
+        // Branch-free loads: lanes past the tile's last entry re-read entry 0 (a cached line) instead of being
+        // predicated off -- a predicate per load had cost a branch and a basic block per load.  Their products land
+        // in prod[j >= cnt], which no row reads.  All column indices first, then all values: vmcnt retires in
+        // order, so the x gathers can start as soon as the indices are back while the value loads are in flight.
+        if (cnt > 0) {  // uniform
+            const int jb = __builtin_amdgcn_readfirstlane(j0);
+            const int *__restrict__ colb = col + jb;
+            const T *__restrict__ valb = val + jb;
+            unsigned jj[NI];
+            int cc[NI];
+            T vv[NI], xv[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t + i * HIPK_THREADS;
-            if (j < cnt) cc[i] = col[j0 + j];
-        }
+            for (int i = 0; i < NI; ++i) {
+                const int j = t + i * HIPK_THREADS;
+                jj[i] = (unsigned)(j < cnt ? j : 0);
+            }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t + i * HIPK_THREADS;
-            if (j < cnt) vv[i] = hipk_ld_nt(val + j0 + j);
-        }
-        T xv[NI];
+            for (int i = 0; i < NI; ++i) cc[i] = colb[jj[i]];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t + i * HIPK_THREADS;
-            if (j < cnt) xv[i] = x[cc[i]];
-        }
+            for (int i = 0; i < NI; ++i) vv[i] = hipk_ld_nt(valb + jj[i]);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t + i * HIPK_THREADS;
-            if (j < cnt) prod[j] = vv[i] * xv[i];
+            for (int i = 0; i < NI; ++i) xv[i] = x[cc[i]];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) prod[t + i * HIPK_THREADS] = vv[i] * xv[i];
         }
         int is_long = 0;
         int lo = 0, len = 0;
