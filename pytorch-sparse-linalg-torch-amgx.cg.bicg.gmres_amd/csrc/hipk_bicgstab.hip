@@ -80,7 +80,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_bi_direction_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rr,
     const double *__restrict__ part_rhr, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ p) {
     hipk_pre<T, 2> pre;  // r and q travel while the stop word is read and the partials are folded
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_bi_direction_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_bi_supdate_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
     const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
     double *__restrict__ part_ss) {
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_bi_supdate_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_bi_xupdate_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
     const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ rhat,
     T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr) {
-    hipk_pre<T, 1> pre;  // s up front; p, x, rhat, t follow after the fold (five streams: register budget)
-    pre.issue(n, ch, blockIdx.x, {s});
+    hipk_pre<T, 1> pre;  // s up front; p, x, rhat, t follow after the fold (two early operands already cost the
+    pre.issue(n, ch, blockIdx.x, {s});  // kernel its 8 workgroups per CU: 71 VGPRs)
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     const double ss = hipk_reduce_parts(part_ss, g, sbuf);

@@ -67,17 +67,11 @@ __device__ __forceinline__ void hipk_st_nt_vec(T *__restrict__ p, int64_t i, int
 
 // Iterate the calling thread's elements of chunk c in reduction-spec order.
 // f(int64_t i, int nv): i = first element, nv = valid elements (1..VEC).
-template <typename T, bool FULLPATH = true, typename F>
+template <typename T, typename F>
 __device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
     constexpr int VEC = hipk_vec<T>::VEC;
     const int64_t base = (int64_t)c * ch;
     const int64_t end = (base + ch < n) ? base + ch : n;
-    // FULLPATH = false keeps the predicated form for kernels whose register budget the hoisted loads would break
-    if (FULLPATH && end - base == ch) {  // full chunk (uniform): every access is a whole vector, no per-access predicate
-#pragma unroll 2
-        for (int64_t i = base + (int64_t)VEC * threadIdx.x; i < end; i += (int64_t)VEC * HIPK_THREADS) f(i, VEC);
-        return;
-    }
 #pragma unroll 4
     for (int64_t i = base + (int64_t)VEC * threadIdx.x; i < end; i += (int64_t)VEC * HIPK_THREADS) {
         const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
@@ -97,41 +91,33 @@ struct hipk_pre {
     static constexpr int VEC = hipk_vec<T>::VEC;
     static constexpr int N = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // register-resident steps per thread
     T v[N][NV][VEC];
+    int nvs[N];
     int64_t i0, step, end;
     const T *ptr[NV];
-    bool full;  // uniform: the chunk has all its ch elements -> whole-vector accesses, no predicates.  Only the
-                // LAST chunk of a vector can be ragged; it takes the plain predicated loop without early loads.
 
     __device__ __forceinline__ void issue(int64_t n, int ch, int c, const T *const (&p)[NV]) {
         const int64_t base = (int64_t)c * ch;
         end = (base + ch < n) ? base + ch : n;
         step = (int64_t)VEC * HIPK_THREADS;
         i0 = base + (int64_t)VEC * threadIdx.x;
-        full = (end - base == ch);
 #pragma unroll
         for (int a = 0; a < NV; ++a) ptr[a] = p[a];
-        if (full) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
+        for (int k = 0; k < N; ++k) {
+            const int64_t i = i0 + k * step;
+            nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
+            if (nvs[k] > 0) {
 #pragma unroll
-                for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i0 + k * step, VEC, v[k][a]);
+                for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nvs[k], v[k][a]);
             }
         }
     }
     template <typename F>
     __device__ __forceinline__ void run(F f) {
-        if (full) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) f(i0 + k * step, VEC, v[k]);
-            for (int64_t i = i0 + N * step; i < end; i += step) {
-                T w[NV][VEC];
-#pragma unroll
-                for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, VEC, w[a]);
-                f(i, VEC, w);
-            }
-            return;
-        }
-        for (int64_t i = i0; i < end; i += step) {
+        for (int k = 0; k < N; ++k)
+            if (nvs[k] > 0) f(i0 + k * step, nvs[k], v[k]);
+        for (int64_t i = i0 + N * step; i < end; i += step) {
             const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
             T w[NV][VEC];
 #pragma unroll

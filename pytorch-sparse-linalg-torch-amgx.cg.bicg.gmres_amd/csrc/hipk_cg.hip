@@ -64,7 +64,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
 // two operands BEFORE reading the stop word and folding the partials (hipk_pre, hipk_blas1.h; no store happens
 // until the stop test has passed).  Order of operations per element is unchanged.
 template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_cg_update_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
     const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr) {
     const int c = blockIdx.x;
@@ -92,15 +92,15 @@ __global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_cg_update_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_cg_direction_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
     T *__restrict__ p, T *__restrict__ x) {
     const int c = blockIdx.x;
-    // p is requested up front; r and x follow after the fold: the kernel must keep 8 workgroups per CU (64 VGPRs;
-    // 2048 slots >= 1954 chunks, one round) and two early operands plus the hoisted x loads spill at that budget
-    hipk_pre<T, 1> pre;
-    pre.issue(n, ch, c, {(const T *)p});
+    // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
+    // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, c, {r, (const T *)p});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double pAp, rr;
@@ -108,17 +108,16 @@ __global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_cg_direction_kernel(
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
-    pre.run([&](int64_t i, int nv, T(&v)[1][hipk_vec<T>::VEC]) {
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
-        T rv[VEC], xv[VEC], pv[VEC];
-        hipk_ld<T>(r, i, nv, rv);
+        T xv[VEC], pv[VEC];
         hipk_ld<T>((const T *)x, i, nv, xv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const T m0 = alpha * v[0][k];
+            const T m0 = alpha * v[1][k];
             xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
-            const T m = beta * v[0][k];
-            pv[k] = rv[k] + m;  // TSL:852
+            const T m = beta * v[1][k];
+            pv[k] = v[0][k] + m;  // TSL:852
         }
         hipk_st<T>(x, i, nv, xv);
         hipk_st<T>(p, i, nv, pv);
