@@ -207,10 +207,24 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
                 continue;
             }
             const int gcnt = crowL[re] - g0;
+            {  // branch-free, as on the fast path: surplus lanes re-read the group's first entry (gcnt >= 1 here)
+                const int gb = __builtin_amdgcn_readfirstlane(g0);
+                const int *__restrict__ colb = col + gb;
+                const T *__restrict__ valb = val + gb;
+                int cc[NI];
+                T vv[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int j = t + i * HIPK_THREADS;
-                if (j < gcnt) prod[j] = hipk_ld_nt(val + g0 + j) * x[col[g0 + j]];
+                for (int i = 0; i < NI; ++i) {
+                    const int j = t + i * HIPK_THREADS;
+                    cc[i] = colb[(unsigned)(j < gcnt ? j : 0)];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = t + i * HIPK_THREADS;
+                    vv[i] = hipk_ld_nt(valb + (unsigned)(j < gcnt ? j : 0));
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) prod[t + i * HIPK_THREADS] = vv[i] * x[cc[i]];
             }
             __syncthreads();
             int is_long = 0;
