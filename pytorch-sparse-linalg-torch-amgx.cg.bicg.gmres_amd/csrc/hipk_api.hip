@@ -375,8 +375,7 @@ extern "C" int hipk_csr_spmv_path(hipk_csr_t h) {
     if (!h) return -1;
     if (h->n_rows > 0 && h->nnz / h->n_rows >= 48) return HIPK_PATH_ROWWAVE;
     if (h->n_codes > 0 && h->path_override != 1) return HIPK_PATH_CODED;
-    const int cap = (h->dtype == HIPK_F64) ? 1280 : 2048;
-    return (h->max_tile_nnz <= cap && h->max_row_len <= HIPK_LONG_ROW) ? HIPK_PATH_TILE_FAST : HIPK_PATH_TILE;
+    return (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW) ? HIPK_PATH_TILE_FAST : HIPK_PATH_TILE;
 }
 extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
     HIPK_REQUIRE(h != nullptr, HIPK_ERR_ARG, "null handle");
@@ -507,6 +506,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)
             hipk_spmv_kernel<double, 1280, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+        else if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)  // e.g. 7-point 3-D stencils (1792 per tile)
+            hipk_spmv_kernel<double, 2048, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
         else
             hipk_spmv_kernel<double, 1280, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
     } else {
