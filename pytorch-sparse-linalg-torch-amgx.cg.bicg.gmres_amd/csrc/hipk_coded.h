@@ -55,15 +55,67 @@ __device__ __forceinline__ unsigned long long hipk_value_bits<float>(float v) {
     return (unsigned long long)__float_as_uint(v);
 }
 
-// pass 1: insert every distinct (col - row, value) pair.  A slot is claimed with one CAS; afterwards entries
-// find their pair with a plain load, so the 20 M entries of a stencil matrix cost 5 CAS operations in total.
+// Workgroup-local memo of the global table (LDS, open addressing on the same hash): 20 M entries asking the same
+// five global slots would serialise on one L2 channel (3.4 ms per pass at N = 4 M).  An entry first looks its
+// hash up here; only the first sighting per workgroup goes to the global table.  val: pass 1 stores 1 ("known to
+// be in the global table"), pass 2 stores 1 + code.
+#define HIPK_MEMO_SLOTS 1024
+struct hipk_dict_memo {
+    unsigned long long key[HIPK_MEMO_SLOTS];
+    unsigned long long bits[HIPK_MEMO_SLOTS];  // payload, compared exactly: a colliding hash is a miss, never a wrong code
+    int off[HIPK_MEMO_SLOTS];
+    int val[HIPK_MEMO_SLOTS];
+};
+__device__ __forceinline__ void hipk_memo_clear(hipk_dict_memo &m) {
+    for (int i = threadIdx.x; i < HIPK_MEMO_SLOTS; i += blockDim.x) {
+        m.key[i] = 0ull;
+        m.val[i] = 0;
+    }
+    __syncthreads();
+}
+// returns val (> 0) if the pair is memoised, else 0
+__device__ __forceinline__ int hipk_memo_find(const hipk_dict_memo &m, unsigned long long h, int off,
+                                              unsigned long long bits) {
+    unsigned int s = (unsigned int)(h >> 20) & (HIPK_MEMO_SLOTS - 1);
+    for (int probe = 0; probe < 16; ++probe) {
+        const unsigned long long k = ((volatile const unsigned long long *)m.key)[s];
+        if (k == h) {
+            const int v = ((volatile const int *)m.val)[s];  // 0 while the owner is still publishing: a miss
+            if (v != 0 && ((volatile const unsigned long long *)m.bits)[s] == bits && ((volatile const int *)m.off)[s] == off)
+                return v;
+            return 0;
+        }
+        if (k == 0) return 0;
+        s = (s + 1) & (HIPK_MEMO_SLOTS - 1);
+    }
+    return 0;
+}
+__device__ __forceinline__ void hipk_memo_put(hipk_dict_memo &m, unsigned long long h, int off, unsigned long long bits,
+                                              int val) {
+    unsigned int s = (unsigned int)(h >> 20) & (HIPK_MEMO_SLOTS - 1);
+    for (int probe = 0; probe < 16; ++probe) {
+        const unsigned long long k = atomicCAS(&m.key[s], 0ull, h);
+        if (k == 0) {  // this thread owns the slot: payload first, then the value that makes it visible
+            ((volatile unsigned long long *)m.bits)[s] = bits;
+            ((volatile int *)m.off)[s] = off;
+            __threadfence_block();
+            ((volatile int *)m.val)[s] = val;
+            return;
+        }
+        if (k == h) return;  // someone else memoises this hash (same pair, or a collision that stays a miss)
+        s = (s + 1) & (HIPK_MEMO_SLOTS - 1);
+    }  // memo full around this hash: the entry simply keeps asking the global table
+}
+
+// pass 1: insert every distinct (col - row, value) pair.  A global slot is claimed with one CAS.
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const int *__restrict__ crow,
                                                                         const int *__restrict__ col,
                                                                         const T *__restrict__ val, int64_t n_rows,
                                                                         hipk_dict_table *tb) {
+    __shared__ hipk_dict_memo memo;
+    hipk_memo_clear(memo);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    unsigned long long last_h = 0;  // the previous pair of this thread is already in the table
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         if (__hip_atomic_load(&tb->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         const int lo = crow[r], hi = crow[r + 1];
@@ -71,7 +123,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const in
             const int off = col[j] - (int)r;
             const unsigned long long bits = hipk_value_bits<T>(val[j]);
             const unsigned long long h = hipk_pair_hash(off, bits);
-            if (h == last_h) continue;
+            if (hipk_memo_find(memo, h, off, bits)) continue;
             unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
             for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
                 // plain (cacheable) look-up: a stale "empty" only costs a CAS, which returns the true owner
@@ -91,13 +143,27 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const in
                 if (k == h) break;
                 s = (s + 1) & (HIPK_DICT_SLOTS - 1);
             }
-            last_h = h;
+            hipk_memo_put(memo, h, off, bits, 1);
         }
     }
 }
 
-// pass 2: code[j] = dictionary index of entry j (payload compared exactly: a hash collision or a value changed
-// between the passes sets `fail`), rowlen[r] = entries of row r.
+// global look-up of a pair: slot index, or -1.  The payload is compared exactly: a hash collision or a value that
+// changed between the passes is reported as "not found".
+template <typename T>
+__device__ __forceinline__ int hipk_dict_lookup(const hipk_dict_table *tb, unsigned long long h, int off,
+                                                unsigned long long bits) {
+    unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
+    for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
+        const unsigned long long k = tb->key[s];
+        if (k == h) return (tb->bits[s] == bits && tb->off[s] == off) ? (int)s : -1;
+        if (k == 0) return -1;
+        s = (s + 1) & (HIPK_DICT_SLOTS - 1);
+    }
+    return -1;
+}
+
+// pass 2: code[j] = dictionary index of entry j, rowlen[r] = entries of row r (CSR-ordered layout)
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_kernel(const int *__restrict__ crow,
                                                                         const int *__restrict__ col,
@@ -105,6 +171,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_kernel(const in
                                                                         hipk_dict_table *tb,
                                                                         unsigned char *__restrict__ code,
                                                                         unsigned char *__restrict__ rowlen) {
+    __shared__ hipk_dict_memo memo;
+    hipk_memo_clear(memo);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const int lo = crow[r], hi = crow[r + 1];
@@ -113,23 +181,18 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_kernel(const in
             const int off = col[j] - (int)r;
             const unsigned long long bits = hipk_value_bits<T>(val[j]);
             const unsigned long long h = hipk_pair_hash(off, bits);
-            unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
-            int found = -1;
-            for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
-                const unsigned long long k = tb->key[s];
-                if (k == h) {
-                    found = (int)s;
-                    break;
+            int c1 = hipk_memo_find(memo, h, off, bits);  // 1 + code
+            if (c1 == 0) {
+                const int found = hipk_dict_lookup<T>(tb, h, off, bits);
+                if (found < 0) {
+                    tb->fail = 1;
+                    code[j] = 0;
+                    continue;
                 }
-                if (k == 0) break;
-                s = (s + 1) & (HIPK_DICT_SLOTS - 1);
+                c1 = 1 + tb->slot_code[found];
+                hipk_memo_put(memo, h, off, bits, c1);
             }
-            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off) {
-                tb->fail = 1;
-                code[j] = 0;
-            } else {
-                code[j] = (unsigned char)tb->slot_code[found];
-            }
+            code[j] = (unsigned char)(c1 - 1);
         }
     }
 }
@@ -308,6 +371,8 @@ template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
     const int *__restrict__ crow, const int *__restrict__ col, const T *__restrict__ val, int64_t n_rows,
     hipk_dict_table *tb, const int *__restrict__ tile_off, unsigned char *__restrict__ code) {
+    __shared__ hipk_dict_memo memo;
+    hipk_memo_clear(memo);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const int lo = crow[r], hi = crow[r + 1];
@@ -319,24 +384,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
             const int off = col[j] - (int)r;
             const unsigned long long bits = hipk_value_bits<T>(val[j]);
             const unsigned long long h = hipk_pair_hash(off, bits);
-            unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
-            int found = -1;
-            for (int probe = 0; probe < HIPK_DICT_SLOTS; ++probe) {
-                const unsigned long long k = tb->key[s];
-                if (k == h) {
-                    found = (int)s;
-                    break;
-                }
-                if (k == 0) break;
-                s = (s + 1) & (HIPK_DICT_SLOTS - 1);
-            }
             const int k = j - lo;
-            if (found < 0 || tb->bits[found] != bits || tb->off[found] != off || k >= 4 * D + (units & 3)) {
+            int c1 = hipk_memo_find(memo, h, off, bits);  // 1 + code
+            if (c1 == 0) {
+                const int found = hipk_dict_lookup<T>(tb, h, off, bits);
+                if (found >= 0) {
+                    c1 = 1 + tb->slot_code[found];
+                    hipk_memo_put(memo, h, off, bits, c1);
+                }
+            }
+            if (c1 == 0 || k >= 4 * D + (units & 3)) {
                 tb->fail = 1;
             } else {
                 const size_t pos = (k < 4 * D) ? (size_t)(k >> 2) * 1024 + (size_t)t * 4 + (k & 3)
                                                : (size_t)D * 1024 + (size_t)(k - 4 * D) * HIPK_TILE + t;
-                tilep[pos] = (unsigned char)tb->slot_code[found];
+                tilep[pos] = (unsigned char)(c1 - 1);
             }
         }
     }
