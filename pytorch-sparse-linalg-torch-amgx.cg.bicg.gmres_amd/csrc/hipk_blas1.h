@@ -67,12 +67,12 @@ __device__ __forceinline__ void hipk_st_nt_vec(T *__restrict__ p, int64_t i, int
 
 // Iterate the calling thread's elements of chunk c in reduction-spec order.
 // f(int64_t i, int nv): i = first element, nv = valid elements (1..VEC).
-template <typename T, typename F>
+template <typename T, int UNROLL = 4, typename F>
 __device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
     constexpr int VEC = hipk_vec<T>::VEC;
     const int64_t base = (int64_t)c * ch;
     const int64_t end = (base + ch < n) ? base + ch : n;
-#pragma unroll 4
+#pragma unroll UNROLL
     for (int64_t i = base + (int64_t)VEC * threadIdx.x; i < end; i += (int64_t)VEC * HIPK_THREADS) {
         const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
         f(i, nv);

@@ -83,6 +83,10 @@ __device__ __forceinline__ void hipk_block_sum8(double (&v)[8], int nb, double *
 }
 
 // part[j*MAXP + c] = chunk partial of <V_j, w>, j = 0..k  (`_project_on_columns`, TSL:276-281)
+// grid = (chunks, ceil((k+1)/8)): a workgroup takes EIGHT columns of one chunk -- eight accumulators and eight
+// column streams per thread keep it at 8 workgroups per CU (31 accumulators in one workgroup: 2-4 per CU, several
+// rounds of workgroups); w's chunk is re-read by each column group from L2.  All eight loads of a step are issued
+// before their FMAs.  Per column the accumulation order is the spec's.
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_kernel(
     int64_t n, int ch, const hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
@@ -91,37 +95,31 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_kernel(
     if (pass == 1 && !scal->pass2) return;
     __shared__ double sbuf[8 * HIPK_THREADS];
     const int c = blockIdx.x;
-    double acc[HIPK_GM_LDH];
+    const int j0 = 8 * blockIdx.y;  // <= k by construction of the grid
+    double acc[8];
 #pragma unroll
-    for (int j = 0; j < HIPK_GM_LDH; ++j) acc[j] = 0.0;
-    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+    for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+    hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T wv[VEC];
         hipk_ld<T>(w, i, nv, wv);
+        T vv[8][VEC];
 #pragma unroll
-        for (int j = 0; j < HIPK_GM_LDH; ++j) {
-            if (j <= k) {
-                T vv[VEC];
-                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    if (e < nv) acc[j] = fma((double)vv[e], (double)wv[e], acc[j]);
+                    if (e < nv) acc[b] = fma((double)vv[b][e], (double)wv[e], acc[b]);
             }
-        }
     });
+    hipk_block_sum8(acc, 8, sbuf);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int b0 = 0; b0 < HIPK_GM_LDH; b0 += 8) {
-        if (b0 <= k) {
-            double v8[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) v8[b] = acc[b0 + b];
-            hipk_block_sum8(v8, 8, sbuf);
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b0 + b <= k) part[(size_t)(b0 + b) * HIPK_MAX_PARTS + c] = v8[b];
-            }
-        }
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = acc[b];
     }
 }
 
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
     __syncthreads();
     const int c = blockIdx.x;
     double acc = 0.0;
-    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+    hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T wv[VEC];
         hipk_ld<T>((const T *)w, i, nv, wv);
@@ -157,13 +155,19 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s[e] = 0.0;
 #pragma unroll
-        for (int j = 0; j < HIPK_GM_LDH; ++j) {
-            if (j <= k) {
-                T vv[VEC];
-                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
-                const double hj = hs[j];
+        for (int j0 = 0; j0 < HIPK_GM_LDH; j0 += 8) {  // batches of eight column loads, then their FMAs in column order
+            if (j0 <= k) {
+                T vv[8][VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], hj, s[e]);
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) {
+                        const double hj = hs[j0 + b];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[b][e], hj, s[e]);
+                    }
             }
         }
 #pragma unroll
@@ -547,8 +551,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
             if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
-                hipk_gm_multidot_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                               part_md);
+                hipk_gm_multidot_kernel<T><<<dim3(gm.g, k / 8 + 1), HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V,
+                                                                                                ldv, w, part_md);
                 hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
                 hipk_gm_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_qq);
             }
