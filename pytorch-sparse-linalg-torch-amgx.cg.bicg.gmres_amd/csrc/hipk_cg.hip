@@ -255,7 +255,9 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     HIPK_CHECK_HIP(hipGetLastError());
     hipk_cg_scal hs;
     HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
-    prof.calibrate(stream);
+    // calibration kernel: a chunked dot over r (reads 16 n bytes, writes the spare partial slot): the size class of
+    // the kernels the pairs bracketed
+    prof.calibrate(stream, [&]() { (void)hipk_launch_dot_parts(n, r, r, A->dtype, part_c, stream); });
     HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
 
