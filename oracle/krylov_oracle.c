@@ -70,6 +70,7 @@ typedef double real;
 #define orc_dot_tiled orc32_dot_tiled
 #define orc_spmv orc32_spmv
 #define orc_cg orc32_cg
+#define orc_pcg_jacobi orc32_pcg_jacobi
 #define orc_bicgstab orc32_bicgstab
 #define orc_gmres orc32_gmres
 #endif
@@ -318,6 +319,97 @@ int orc_cg(int64_t n, const int32_t *crow, const int32_t *col, const real *val, 
     st->iterations = k;
     st->matvecs = matvecs + 1;
     st->recurrence_rs = gamma;
+    free(r);
+    free(p);
+    free(Ap);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ CG with M = diag(dinv) (Jacobi), TSL:806-856
+ * with `M is not _identity`: z = M r, gamma = <r,z>, the stop test uses rs = <r,r> (TSL:835-838), and the final
+ * `info` compares ||M (b - A x)|| (TSL:1007).  Restates the device kernels of hipk_pcg_solve:
+ *   start      z = dinv*r (one rounding), p = z, gamma0 = plain chunked dot <r,z>; rs0 = tiled dot of the residual SpMV
+ *   update     r -= alpha*Ap (two roundings), z = dinv*r, plain chunked dots <r,r> and <r,z>
+ *   direction  x += alpha*p, z = dinv*r again (same bits), p = z + beta*p                                            */
+static double chunk_dot_scaled(const real *a, const real *d, int with_a, int64_t base, int64_t end) {
+    /* with_a = 1: sum fma(a_i, (real)(d_i*a_i), .)   (<r, z>);   with_a = 0: sum fma(m_i, m_i, .), m_i = (real)(d_i*a_i) */
+    double v[ORC_THREADS];
+    for (int t = 0; t < ORC_THREADS; ++t) v[t] = 0.0;
+    for (int64_t i = base; i < end; ++i) {
+        const int t = (int)(((i - base) % (ORC_THREADS * ORC_VEC)) / ORC_VEC);
+        const real m = d[i] * a[i];
+        v[t] = with_a ? fma((double)a[i], (double)m, v[t]) : fma((double)m, (double)m, v[t]);
+    }
+    return tree256(v);
+}
+
+static double dot_scaled(int64_t n, const real *a, const real *d, int with_a) {
+    int ch, g;
+    orc_chunk_geom(n, &ch, &g);
+    double parts[ORC_MAX_PARTS];
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int c = 0; c < g; ++c) {
+        const int64_t base = (int64_t)c * ch;
+        const int64_t end = base + ch < n ? base + ch : n;
+        parts[c] = chunk_dot_scaled(a, d, with_a, base, end);
+    }
+    return reduce_parts(parts, g);
+}
+
+int orc_pcg_jacobi(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv,
+                   const real *b, real *x /* in: x0, out: x */, double tol, double atol, int64_t maxiter,
+                   orc_stats *st) {
+    memset(st, 0, sizeof(*st));
+    if (maxiter < 0) maxiter = 10 * n;
+    real *r = (real *)malloc(sizeof(real) * (size_t)n);
+    real *p = (real *)malloc(sizeof(real) * (size_t)n);
+    real *Ap = (real *)malloc(sizeof(real) * (size_t)n);
+    const double bs = orc_dot(n, b, b);
+    const float tolf = (float)tol, atolf = (float)atol;
+    const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
+    const double atol2 = a2 > a3 ? a2 : a3;
+    orc_spmv(n, crow, col, val, x, b, r);
+    int64_t matvecs = 1;
+    double rs = orc_dot_tiled(n, r, r); /* fused in the residual SpMV */
+    for (int64_t i = 0; i < n; ++i) p[i] = dinv[i] * r[i];
+    double gamma = dot_scaled(n, r, dinv, 1);
+    int64_t k = 0;
+    while (!(k >= maxiter || rs <= atol2)) {
+        orc_spmv(n, crow, col, val, p, NULL, Ap);
+        ++matvecs;
+        const double pAp = orc_dot_tiled(n, p, Ap);
+        const double alpha = gamma / pAp;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const real m1 = (real)alpha * Ap[i];
+            r[i] = r[i] - m1;
+        }
+        const double rr = orc_dot(n, r, r);
+        const double rz = dot_scaled(n, r, dinv, 1);
+        const double beta = rz / gamma;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const real m0 = (real)alpha * p[i];
+            x[i] = x[i] + m0;
+            const real z = dinv[i] * r[i];
+            const real m = (real)beta * p[i];
+            p[i] = z + m;
+        }
+        gamma = rz;
+        rs = rr;
+        ++k;
+    }
+    /* TSL:1007-1016 with M: ||M (b - A x)|| */
+    orc_spmv(n, crow, col, val, x, b, Ap);
+    ++matvecs;
+    st->residual_norm = norm_from_sq(dot_scaled(n, Ap, dinv, 0));
+    st->b_norm = norm_from_sq(bs);
+    st->x_norm = norm_from_sq(orc_dot(n, x, x));
+    st->threshold = tmax((double)(float)tol * st->b_norm, (double)(float)atol);
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+    st->iterations = k;
+    st->matvecs = matvecs;
+    st->recurrence_rs = rs;
     free(r);
     free(p);
     free(Ap);

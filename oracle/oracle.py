@@ -81,6 +81,7 @@ def lib():
         sp = ctypes.POINTER(_Stats)
         L.orc_cg.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_bicgstab.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc_pcg_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_gmres.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                 ctypes.c_int, ctypes.c_int, sp]
         # fp32-storage variant (same source compiled with -DORC_F32): vectors/values float, dots and scalars fp64
@@ -92,6 +93,7 @@ def lib():
         L.orc32_spmv.argtypes = [i64, ip, ip, fp, fp, fp, fp]
         L.orc32_cg.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc32_bicgstab.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc32_pcg_jacobi.argtypes = [i64, ip, ip, fp, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc32_gmres.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                   ctypes.c_int, ctypes.c_int, sp]
         L.orc32_set_threads.argtypes = [ctypes.c_int]
@@ -202,6 +204,25 @@ def cg(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleRe
     st = _Stats()
     lib().orc_cg(b.size, _i(crow), _i(col), _d(val), _d(b), _d(x), float(tol), float(atol),
                  -1 if maxiter is None else int(maxiter), ctypes.byref(st))
+    return _result(x, st)
+
+
+def pcg_jacobi(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    """CG with M = diag(dinv) (TSL:806-856 with a non-identity M): restates hipk_pcg_solve."""
+    crow, col, val, b, x = _prep(crow, col, val, b, x0)
+    dinv = np.ascontiguousarray(dinv, dtype=np.float64)
+    st = _Stats()
+    lib().orc_pcg_jacobi(b.size, _i(crow), _i(col), _d(val), _d(dinv), _d(b), _d(x), float(tol), float(atol),
+                         -1 if maxiter is None else int(maxiter), ctypes.byref(st))
+    return _result(x, st)
+
+
+def pcg_jacobi32(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    crow, col, val, b, x = _prep32(crow, col, val, b, x0)
+    dinv = _f32(dinv)
+    st = _Stats()
+    lib().orc32_pcg_jacobi(b.size, _i(crow), _i(col), _f(val), _f(dinv), _f(b), _f(x), float(tol), float(atol),
+                           -1 if maxiter is None else int(maxiter), ctypes.byref(st))
     return _result(x, st)
 
 
