@@ -165,6 +165,15 @@ size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype);
 int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,
                      const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
+/* ---- CG with a Jacobi preconditioner ---------------------------------
+ * `cg(A, b, M=...)` of the reference (TSL:1019-1021) with M(v) = dinv .* v, the iteration of TSL:806-856 for a
+ * non-identity M: gamma = <r, M r>, stop test on <r,r>, `info` from ||M (b - A x)|| (TSL:1007).  `dinv` is a
+ * device vector of the matrix' dtype (the reciprocal diagonal); the scaling is fused into the update and direction
+ * kernels.  Same params / stats / work-buffer conventions as hipk_cg_solve. */
+size_t hipk_pcg_work_bytes(int64_t n, int dtype);
+int hipk_pcg_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
+                   const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the
  * SAME fused kernels from the host side of each rank and exchanges (a) the x-vector

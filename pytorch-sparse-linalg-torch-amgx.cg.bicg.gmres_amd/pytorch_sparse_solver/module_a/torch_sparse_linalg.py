@@ -118,6 +118,12 @@ class _Flat:
 
 
 # ------------------------------------------------------------------------- fast path
+def _jacobi_of(M):
+    """The JacobiPreconditioner behind `M`, if that is what it is (the fast path runs it device-resident)."""
+    from .preconditioners import JacobiPreconditioner
+    return M if isinstance(M, JacobiPreconditioner) else None
+
+
 def _fast_ok(A, b, x0, M) -> bool:
     return (isinstance(A, torch.Tensor) and A.is_cuda and A.ndim == 2 and not torch.is_complex(A)
             and A.dtype in (torch.float64, torch.float32)
@@ -127,7 +133,7 @@ def _fast_ok(A, b, x0, M) -> bool:
             and (M is None or M is _identity))
 
 
-def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_method='batched'):
+def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_method='batched', jacobi=None):
     from .. import _hipk
 
     if A.shape[0] != A.shape[1]:
@@ -144,8 +150,14 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
     work_dtype = torch.float64 if h.dtype == torch.float64 else torch.float32
     bb = b.detach().to(work_dtype).contiguous()
     x = torch.zeros_like(bb) if x0 is None else x0.detach().to(work_dtype).clone().contiguous()
-    st = _hipk.solve(method, h, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
-                     solve_method=solve_method)
+    if jacobi is not None:  # cg with M = diag(dinv): hipk_pcg_solve
+        if jacobi.shape != tuple(A.shape):
+            raise ValueError(f'preconditioner shape {jacobi.shape} does not match the operator {tuple(A.shape)}')
+        dinv = jacobi.dinv.detach().to(device=bb.device, dtype=work_dtype).contiguous()
+        st = _hipk.solve_pcg(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter)
+    else:
+        st = _hipk.solve(method, h, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                         solve_method=solve_method)
     _set_stats(st)
     return x, int(st.info)
 
@@ -347,6 +359,8 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
     """Shared CG/BiCGStab wrapper (`_isolve`, TSL:968-1016)."""
     if _fast_ok(A, b, x0, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter)
+    if kind == 'cg' and _jacobi_of(M) is not None and _fast_ok(A, b, x0, None):
+        return _fast_solve('cg', A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size
