@@ -8,7 +8,7 @@ _PROBES = ("check_module_a_available", "check_module_b_available", "check_module
            "get_available_backends")
 _CONVERTERS = ("dense_to_sparse_csr", "sparse_coo_to_csr", "ensure_sparse_format")
 _BUILDERS = ("create_poisson_2d_csr", "create_poisson_2d_sparse_coo", "create_convdiff_2d_csr",
-             "create_ldc_pressure_csr", "stencil5_csr_components")
+             "create_ldc_pressure_csr", "create_variable_diffusion_2d_csr", "stencil5_csr_components")
 
 for _name in _PROBES:
     globals()[_name] = getattr(_av, _name)

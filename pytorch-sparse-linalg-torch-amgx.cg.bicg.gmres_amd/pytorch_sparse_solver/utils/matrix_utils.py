@@ -166,3 +166,30 @@ def compute_residual(A: Union[torch.Tensor, callable], x: torch.Tensor, b: torch
 
 def compute_relative_residual(A: Union[torch.Tensor, callable], x: torch.Tensor, b: torch.Tensor) -> float:
     return (torch.norm(compute_residual(A, x, b)) / torch.norm(b)).item()
+
+
+def create_variable_diffusion_2d_csr(nx: int, ny: int, contrast: float = 2.0, seed: int = 0, device='cpu',
+                                     dtype=torch.float64) -> torch.Tensor:
+    """-div(k grad u) on an nx x ny grid (row k = i*ny + j, Dirichlet truncation) with a log-normal cell coefficient
+    k = exp(contrast * N(0,1)) and harmonic face averages: SPD, 5-point, strongly varying diagonal -- the test
+    problem of the Jacobi-preconditioned CG path (not in the reference; synthetic)."""
+    g = torch.Generator().manual_seed(seed)
+    k = torch.exp(contrast * torch.randn(nx + 2, ny + 2, generator=g, dtype=torch.float64))
+    kc = k[1:-1, 1:-1]
+
+    def harm(a, b):
+        return 2.0 * a * b / (a + b)
+
+    faces = ((harm(kc, k[:-2, 1:-1]), (-1, 0)), (harm(kc, k[2:, 1:-1]), (1, 0)),
+             (harm(kc, k[1:-1, :-2]), (0, -1)), (harm(kc, k[1:-1, 2:]), (0, 1)))
+    idx = torch.arange(nx * ny).reshape(nx, ny)
+    rows, cols, vals = [idx.reshape(-1)], [idx.reshape(-1)], [sum(w for w, _ in faces).reshape(-1)]
+    for w, (di, dj) in faces:
+        i0, i1 = max(0, -di), nx - max(0, di)
+        j0, j1 = max(0, -dj), ny - max(0, dj)
+        rows.append(idx[i0:i1, j0:j1].reshape(-1))
+        cols.append(idx[i0 + di:i1 + di, j0 + dj:j1 + dj].reshape(-1))
+        vals.append(-w[i0:i1, j0:j1].reshape(-1))
+    A = torch.sparse_coo_tensor(torch.stack([torch.cat(rows), torch.cat(cols)]), torch.cat(vals).to(dtype),
+                                (nx * ny, nx * ny))
+    return A.coalesce().to_sparse_csr().to(device)

@@ -44,33 +44,12 @@ def test_pcg_bit_exact_vs_oracle_and_reference_counts(hipk, oracle, r):
     assert np.linalg.norm(x.cpu().numpy() - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
 
 
-def _varcoef_5pt(nx, seed=0):
-    """-div(k grad u), k log-normal per cell, harmonic face averages; CSR on the device, vectorised."""
-    g = torch.Generator().manual_seed(seed)
-    k = torch.exp(2.0 * torch.randn(nx + 2, nx + 2, generator=g, dtype=torch.float64))
-    kc = k[1:-1, 1:-1]
-    harm = lambda a, b: 2.0 * a * b / (a + b)
-    wN, wS, wW, wE = harm(kc, k[:-2, 1:-1]), harm(kc, k[2:, 1:-1]), harm(kc, k[1:-1, :-2]), harm(kc, k[1:-1, 2:])
-    diag = (wN + wS + wW + wE).reshape(-1)
-    idx = torch.arange(nx * nx).reshape(nx, nx)
-    rows = [idx.reshape(-1)]
-    cols = [idx.reshape(-1)]
-    vals = [diag]
-    for w, (di, dj) in ((wN, (-1, 0)), (wS, (1, 0)), (wW, (0, -1)), (wE, (0, 1))):
-        i0, i1 = max(0, -di), nx - max(0, di)
-        j0, j1 = max(0, -dj), nx - max(0, dj)
-        rows.append(idx[i0:i1, j0:j1].reshape(-1))
-        cols.append(idx[i0 + di:i1 + di, j0 + dj:j1 + dj].reshape(-1))
-        vals.append(-w[i0:i1, j0:j1].reshape(-1))
-    A = torch.sparse_coo_tensor(torch.stack([torch.cat(rows), torch.cat(cols)]), torch.cat(vals), (nx * nx, nx * nx))
-    return A.coalesce().to_sparse_csr().to(DEV)
-
-
 def test_pcg_large_variable_coefficient_problem(hipk, oracle):
     """N = 1M variable-coefficient diffusion: bit-exact vs the oracle, and far fewer iterations than plain CG."""
     from pytorch_sparse_solver.module_a import JacobiPreconditioner, cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
     nx = 1000
-    A = _varcoef_5pt(nx)
+    A = create_variable_diffusion_2d_csr(nx, nx, device=DEV)
     n = nx * nx
     b = torch.randn(n, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     M = JacobiPreconditioner(A)

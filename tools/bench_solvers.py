@@ -25,7 +25,8 @@ def run(name, fn, A, b, reps=2, **kw):
     out = {"case": name, "n": h.n, "nnz": h.nnz, "info": info, "iterations_or_cycles": st.iterations,
            "matvecs": st.matvecs, "breakdown": st.breakdown, "relres": st.residual_norm / st.b_norm,
            "wall_ms": dt * 1e3, "device_ms": st.solve_ms, "matvecs_per_s": st.matvecs / dt,
-           "iters_per_s": st.iterations / dt, "kwargs": {k: v for k, v in kw.items()}}
+           "iters_per_s": st.iterations / dt, "kwargs": {k: (v if isinstance(v, (int, float, str)) else type(v).__name__)
+                                                         for k, v in kw.items()}}
     print(json.dumps(out), flush=True)
 
 
@@ -36,6 +37,14 @@ def main():
     run("config2_poisson_cg", cg, A, ones, tol=1e-6)
     run("config2_poisson_bicgstab", bicgstab, A, ones, tol=1e-6)
     run("config2_poisson_gmres30_batched", gmres, A, ones, reps=1, tol=1e-6, restart=30, maxiter=20)
+    # Jacobi-preconditioned CG on a variable-coefficient diffusion matrix of the same size, fixed work
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    K = create_variable_diffusion_2d_csr(nx, nx, device=DEV)
+    gk = torch.Generator(device=DEV).manual_seed(1)
+    bk = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=gk)
+    run("vardiff_cg_plain_2000it", cg, K, bk, tol=1e-12, maxiter=2000)
+    run("vardiff_cg_jacobi_2000it", cg, K, bk, tol=1e-12, maxiter=2000, M=JacobiPreconditioner(K))
     C = create_convdiff_2d_csr(nx, nx, device=DEV)
     g = torch.Generator(device=DEV).manual_seed(0)
     xt = torch.randn(nx * nx, dtype=torch.float64, device=DEV, generator=g)
