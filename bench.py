@@ -254,7 +254,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 100
         ach = prob.spmv_bytes / (ms * 1e-3) / 1e9
-        lpath = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded"}.get(int(_hipk.lib().hipk_csr_spmv_path(prob.A["h"])), "?")
+        lpath = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded", 4: "offset_coded"}.get(int(_hipk.lib().hipk_csr_spmv_path(prob.A["h"])), "?")
         roof = {"bound": "hbm", "kernel": f"SpMV of rank 0's row block ({lpath} path), stand-alone, SURVEY 8d bytes",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                 "avg_launch_us": ms * 1e3, "launches_timed": 100, "algorithmic_bytes_per_launch": prob.spmv_bytes}

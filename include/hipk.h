@@ -113,11 +113,16 @@ int64_t hipk_csr_spmv_bytes(hipk_csr_t h);
  *   CODED     : the matrix has at most 256 distinct (col - row, value) pairs and short rows (finite-difference /
  *               finite-volume stencils, e.g. matrix_utils.py:193-257 and ldc_solver_common.py:90-135): the handle
  *               keeps one byte per entry + one byte per row + the dictionary and streams those instead of
- *               col/val/crow.  The values are SNAPSHOTTED at creation (`val` must not change anyway, see above). */
-enum hipk_spmv_path { HIPK_PATH_TILE_FAST = 0, HIPK_PATH_TILE = 1, HIPK_PATH_ROWWAVE = 2, HIPK_PATH_CODED = 3 };
+ *               col/val/crow.  The values are SNAPSHOTTED at creation (`val` must not change anyway, see above).
+ *   OFFSET_CODED : too many distinct values, but at most 255 distinct column OFFSETS and short rows (variable-coefficient
+ *               stencils): one offset-code byte + the value per entry in coalesced planes, 9 instead of 12 bytes
+ *               per entry and no row pointers.  Values snapshotted as for CODED. */
+enum hipk_spmv_path { HIPK_PATH_TILE_FAST = 0, HIPK_PATH_TILE = 1, HIPK_PATH_ROWWAVE = 2, HIPK_PATH_CODED = 3,
+                      HIPK_PATH_OFFSET_CODED = 4 };
 int hipk_csr_spmv_path(hipk_csr_t h);
-/* mode 0: automatic (default); 1: never use the coded form (A/B measurements, parity tests).
- * Environment: HIPK_SPMV_CODED=0 at creation time skips building the coded form altogether. */
+/* mode 0: automatic (default); 1: never use the coded forms (A/B measurements, parity tests).
+ * Environment: HIPK_SPMV_CODED=0 at creation time skips building the coded forms altogether,
+ * HIPK_SPMV_OFFSET_CODED=0 only the offset-coded one. */
 int hipk_csr_set_path(hipk_csr_t h, int mode);
 /* Bytes one SpMV has to move in the format the selected path streams (= hipk_csr_spmv_bytes unless CODED). */
 int64_t hipk_csr_format_bytes(hipk_csr_t h);

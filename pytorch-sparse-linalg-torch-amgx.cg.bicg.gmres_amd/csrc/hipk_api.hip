@@ -84,7 +84,8 @@ __global__ void hipk_huge_rows_kernel(const int *__restrict__ crow, int64_t n_ro
 
 
 // Try to build the coded form (hipk_coded.h).  Failure of any kind just leaves the handle on the plain kernels.
-template <typename T>
+// OFFS_ONLY: dictionary of column offsets only + per-entry value planes (variable-coefficient stencils; layout 3).
+template <typename T, bool OFFS_ONLY>
 static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
     hipk_dict_table *tb = nullptr;
     hipError_t e = hipMalloc((void **)&tb, sizeof(hipk_dict_table));
@@ -97,7 +98,8 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
     if (e != hipSuccess) return e;
     int grid = (int)((h->n_rows + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipk_dict_insert_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows, tb);
+    hipk_dict_insert_kernel<T, OFFS_ONLY><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val, h->n_rows,
+                                                                            tb);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipk_dict_table *ht = new hipk_dict_table;
@@ -140,8 +142,9 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
     // layout of the code bytes: sliced-ELL planes when the padding stays small, else CSR order + row lengths
     const char *lay = getenv("HIPK_SPMV_CODED_LAYOUT");
     // (the persistent sliced-ELL kernel needs n_rows <= n_cols and 32-bit byte offsets into x)
-    const bool want_sell = !(lay && strcmp(lay, "csr") == 0) && nc <= HIPK_SELL_PAD && h->n_rows <= h->n_cols &&
-                           (uint64_t)h->n_cols * sizeof(T) < (1ull << 32);
+    const bool want_sell = (OFFS_ONLY || !(lay && strcmp(lay, "csr") == 0)) && nc <= HIPK_SELL_PAD &&
+                           h->n_rows <= h->n_cols && (uint64_t)h->n_cols * sizeof(T) < (1ull << 32);
+    if (OFFS_ONLY && !want_sell) return hipSuccess;  // the offset-coded form exists in the sliced-ELL layout only
     const int ntiles = (int)((h->n_rows + HIPK_TILE - 1) / HIPK_TILE);
     std::vector<int> toff;
     bool sell = false;
@@ -184,15 +187,20 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
             e = hipMemcpyAsync(tw, toff.data(), sizeof(int) * (size_t)(ntiles + 1), hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->sell_bytes + 256);
             if (e == hipSuccess) e = hipMemsetAsync(h->code, HIPK_SELL_PAD, (size_t)h->sell_bytes + 256, stream);
+            if (OFFS_ONLY) {
+                if (e == hipSuccess) e = hipMalloc(&h->sell_vals, ((size_t)h->sell_bytes + 256) * sizeof(T));
+                if (e == hipSuccess) e = hipMemsetAsync(h->sell_vals, 0, ((size_t)h->sell_bytes + 256) * sizeof(T), stream);
+            }
             if (e == hipSuccess) {
-                hipk_dict_encode_sell_kernel<T><<<grid, HIPK_THREADS, 0, stream>>>(h->crow, h->col, (const T *)h->val,
-                                                                                  h->n_rows, tb, h->tile_off, h->code);
+                hipk_dict_encode_sell_kernel<T, OFFS_ONLY><<<grid, HIPK_THREADS, 0, stream>>>(
+                    h->crow, h->col, (const T *)h->val, h->n_rows, tb, h->tile_off, h->code, (T *)h->sell_vals);
                 e = hipGetLastError();
             }
         } else {
             (void)hipFree(tw);
         }
     }
+    if (OFFS_ONLY && !sell) return e;  // planes mostly padding: no offset-coded form
     if (!sell) {
         if (e == hipSuccess) e = hipMalloc((void **)&h->code, (size_t)h->nnz + 32);
         if (e == hipSuccess) e = hipMalloc((void **)&h->rowlen, (size_t)h->n_rows + 16);
@@ -209,7 +217,7 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
     if (e != hipSuccess) return e;
     if (!fail) {
         h->n_codes = nc;
-        h->coded_layout = sell ? 2 : 1;
+        h->coded_layout = OFFS_ONLY ? 3 : (sell ? 2 : 1);
     }
     return hipSuccess;
 }
@@ -220,6 +228,8 @@ static void hipk_drop_coded(hipk_csr_s *h) {
     if (h->dict_off) (void)hipFree(h->dict_off);
     if (h->dict_val) (void)hipFree(h->dict_val);
     if (h->tile_off) (void)hipFree(h->tile_off);
+    if (h->sell_vals) (void)hipFree(h->sell_vals);
+    h->sell_vals = nullptr;
     h->tile_off = nullptr;
     h->coded_layout = 0;
     h->code = h->rowlen = nullptr;
@@ -343,9 +353,19 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     }
     const char *env = getenv("HIPK_SPMV_CODED");
     if (n_rows > 0 && nnz > 0 && h->max_row_len <= HIPK_LONG_ROW && !(env && env[0] == '0')) {
-        e = (dtype == HIPK_F64) ? hipk_build_coded<double>(h, stream) : hipk_build_coded<float>(h, stream);
+        e = (dtype == HIPK_F64) ? hipk_build_coded<double, false>(h, stream) : hipk_build_coded<float, false>(h, stream);
         if (e != hipSuccess) (void)hipGetLastError();  // e.g. out of memory: stay on the plain kernels
-        if (h->n_codes == 0) hipk_drop_coded(h);
+        if (h->n_codes == 0) {
+            // too many distinct (offset, value) pairs: try offsets alone, values kept per entry (9 B instead of 12 B per
+            // entry, no row pointers) -- HIPK_SPMV_OFFSET_CODED=0 skips it
+            hipk_drop_coded(h);
+            const char *oc = getenv("HIPK_SPMV_OFFSET_CODED");
+            if (!(oc && oc[0] == '0')) {
+                e = (dtype == HIPK_F64) ? hipk_build_coded<double, true>(h, stream) : hipk_build_coded<float, true>(h, stream);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+            if (h->n_codes == 0) hipk_drop_coded(h);
+        }
     }
     *out = h;
     return HIPK_OK;
@@ -374,7 +394,7 @@ extern "C" int64_t hipk_csr_spmv_bytes(hipk_csr_t h) {
 extern "C" int hipk_csr_spmv_path(hipk_csr_t h) {
     if (!h) return -1;
     if (h->n_rows > 0 && h->nnz / h->n_rows >= 48) return HIPK_PATH_ROWWAVE;
-    if (h->n_codes > 0 && h->path_override != 1) return HIPK_PATH_CODED;
+    if (h->n_codes > 0 && h->path_override != 1) return h->coded_layout == 3 ? HIPK_PATH_OFFSET_CODED : HIPK_PATH_CODED;
     return (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW) ? HIPK_PATH_TILE_FAST : HIPK_PATH_TILE;
 }
 extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
@@ -386,6 +406,8 @@ extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
 extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
     if (!h) return -1;
     const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
+    if (hipk_csr_spmv_path(h) == HIPK_PATH_OFFSET_CODED)  // code + value planes (+ plane offsets unless uniform) + x + y
+        return h->sell_bytes * (1 + sv) + (h->sell_w > 0 ? 0 : ((h->n_rows + 255) / 256) * 8) + 2 * h->n_rows * sv;
     if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED) {
         if (h->coded_layout == 2)  // byte planes (+ two plane offsets per tile unless uniform) + x + y
             return h->sell_bytes + (h->sell_w > 0 ? 0 : ((h->n_rows + 255) / 256) * 8) + 2 * h->n_rows * sv;
@@ -450,15 +472,17 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         const size_t lds = HIPK_CODED_MAX * (sv + 4) + (size_t)R * 16 + (size_t)R * a.code_cap;
         a.tile_off = h->tile_off;
         a.sell_w = h->sell_w;
-        const bool sell = h->coded_layout == 2;
+        const bool sell = h->coded_layout >= 2;
+        a.sell_vals = h->sell_vals;
         if (sell) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
             // exact tile size for the common stencil widths, run-time size otherwise
             const int tpc = a.ch / 256;
             void (*kern)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_LOOP(T, C)                                                                                 \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C> \
-     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C> : hipk_spmv_sell_loop_kernel<T, 0, C>)
+#define HIPK_PICK_LOOP_V(T, C, V)                                                                                   \
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V> \
+     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V> : hipk_spmv_sell_loop_kernel<T, 0, C, V>)
+#define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
             kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
@@ -475,6 +499,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 lgrid = ((lgrid + 7) >> 3) << 3;
             }
 #undef HIPK_PICK_LOOP
+#undef HIPK_PICK_LOOP_V
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);

@@ -108,7 +108,8 @@ __device__ __forceinline__ void hipk_memo_put(hipk_dict_memo &m, unsigned long l
 }
 
 // pass 1: insert every distinct (col - row, value) pair.  A global slot is claimed with one CAS.
-template <typename T>
+// OFFS_ONLY: the dictionary holds column offsets only (values stay per entry: variable-coefficient stencils)
+template <typename T, bool OFFS_ONLY>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const int *__restrict__ crow,
                                                                         const int *__restrict__ col,
                                                                         const T *__restrict__ val, int64_t n_rows,
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const in
         const int lo = crow[r], hi = crow[r + 1];
         for (int j = lo; j < hi; ++j) {
             const int off = col[j] - (int)r;
-            const unsigned long long bits = hipk_value_bits<T>(val[j]);
+            const unsigned long long bits = OFFS_ONLY ? 0ull : hipk_value_bits<T>(val[j]);
             const unsigned long long h = hipk_pair_hash(off, bits);
             if (hipk_memo_find(memo, h, off, bits)) continue;
             unsigned int s = (unsigned int)h & (HIPK_DICT_SLOTS - 1);
@@ -367,10 +368,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int
 }
 
 // code of row r, entry k -> its byte in r's tile (the planes are prefilled with HIPK_SELL_PAD)
-template <typename T>
+template <typename T, bool OFFS_ONLY>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
     const int *__restrict__ crow, const int *__restrict__ col, const T *__restrict__ val, int64_t n_rows,
-    hipk_dict_table *tb, const int *__restrict__ tile_off, unsigned char *__restrict__ code) {
+    hipk_dict_table *tb, const int *__restrict__ tile_off, unsigned char *__restrict__ code, T *__restrict__ vals) {
     __shared__ hipk_dict_memo memo;
     hipk_memo_clear(memo);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
         const int t = (int)(r & 255);
         for (int j = lo; j < hi; ++j) {
             const int off = col[j] - (int)r;
-            const unsigned long long bits = hipk_value_bits<T>(val[j]);
+            const unsigned long long bits = OFFS_ONLY ? 0ull : hipk_value_bits<T>(val[j]);
             const unsigned long long h = hipk_pair_hash(off, bits);
             const int k = j - lo;
             int c1 = hipk_memo_find(memo, h, off, bits);  // 1 + code
@@ -399,6 +400,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
                 const size_t pos = (k < 4 * D) ? (size_t)(k >> 2) * 1024 + (size_t)t * 4 + (k & 3)
                                                : (size_t)D * 1024 + (size_t)(k - 4 * D) * HIPK_TILE + t;
                 tilep[pos] = (unsigned char)(c1 - 1);
+                // value planes (offset-coded layout): plane k of the tile, one value per row; a tile of U units holds
+                // exactly U entries per row, so its planes start at element tile_off * 256
+                if (OFFS_ONLY) vals[(size_t)o0 * HIPK_TILE + (size_t)k * HIPK_TILE + t] = val[j];
             }
         }
     }
@@ -421,7 +425,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 //   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
 //   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
 #define HIPK_SELL_MAX_TPC 64  // tiles per chunk the chunked form holds in LDS (chunks up to 16384 rows)
-template <typename T, int UNITS, bool CHUNKED>
+// VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
+//   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
+//   row pointers, for stencils with variable coefficients.
+template <typename T, int UNITS, bool CHUNKED, bool VALS>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
     static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
@@ -466,13 +473,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
         return w;
     };
+    constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
     struct req_t {  // what a tile needs before its x gathers can be issued
         unsigned c[G0];
         T w, b;
+        T v[VALS ? NE : 1];  // VALS: the row's first NE values
         int D, Bp;
         const unsigned char *tp;
+        const T *vp;  // VALS: this thread's element of the tile's value plane 0
     };
-    constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
+    const T *__restrict__ vals = (const T *)a.sell_vals;
     auto request = [&](int tl, req_t &q) {  // tile tl's first G0 groups and epilogue operands
         const int r0 = tl * HIPK_TILE;
         if (UNITS > 0) {
@@ -488,6 +498,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
 #pragma unroll
         for (int g = 0; g < G0; ++g) q.c[g] = load_group(q.tp, q.D, q.Bp, g);
+        if (VALS) {
+            q.vp = vals + (size_t)(q.tp - code) + t;  // same prefix: a tile of U units has U value planes
+            const int cap = 4 * q.D + q.Bp;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                q.v[k] = (T)0;
+                if (UNITS > 0 || k < cap) q.v[k] = hipk_ld_nt(q.vp + (size_t)k * HIPK_TILE);
+            }
+        }
         q.w = (T)0;
         q.b = (T)0;
         if (r0 + t < n32) {
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const T p = dval[ck] * xc[k];
+            const T p = (VALS ? rc.v[k] : dval[ck]) * xc[k];
             const T s1 = s + p;
             s = (ck != HIPK_SELL_PAD) ? s1 : s;
         }
@@ -549,17 +568,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             const int rowx = row < n32 ? row : n32 - 1;
             for (int g = G0; g < groups; ++g) {  // wider stencils: further groups of four codes
                 const unsigned cw = load_group(rc.tp, rc.D, rc.Bp, g);
-                T xw[4];
+                const int cap = 4 * rc.D + rc.Bp;
+                T xw[4], vw[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned ck = (cw >> (k * 8)) & 0xFFu;
                     const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
                     xw[k] = *(const T *)(xb + bo);
+                    vw[k] = (T)0;
+                    if (VALS && 4 * g + k < cap) vw[k] = hipk_ld_nt(rc.vp + (size_t)(4 * g + k) * HIPK_TILE);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned ck = (cw >> (k * 8)) & 0xFFu;
-                    const T p = dval[ck] * xw[k];
+                    const T p = (VALS ? vw[k] : dval[ck]) * xw[k];
                     const T s1 = s + p;
                     s = (ck != HIPK_SELL_PAD) ? s1 : s;
                 }

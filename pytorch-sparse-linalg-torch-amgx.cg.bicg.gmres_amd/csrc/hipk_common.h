@@ -94,7 +94,9 @@ struct hipk_csr_s {
     void *dict_val;         // device, 256 values of `dtype`
     int n_codes;            // 0: no coded form
     int path_override;      // hipk_csr_set_path: 0 auto, 1 never use the coded form
-    int coded_layout;       // 1: codes in CSR order (+ rowlen); 2: sliced-ELL planes (tile_off / sell_w)
+    int coded_layout;       // 1: codes in CSR order (+ rowlen); 2: sliced-ELL planes (tile_off / sell_w);
+                            // 3: sliced-ELL planes of OFFSET codes + value planes (sell_vals)
+    void *sell_vals;        // device, sell_bytes values of `dtype`, owned (layout 3)
     int *tile_off;          // device, ntiles + 1 (sliced-ELL)
     int sell_w;             // uniform tile size in units of 256 B, or 0
     int64_t sell_bytes;     // bytes of all tiles

@@ -57,6 +57,7 @@ struct hipk_spmv_args {
     int code_cap;  // bytes of LDS per tile for the code bytes
     const int *tile_off;  // sliced-ELL layout: prefix sum of the tile sizes (units of 256 bytes), ntiles + 1
     int sell_w;           //   > 0: every tile has this size
+    const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
 };
 
 #ifdef __HIPCC__

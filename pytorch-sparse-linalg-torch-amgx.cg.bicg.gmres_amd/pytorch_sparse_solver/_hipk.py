@@ -216,7 +216,7 @@ class CsrHandle:
     def spmv_bytes(self) -> int:
         return int(lib().hipk_csr_spmv_bytes(self._h))
 
-    PATHS = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded"}
+    PATHS = {0: "tile_fast", 1: "tile", 2: "rowwave", 3: "coded", 4: "offset_coded"}
 
     def path(self) -> str:
         """SpMV kernel family selected by the structure analysis (include/hipk.h, hipk_spmv_path)."""

@@ -34,8 +34,8 @@ def make_handle(hipk, crow, col, val, n, dtype=torch.float64):
                           torch.from_numpy(val).to(DEV).to(dtype), (n, n))
 
 
-def both_paths(hipk, h, x):
-    assert h.path() == "coded"
+def both_paths(hipk, h, x, expect="coded"):
+    assert h.path() == expect
     y_coded = hipk.spmv(h, x).cpu().numpy()
     h.set_path(plain_only=True)
     assert h.path() in ("tile_fast", "tile")
@@ -120,10 +120,18 @@ def test_ragged_rows_with_few_pairs_fall_back_to_the_csr_layout(hipk, oracle):
     assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
 
 
-def test_random_values_and_long_rows_are_not_coded(hipk):
+def test_random_values_and_long_rows_are_not_coded(hipk, monkeypatch):
     n = 3000
     crow, col, val = banded(n, [-1, 0, 1], lambda r, k: np.random.default_rng(0).standard_normal(len(r)))
+    assert make_handle(hipk, crow, col, val, n).path() == "offset_coded"      # few offsets, arbitrary values
+    monkeypatch.setenv("HIPK_SPMV_OFFSET_CODED", "0")
     assert make_handle(hipk, crow, col, val, n).path() == "tile_fast"
+    monkeypatch.delenv("HIPK_SPMV_OFFSET_CODED")
+    rng = np.random.default_rng(1)                                            # random columns: > 255 distinct offsets
+    lens = np.full(n, 4)
+    crow = np.concatenate([[0], np.cumsum(lens)])
+    col = np.concatenate([np.sort(rng.choice(n, 4, replace=False)) for _ in range(n)])
+    assert make_handle(hipk, crow, col, rng.standard_normal(4 * n), n).path() == "tile_fast"
     crow, col, val = banded(n, list(range(-20, 21)), lambda r, k: 1.0 + k)       # 41 entries per row > 32
     assert make_handle(hipk, crow, col, val, n).path() == "tile"
 
@@ -255,3 +263,52 @@ def test_chunked_form_with_a_ragged_last_chunk_and_larger_chunks(hipk, oracle):
     for a, c in zip(coded, plain):
         assert np.array_equal(a, c)
     assert np.array_equal(coded[0], b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy()))
+
+
+# ------------------------------------------------------------------ offset-coded layout (variable coefficients)
+@pytest.mark.parametrize("chunked", ["1", "0"])
+@pytest.mark.parametrize("offsets", [[-300, -1, 0, 1, 300], [-1, 0, 1], [-40, -7, -1, 0, 1, 7, 40], [0, 5, 9, 11, 50, 51],
+                                     list(range(-13, 14))])
+@pytest.mark.parametrize("n", [1, 255, 257, 1023, 70_001, 1_200_011])
+def test_offset_coded_random_values_all_widths(hipk, oracle, n, offsets, chunked, monkeypatch):
+    monkeypatch.setenv("HIPK_SPMV_SELL_CHUNKED", chunked)
+    rng = np.random.default_rng(n + len(offsets))
+    crow, col, val = banded(n, offsets, lambda r, k: rng.standard_normal(len(r)))
+    h = make_handle(hipk, crow, col, val, n)
+    x = rng.standard_normal(n)
+    if n == 1 and 0 not in offsets:
+        return                                                                # empty matrix
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV), expect="offset_coded")
+    ref = oracle.spmv(crow, col, val, x)
+    assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
+    assert h.format_bytes() < h.spmv_bytes()
+
+
+def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle):
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    A = create_variable_diffusion_2d_csr(1500, 1500, device=DEV)             # 2.25M rows: chunked persistent kernel
+    n = A.shape[0]
+    h = hipk.handle_for(A)
+    assert h.path() == "offset_coded" and h.format_bytes() < 0.8 * h.spmv_bytes()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x, w, b = (torch.randn(n, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
+    coded = _spmv_ex_all_modes(hipk, h, x, w, b)
+    res = {}
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        xs = torch.zeros_like(b)
+        st = hipk.solve("cg", h, b, xs, tol=1e-10, atol=0.0, maxiter=150)
+        res[plain] = (xs.cpu().numpy(), st.iterations, st.residual_norm)
+    plain = _spmv_ex_all_modes(hipk, h, x, w, b)
+    h.set_path(plain_only=False)
+    for a, c in zip(coded, plain):
+        assert np.array_equal(a, c)
+    assert np.array_equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
+    crow, col, val = (t.cpu().numpy() for t in (A.crow_indices(), A.col_indices(), A.values()))
+    assert np.array_equal(coded[0], b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy()))
+    A32 = torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
+    h32 = hipk.handle_for(A32)
+    assert h32.path() == "offset_coded"
+    x32 = x.float()
+    y32, y32p = both_paths(hipk, h32, x32, expect="offset_coded")
+    assert np.array_equal(y32, y32p) and np.array_equal(y32, oracle.spmv32(crow, col, val.astype(np.float32), x32.cpu().numpy()))
