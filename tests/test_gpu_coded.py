@@ -278,7 +278,8 @@ def test_offset_coded_random_values_all_widths(hipk, oracle, n, offsets, chunked
     x = rng.standard_normal(n)
     if n == 1 and 0 not in offsets:
         return                                                                # empty matrix
-    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV), expect="offset_coded")
+    expect = "coded" if len(val) <= 255 else "offset_coded"                  # every value distinct: pairs = entries
+    y_coded, y_plain = both_paths(hipk, h, torch.from_numpy(x).to(DEV), expect=expect)
     ref = oracle.spmv(crow, col, val, x)
     assert np.array_equal(y_coded, ref) and np.array_equal(y_plain, ref)
     assert h.format_bytes() < h.spmv_bytes()
