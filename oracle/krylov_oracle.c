@@ -73,6 +73,7 @@ typedef double real;
 #define orc_pcg_jacobi orc32_pcg_jacobi
 #define orc_bicgstab orc32_bicgstab
 #define orc_gmres orc32_gmres
+#define orc_gmres_jacobi orc32_gmres_jacobi
 #endif
 
 static int g_threads = 1;
@@ -610,9 +611,21 @@ static void givens(double a, double b, double *cs, double *sn) {
 }
 
 /* gpu_tolerances: 1 = the `device.type == 'cuda'` branch of TSL:737-744 */
-int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b,
-              real *x, double tol, double atol, int restart, int64_t maxiter, int method /*0 batched,1 incremental*/,
-              int gpu_tolerances, orc_stats *st) {
+/* M = diag(dinv) (left preconditioning: every A(.) of TSL:641-803 is followed by M(.), TSL:351, 791, 766; ptol from
+   ||M b||, TSL:750): dinv == NULL is the unpreconditioned solver.  Row scaling is one extra rounding per element, applied
+   by the SpMV epilogue on the device (mode bit HIPK_SPMV_SCALE) before the fused dots. */
+static void spmv_m(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv, const real *x,
+                   const real *bsub, real *out) {
+    orc_spmv(n, crow, col, val, x, bsub, out);
+    if (dinv != NULL) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) out[i] = dinv[i] * out[i];
+    }
+}
+
+static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv,
+                      const real *b, real *x, double tol, double atol, int restart, int64_t maxiter,
+                      int method /*0 batched,1 incremental*/, int gpu_tolerances, orc_stats *st) {
     memset(st, 0, sizeof(*st));
     if (restart < 1 || restart > 31) return -1;
     if (maxiter < 0) maxiter = 10 * n;
@@ -631,11 +644,12 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *va
     const double adaptive = (cand > tol) ? cand : (double)(float)tol; /* python max(): float stays a float -> fp32 tensor */
     const double base_atol = (double)(float)(ORC_EPS64 * (gpu_tolerances ? 1000 : 100) * (double)n);
     const double atol_eff = tmax(adaptive * b_norm, tmax((double)(float)atol, base_atol));
-    const double ptol = b_norm * tmin(1.0, atol_eff / b_norm); /* TSL:750-753, M = identity */
+    const double mb_norm = dinv ? norm_from_sq(dot_scaled(n, b, dinv, 0)) : b_norm;  /* ||M b||, TSL:750 */
+    const double ptol = mb_norm * tmin(1.0, atol_eff / b_norm);                      /* TSL:750-753 */
 
     /* TSL:791-792 */
     real *res = V; /* residual lives in column 0 */
-    orc_spmv(n, crow, col, val, x, b, res);
+    spmv_m(n, crow, col, val, dinv, x, b, res);
     int64_t matvecs = 1;
     double res_norm = norm_from_sq(orc_dot_tiled(n, res, res));
     {
@@ -658,7 +672,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *va
         while (k < m && !breakdown && (method == 0 || err > ptol)) {
             /* ---- `_kth_arnoldi_iteration` (TSL:331-388) */
             real *w = V + (size_t)(k + 1) * n;
-            orc_spmv(n, crow, col, val, V + (size_t)k * n, NULL, w);
+            spmv_m(n, crow, col, val, dinv, V + (size_t)k * n, NULL, w);
             ++matvecs;
             double norm0 = norm_from_sq(orc_dot_tiled(n, w, w)); /* fused in the SpMV */
             if (!(norm0 > ORC_EPS)) norm0 = 0.0;
@@ -736,7 +750,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *va
                 x[i] = (real)((double)x[i] + s);
             }
         }
-        orc_spmv(n, crow, col, val, x, b, res);
+        spmv_m(n, crow, col, val, dinv, x, b, res);
         ++matvecs;
         res_norm = norm_from_sq(orc_dot_tiled(n, res, res));
         {
@@ -748,7 +762,7 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *va
         ++cycles;
     }
     /* TSL:766-773 */
-    orc_spmv(n, crow, col, val, x, b, tmp);
+    spmv_m(n, crow, col, val, dinv, x, b, tmp);
     ++matvecs;
     st->residual_norm = norm_from_sq(orc_dot_tiled(n, tmp, tmp));
     st->x_norm = norm_from_sq(orc_dot(n, x, x));
@@ -762,4 +776,15 @@ int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *va
     free(V);
     free(tmp);
     return 0;
+}
+
+int orc_gmres(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b, real *x, double tol,
+              double atol, int restart, int64_t maxiter, int method, int gpu_tolerances, orc_stats *st) {
+    return gmres_impl(n, crow, col, val, NULL, b, x, tol, atol, restart, maxiter, method, gpu_tolerances, st);
+}
+
+int orc_gmres_jacobi(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv, const real *b,
+                     real *x, double tol, double atol, int restart, int64_t maxiter, int method, int gpu_tolerances,
+                     orc_stats *st) {
+    return gmres_impl(n, crow, col, val, dinv, b, x, tol, atol, restart, maxiter, method, gpu_tolerances, st);
 }

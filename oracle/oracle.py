@@ -84,6 +84,8 @@ def lib():
         L.orc_pcg_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_gmres.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                 ctypes.c_int, ctypes.c_int, sp]
+        L.orc_gmres_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
+                                       ctypes.c_int, ctypes.c_int, sp]
         # fp32-storage variant (same source compiled with -DORC_F32): vectors/values float, dots and scalars fp64
         fp = ctypes.POINTER(ctypes.c_float)
         L.orc32_dot.argtypes = [i64, fp, fp]
@@ -96,6 +98,8 @@ def lib():
         L.orc32_pcg_jacobi.argtypes = [i64, ip, ip, fp, fp, fp, fp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc32_gmres.argtypes = [i64, ip, ip, fp, fp, fp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                   ctypes.c_int, ctypes.c_int, sp]
+        L.orc32_gmres_jacobi.argtypes = [i64, ip, ip, fp, fp, fp, fp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
+                                         ctypes.c_int, ctypes.c_int, sp]
         L.orc32_set_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
@@ -242,6 +246,21 @@ def gmres(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=No
     rc = lib().orc_gmres(b.size, _i(crow), _i(col), _d(val), _d(b), _d(x), float(tol), float(atol), int(restart),
                          -1 if maxiter is None else int(maxiter), method, 1 if gpu_tolerances else 0,
                          ctypes.byref(st))
+    if rc != 0:
+        raise ValueError("oracle gmres supports 1 <= restart <= 31")
+    return _result(x, st)
+
+
+def gmres_jacobi(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=None,
+                 solve_method="batched", gpu_tolerances=False) -> OracleResult:
+    """GMRES with M = diag(dinv) (left preconditioning, TSL:351, 750, 766, 791): restates hipk_pgmres_solve."""
+    crow, col, val, b, x = _prep(crow, col, val, b, x0)
+    dinv = np.ascontiguousarray(dinv, dtype=np.float64)
+    st = _Stats()
+    method = {"batched": 0, "incremental": 1}[solve_method]
+    rc = lib().orc_gmres_jacobi(b.size, _i(crow), _i(col), _d(val), _d(dinv), _d(b), _d(x), float(tol), float(atol),
+                                int(restart), -1 if maxiter is None else int(maxiter), method,
+                                1 if gpu_tolerances else 0, ctypes.byref(st))
     if rc != 0:
         raise ValueError("oracle gmres supports 1 <= restart <= 31")
     return _result(x, st)

@@ -10,7 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-RUNS = json.load(open(os.path.join(GOLD, "pcg_index.json")))["runs"]
+ALL = json.load(open(os.path.join(GOLD, "pcg_index.json")))["runs"]
+RUNS = [r for r in ALL if r.get("solver", "cg") == "cg"]
+GM = [r for r in ALL if r.get("solver") == "gmres"]
 
 
 def rid(r):
