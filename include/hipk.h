@@ -178,6 +178,10 @@ int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t wo
 size_t hipk_pcg_work_bytes(int64_t n, int dtype);
 int hipk_pcg_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
                    const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* GMRES with the same M (left preconditioning: the reference applies M after every A, TSL:351, 791, 766; ptol from
+ * ||M b||, TSL:750).  The row scaling runs in the SpMV epilogue.  Work buffer: hipk_gmres_work_bytes. */
+int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
+                      const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
 
     int64_t r0[R];
     int nr[R], len[R], head[R];  // head: offset of the tile's first code inside its LDS buffer
-    T wrow[R], brow[R];
+    T wrow[R], brow[R], drow[R];
     uint4 cv[R];
     int nvec[R];
     const unsigned char *cbase[R];
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
         len[i] = 0;
         wrow[i] = (T)0;
         brow[i] = (T)0;
+        drow[i] = (T)0;
         nvec[i] = 0;
         head[i] = 0;
         cbase[i] = code;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
                 len[i] = rowlen[r0[i] + t];
                 if (mode & HIPK_SPMV_DOT_W) wrow[i] = ((const T *)a.w)[r0[i] + t];
                 if (mode & HIPK_SPMV_RESID) brow[i] = ((const T *)a.bsub)[r0[i] + t];
+                if (mode & HIPK_SPMV_SCALE) drow[i] = ((const T *)a.dscale)[r0[i] + t];
             }
             if (t < nvec[i]) cv[i] = ((const uint4 *)cbase[i])[t];
         }
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
         if (t < nr[i]) {
             T out = s;
             if (mode & HIPK_SPMV_RESID) out = brow[i] - out;
+            if (mode & HIPK_SPMV_SCALE) out = drow[i] * out;
             y[row] = out;
             if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow[i] * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     constexpr int NE = UNITS == 0 ? 8 : (UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8));  // entries of the register groups
     struct req_t {  // what a tile needs before its x gathers can be issued
         unsigned c[G0];
-        T w, b;
+        T w, b, d;
         T v[VALS ? NE : 1];  // VALS: the row's first NE values
         int D, Bp;
         const unsigned char *tp;
@@ -509,9 +512,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
         q.w = (T)0;
         q.b = (T)0;
+        q.d = (T)0;
         if (r0 + t < n32) {
             if (mode & HIPK_SPMV_DOT_W) q.w = ((const T *)a.w)[r0 + t];
             if (mode & HIPK_SPMV_RESID) q.b = ((const T *)a.bsub)[r0 + t];
+            if (mode & HIPK_SPMV_SCALE) q.d = ((const T *)a.dscale)[r0 + t];
         }
     };
     auto gather = [&](const req_t &q, int tl, T(&xv)[NE]) {
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         if (row < n32) {
             T out = s;
             if (mode & HIPK_SPMV_RESID) out = rc.b - out;
+            if (mode & HIPK_SPMV_SCALE) out = rc.d * out;
             y[row] = out;
             if (mode & HIPK_SPMV_DOT_W) d0 = (double)rc.w * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;

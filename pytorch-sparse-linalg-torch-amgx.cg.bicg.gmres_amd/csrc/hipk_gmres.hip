@@ -460,9 +460,34 @@ extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
     return kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) + (size_t)(m + 2) * vec;
 }
 
+// partials of || d .* v ||^2 (||M b|| of the preconditioned solver, TSL:750)
 template <typename T>
-static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hipk_params *prm, hipk_stats *st,
-                              hipStream_t stream) {
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_scaled_sq_kernel(int64_t n, int ch, const T *__restrict__ v,
+                                                                         const T *__restrict__ d,
+                                                                         double *__restrict__ part) {
+    __shared__ double sbuf[HIPK_THREADS];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    hipk_chunk_loop<T>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T vv[VEC], dv[VEC];
+        hipk_ld<T>(v, i, nv, vv);
+        hipk_ld<T>(d, i, nv, dv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m = dv[k] * vv[k];
+            if (k < nv) acc = fma((double)m, (double)m, acc);
+        }
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) part[c] = acc;
+}
+
+// dinv != nullptr: left Jacobi preconditioning -- every A(.) is followed by M(.) = dinv .* (.) (TSL:351, 791, 766), applied
+// by the SpMV epilogue (HIPK_SPMV_SCALE) before its fused dots; ptol from ||M b|| (TSL:750).  Mirrored by orc_gmres_jacobi.
+template <typename T>
+static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char *work, const hipk_params *prm,
+                              hipk_stats *st, hipStream_t stream) {
     const int64_t n = A->n_rows;
     const hipk_geom gm = A->geom;
     const int m = prm->restart;
@@ -495,14 +520,16 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
     sa.n = n;
     sa.ch = gm.ch;
     sa.g = gm.g;
+    sa.dscale = dinv;
+    const int scale_bit = dinv ? HIPK_SPMV_SCALE : 0;
     int rc;
     int64_t matvecs = 0;
 
-    // residual = b - A x0 into column 0, unit residual + norm (TSL:791-792); <b,b>
+    // residual = M(b - A x0) into column 0, unit residual + norm (TSL:791-792); <b,b>
     hipk_spmv_args sr = sa;
     sr.x = x;
     sr.y = V;
-    sr.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sr.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY | scale_bit;
     sr.bsub = b;
     sr.part0 = part_spare;
     sr.part1 = part_res;
@@ -525,7 +552,17 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
     const double adaptive = (cand > prm->tol) ? cand : (double)(float)prm->tol;
     const double base_atol = (double)(float)(eps * (prm->gpu_tolerances ? 1000 : 100) * (double)n);
     const double atol_eff = hipk_tmax(adaptive * b_norm, hipk_tmax((double)(float)prm->atol, base_atol));
-    const double ptol = b_norm * hipk_tmin(1.0, atol_eff / b_norm);
+    double mb_norm = b_norm;  // ||M b|| (TSL:750)
+    if (dinv) {
+        hipk_gm_scaled_sq_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, b, dinv, part_spare);
+        double *mb_dev = part_xx;  // the <x,x> slot is unused until the end of the solve
+        if ((rc = hipk_launch_finish1(part_spare, gm.g, mb_dev, stream)) != HIPK_OK) return rc;
+        double mb2 = 0.0;
+        HIPK_CHECK_HIP(hipMemcpyAsync(&mb2, mb_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+        mb_norm = hipk_norm_from_sq(mb2);
+    }
+    const double ptol = mb_norm * hipk_tmin(1.0, atol_eff / b_norm);
 
     hipk_gm_scal *hs = (hipk_gm_scal *)malloc(sizeof(hipk_gm_scal));
     if (!hs) {
@@ -543,7 +580,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const
             hipk_spmv_args sw = sa;
             sw.x = V + (int64_t)k * ldv;
             sw.y = w;
-            sw.mode = HIPK_SPMV_DOT_YY;
+            sw.mode = HIPK_SPMV_DOT_YY | scale_bit;  // w = M(A v_k), ||w||^2 of the scaled vector (TSL:351-352)
             sw.part0 = part_spare;
             sw.part1 = part_ww;
             sw.stop_it = &scal->stop_step;
@@ -644,6 +681,29 @@ extern "C" int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work
     HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
     memset(st, 0, sizeof(*st));
     if (A->dtype == HIPK_F64)
-        return hipk_gmres_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st, (hipStream_t)stream);
-    return hipk_gmres_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+        return hipk_gmres_solve_t<double>(A, nullptr, (const double *)b, (double *)x, (char *)work, prm, st,
+                                          (hipStream_t)stream);
+    return hipk_gmres_solve_t<float>(A, nullptr, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+}
+
+extern "C" int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
+                                 const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && dinv && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
+                 "Unsupported solve_method");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && hipk_aligned16(dinv) && (((uintptr_t)work) & 255u) == 0,
+                 HIPK_ERR_ALIGN, "b/x/dinv must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_gmres_work_bytes(A->n_rows, prm->restart, A->dtype), HIPK_ERR_WORKSPACE,
+                 "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_gmres_solve_t<double>(A, (const double *)dinv, (const double *)b, (double *)x, (char *)work, prm, st,
+                                          (hipStream_t)stream);
+    return hipk_gmres_solve_t<float>(A, (const float *)dinv, (const float *)b, (float *)x, (char *)work, prm, st,
+                                     (hipStream_t)stream);
 }

@@ -26,6 +26,8 @@
 #define HIPK_SPMV_DOT_W 1   // part0[c] = sum w_i * out_i
 #define HIPK_SPMV_DOT_YY 2  // part1[c] = sum out_i * out_i
 #define HIPK_SPMV_RESID 4   // out = bsub - A x  instead of A x
+#define HIPK_SPMV_SCALE 8   // out = dscale .* out, after RESID and before the fused dots: left Jacobi preconditioning
+                            // M(A v), M(b - A x) of the preconditioned GMRES (TSL:351, 791); internal, not in hipk_spmv_ex
 #define HIPK_LONG_ROW 32    // rows with more nnz are summed by a wavefront (strided + tree)
 
 struct hipk_spmv_args {
@@ -58,6 +60,7 @@ struct hipk_spmv_args {
     const int *tile_off;  // sliced-ELL layout: prefix sum of the tile sizes (units of 256 bytes), ntiles + 1
     int sell_w;           //   > 0: every tile has this size
     const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
+    const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
 };
 
 #ifdef __HIPCC__
@@ -106,10 +109,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
     const int nr = (int)((a.n - r0 < HIPK_TILE) ? (a.n - r0) : HIPK_TILE);
     // operands of the epilogue, requested now so their latency hides behind the tile's main loads
     // (measured: SpMV+dot inside CG 68.3 -> 66.2 us, stand-alone 59.9 -> 57.7 us)
-    T wrow = (T)0, brow = (T)0;
+    T wrow = (T)0, brow = (T)0, drow = (T)0;
     if (t < nr) {
         if (mode & HIPK_SPMV_DOT_W) wrow = ((const T *)a.w)[r0 + t];
         if (mode & HIPK_SPMV_RESID) brow = ((const T *)a.bsub)[r0 + t];
+        if (mode & HIPK_SPMV_SCALE) drow = ((const T *)a.dscale)[r0 + t];
     }
     int crow_t = 0, crow_e = 0;
     if (t < nr) crow_t = crow[r0 + t];
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
     if (t < nr) {
         T out = yrow;
         if (mode & HIPK_SPMV_RESID) out = brow - out;
+        if (mode & HIPK_SPMV_SCALE) out = drow * out;
         y[r0 + t] = out;
         if (mode & HIPK_SPMV_DOT_W) d0 = (double)wrow * (double)out;
         if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_rowwave_kernel(hipk_sp
     }
     if (lane == 0) {
         if (!listed && (a.mode & HIPK_SPMV_RESID)) s = ((const T *)a.bsub)[row] - s;  // pre-pass: raw sum, the tile kernel finishes
+        if (!listed && (a.mode & HIPK_SPMV_SCALE)) s = ((const T *)a.dscale)[row] * s;
         ((T *)a.y)[row] = s;
     }
 }

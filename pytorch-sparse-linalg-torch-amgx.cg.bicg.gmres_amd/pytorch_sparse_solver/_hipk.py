@@ -28,7 +28,7 @@ SYMBOLS = [
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
-    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve",
+    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
     # step API (row-partitioned multi-GPU CG)
@@ -146,6 +146,7 @@ def lib():
     L.hipk_pcg_work_bytes.argtypes = [i64, i32]
     L.hipk_pcg_work_bytes.restype = ctypes.c_size_t
     L.hipk_pcg_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    L.hipk_pgmres_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     dbl = ctypes.c_double
     L.hipk_csr_create_ex.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, i32, vp]
     L.hipk_spmv_ex.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -406,6 +407,34 @@ def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor
                               ctypes.byref(st), _stream(h.device))
     _check(rc, "hipk_pcg_solve")
     return SolveStats(method="pcg_jacobi", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+                      breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
+                      threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
+                      spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
+                      event_overhead_ms=st.event_overhead_ms)
+
+
+def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                 maxiter: Optional[int], restart: int = 20, solve_method: str = "batched") -> SolveStats:
+    """hipk_pgmres_solve: GMRES with M = diag(dinv) applied after every A (left preconditioning)."""
+    if h.shape[0] != h.shape[1]:
+        raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
+    for t in (dinv, b, x):
+        assert t.is_contiguous() and t.dtype == h.dtype and t.numel() == h.n and t.device == h.device
+    prm = Params()
+    prm.tol, prm.atol = float(tol), float(atol)
+    prm.maxiter = -1 if maxiter is None else int(maxiter)
+    prm.restart = int(restart)
+    prm.gmres_method = {"batched": GMRES_BATCHED, "incremental": GMRES_INCREMENTAL}[solve_method]
+    prm.gpu_tolerances = 1
+    L = lib()
+    wb = int(L.hipk_gmres_work_bytes(h.n, int(restart), _dtype_code(h.dtype)))
+    work = torch.empty(wb, dtype=torch.uint8, device=h.device)
+    st = Stats()
+    with torch.cuda.device(h.device):
+        rc = L.hipk_pgmres_solve(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
+                                 ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
+    _check(rc, "hipk_pgmres_solve")
+    return SolveStats(method="pgmres_jacobi", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,

@@ -150,11 +150,15 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
     work_dtype = torch.float64 if h.dtype == torch.float64 else torch.float32
     bb = b.detach().to(work_dtype).contiguous()
     x = torch.zeros_like(bb) if x0 is None else x0.detach().to(work_dtype).clone().contiguous()
-    if jacobi is not None:  # cg with M = diag(dinv): hipk_pcg_solve
+    if jacobi is not None:  # cg / gmres with M = diag(dinv): hipk_pcg_solve / hipk_pgmres_solve
         if jacobi.shape != tuple(A.shape):
             raise ValueError(f'preconditioner shape {jacobi.shape} does not match the operator {tuple(A.shape)}')
         dinv = jacobi.dinv.detach().to(device=bb.device, dtype=work_dtype).contiguous()
-        st = _hipk.solve_pcg(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter)
+        if method == 'gmres':
+            st = _hipk.solve_pgmres(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                                    solve_method=solve_method)
+        else:
+            st = _hipk.solve_pcg(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter)
     else:
         st = _hipk.solve(method, h, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
                          solve_method=solve_method)
@@ -467,6 +471,9 @@ def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
     # spaces take the generic path (documented routing rule, not a fallback on failure)
     if _fast_ok(A, b, x0, M) and 1 <= restart <= 31:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method)
+    if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31:
+        return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method,
+                           jacobi=_jacobi_of(M))
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size

@@ -97,3 +97,48 @@ def test_preconditioner_of_another_shape_is_rejected(hipk):
     M = JacobiPreconditioner(create_poisson_2d_csr(10, 10, device=DEV))
     with pytest.raises(ValueError, match="preconditioner shape"):
         cg(A, torch.ones(400, dtype=torch.float64, device=DEV), M=M)
+
+
+@pytest.mark.parametrize("r", GM, ids=rid)
+def test_gmres_jacobi_bit_exact_vs_oracle_and_reference_counts(hipk, oracle, r):
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, get_last_stats, gmres
+    d = np.load(os.path.join(GOLD, r["case"] + ".npz"))
+    A = dev_csr(d)
+    M = JacobiPreconditioner(A)
+    x0 = torch.from_numpy(d["x0"]).to(DEV) if r["has_x0"] else None
+    x, info = gmres(A, torch.from_numpy(d["b"]).to(DEV), x0=x0, M=M, **r["kwargs"])
+    st = get_last_stats()
+    assert st.method == "pgmres_jacobi"
+    ref = oracle.gmres_jacobi(d["crow"], d["col"], d["val"], M.dinv.cpu().numpy(), d["b"],
+                              x0=d["x0"] if r["has_x0"] else None, gpu_tolerances=True, **r["kwargs"])
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert st.residual_norm == ref.residual_norm
+    x_ref = d[r["tag"] + "_x"]
+    if st.matvecs == r["matvecs"]:          # the reference ran with the CPU tolerance branch (TSL:737-744)
+        assert np.linalg.norm(x.cpu().numpy() - x_ref) <= 1e-7 * np.linalg.norm(x_ref)
+
+
+def test_gmres_jacobi_on_a_large_offset_coded_matrix(hipk, oracle):
+    """N = 1M variable-coefficient diffusion (offset-coded SpMV with the row-scaling epilogue): bit-exact vs the oracle,
+    and the preconditioned residual drops much faster than the unpreconditioned one."""
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    nx = 1000
+    A = create_variable_diffusion_2d_csr(nx, nx, device=DEV)
+    assert hipk.handle_for(A).path() == "offset_coded"
+    n = nx * nx
+    b = torch.randn(n, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    M = JacobiPreconditioner(A)
+    x, info = gmres(A, b, tol=1e-8, restart=20, maxiter=3, M=M, solve_method="incremental")
+    st = get_last_stats()
+    crow, col, val = (t.cpu().numpy() for t in (A.crow_indices(), A.col_indices(), A.values()))
+    oracle.set_threads(8)
+    ref = oracle.gmres_jacobi(crow, col, val, M.dinv.cpu().numpy(), b.cpu().numpy(), tol=1e-8, restart=20, maxiter=3,
+                              solve_method="incremental", gpu_tolerances=True)
+    oracle.set_threads(1)
+    assert np.array_equal(x.cpu().numpy(), ref.x) and st.matvecs == ref.matvecs
+    x2, _ = gmres(A, b, tol=1e-8, restart=20, maxiter=3, solve_method="incremental")
+    r1 = torch.linalg.norm(b - torch.mv(A, x)) / torch.linalg.norm(b)
+    r2 = torch.linalg.norm(b - torch.mv(A, x2)) / torch.linalg.norm(b)
+    assert r1 < 0.5 * r2
