@@ -72,6 +72,7 @@ typedef double real;
 #define orc_cg orc32_cg
 #define orc_pcg_jacobi orc32_pcg_jacobi
 #define orc_bicgstab orc32_bicgstab
+#define orc_bicgstab_jacobi orc32_bicgstab_jacobi
 #define orc_gmres orc32_gmres
 #define orc_gmres_jacobi orc32_gmres_jacobi
 #endif
@@ -418,14 +419,28 @@ int orc_pcg_jacobi(int64_t n, const int32_t *crow, const int32_t *col, const rea
 }
 
 /* ------------------------------------------------------------------ BiCGStab: TSL:859-964 */
-int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b,
-                 real *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
+/* out = A x (or bsub - A x), then row-scaled by dinv when given: M after A, one extra rounding per element */
+static void spmv_m(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv, const real *x,
+                   const real *bsub, real *out) {
+    orc_spmv(n, crow, col, val, x, bsub, out);
+    if (dinv != NULL) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) out[i] = dinv[i] * out[i];
+    }
+}
+
+
+/* dinv != NULL: M = diag(dinv) applied BEFORE A (TSL:908, 922: phat = M p, shat = M s, x += alpha phat + omega shat),
+   final `info` from ||M (b - A x)|| (TSL:1007).  phat / shat are stored vectors on the device as well. */
+static int bicgstab_impl(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv,
+                         const real *b, real *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
     csr_t A = {n, crow, col, val};
     memset(st, 0, sizeof(*st));
     if (maxiter < 0) maxiter = 10 * n;
     const size_t nb = sizeof(real) * (size_t)n;
     real *r = (real *)malloc(nb), *rhat = (real *)malloc(nb), *p = (real *)malloc(nb);
     real *q = (real *)malloc(nb), *s = (real *)malloc(nb), *t = (real *)malloc(nb);
+    real *phat = dinv ? (real *)malloc(nb) : p, *shat = dinv ? (real *)malloc(nb) : s;
     const double bs = orc_dot(n, b, b);
     const float tolf = (float)tol, atolf = (float)atol;
     const double a2 = (double)(tolf * tolf) * bs, a3 = (double)(atolf * atolf);
@@ -456,8 +471,9 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real 
             const real t2 = p[i] - t1;
             const real t3 = (real)beta * t2;
             p[i] = r[i] + t3;
+            if (dinv) phat[i] = dinv[i] * p[i];
         }
-        orc_spmv(n, crow, col, val, p, NULL, q);
+        orc_spmv(n, crow, col, val, phat, NULL, q);
         ++matvecs;
         const double alpha_new = rho_new / orc_dot_tiled(n, rhat, q);
         if (fabs(alpha_new) < ORC_EPS) {
@@ -468,9 +484,10 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real 
         for (int64_t i = 0; i < n; ++i) {
             const real m = (real)alpha_new * q[i];
             s[i] = r[i] - m;
+            if (dinv) shat[i] = dinv[i] * s[i];
         }
         const int exit_early = orc_dot(n, s, s) < atol2;
-        orc_spmv(n, crow, col, val, s, NULL, t);
+        orc_spmv(n, crow, col, val, shat, NULL, t);
         ++matvecs;
         const double tt = orc_dot_tiled(n, t, t);
         double omega_new;
@@ -484,12 +501,12 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real 
         }
 #pragma omp parallel for schedule(static) if (g_threads > 1)
         for (int64_t i = 0; i < n; ++i) {
-            const real m0 = (real)alpha_new * p[i];
+            const real m0 = (real)alpha_new * phat[i];
             if (exit_early) {
                 x[i] = x[i] + m0;
                 r[i] = s[i];
             } else {
-                const real m1 = (real)omega_new * s[i];
+                const real m1 = (real)omega_new * shat[i];
                 const real m2 = m0 + m1;
                 x[i] = x[i] + m2;
                 const real m3 = (real)omega_new * t[i];
@@ -504,7 +521,18 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real 
         ++k;
         if (exit_early) break;
     }
-    isolve_epilogue(&A, b, x, tol, atol, bs, t, st);
+    if (dinv == NULL) {
+        isolve_epilogue(&A, b, x, tol, atol, bs, t, st);
+    } else { /* TSL:1007 with M */
+        spmv_m(n, crow, col, val, dinv, x, b, t);
+        st->residual_norm = norm_from_sq(orc_dot_tiled(n, t, t));
+        st->b_norm = norm_from_sq(bs);
+        st->x_norm = norm_from_sq(orc_dot(n, x, x));
+        st->threshold = tmax((double)(float)tol * st->b_norm, (double)(float)atol);
+        st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+        free(phat);
+        free(shat);
+    }
     st->iterations = k;
     st->matvecs = matvecs + 1;
     st->breakdown = code;
@@ -516,6 +544,16 @@ int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real 
     free(s);
     free(t);
     return 0;
+}
+
+int orc_bicgstab(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *b, real *x, double tol,
+                 double atol, int64_t maxiter, orc_stats *st) {
+    return bicgstab_impl(n, crow, col, val, NULL, b, x, tol, atol, maxiter, st);
+}
+
+int orc_bicgstab_jacobi(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv,
+                        const real *b, real *x, double tol, double atol, int64_t maxiter, orc_stats *st) {
+    return bicgstab_impl(n, crow, col, val, dinv, b, x, tol, atol, maxiter, st);
 }
 
 /* ------------------------------------------------------------------ GMRES: TSL:641-803, 431-493, 557-638 */
@@ -614,15 +652,6 @@ static void givens(double a, double b, double *cs, double *sn) {
 /* M = diag(dinv) (left preconditioning: every A(.) of TSL:641-803 is followed by M(.), TSL:351, 791, 766; ptol from
    ||M b||, TSL:750): dinv == NULL is the unpreconditioned solver.  Row scaling is one extra rounding per element, applied
    by the SpMV epilogue on the device (mode bit HIPK_SPMV_SCALE) before the fused dots. */
-static void spmv_m(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv, const real *x,
-                   const real *bsub, real *out) {
-    orc_spmv(n, crow, col, val, x, bsub, out);
-    if (dinv != NULL) {
-#pragma omp parallel for schedule(static) if (g_threads > 1)
-        for (int64_t i = 0; i < n; ++i) out[i] = dinv[i] * out[i];
-    }
-}
-
 static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const real *val, const real *dinv,
                       const real *b, real *x, double tol, double atol, int restart, int64_t maxiter,
                       int method /*0 batched,1 incremental*/, int gpu_tolerances, orc_stats *st) {

@@ -82,6 +82,7 @@ def lib():
         L.orc_cg.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_bicgstab.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_pcg_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc_bicgstab_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_gmres.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                 ctypes.c_int, ctypes.c_int, sp]
         L.orc_gmres_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
@@ -248,6 +249,16 @@ def gmres(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=No
                          ctypes.byref(st))
     if rc != 0:
         raise ValueError("oracle gmres supports 1 <= restart <= 31")
+    return _result(x, st)
+
+
+def bicgstab_jacobi(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    """BiCGStab with M = diag(dinv) applied before A (TSL:908, 922): restates hipk_pbicgstab_solve."""
+    crow, col, val, b, x = _prep(crow, col, val, b, x0)
+    dinv = np.ascontiguousarray(dinv, dtype=np.float64)
+    st = _Stats()
+    lib().orc_bicgstab_jacobi(b.size, _i(crow), _i(col), _d(val), _d(dinv), _d(b), _d(x), float(tol), float(atol),
+                              -1 if maxiter is None else int(maxiter), ctypes.byref(st))
     return _result(x, st)
 
 
