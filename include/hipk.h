@@ -182,6 +182,11 @@ int hipk_pcg_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void 
  * ||M b||, TSL:750).  The row scaling runs in the SpMV epilogue.  Work buffer: hipk_gmres_work_bytes. */
 int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
                       const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* BiCGStab with the same M, applied BEFORE A as the reference does (phat = M p, shat = M s, TSL:908, 922; x advances
+ * with phat / shat, TSL:942; `info` from ||M (b - A x)||): phat and shat are two more work vectors. */
+size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype);
+int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
+                         const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the

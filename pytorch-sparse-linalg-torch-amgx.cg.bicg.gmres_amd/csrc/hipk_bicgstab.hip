@@ -79,10 +79,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
     }
 }
 
-template <typename T>
+// PRE = true: Jacobi preconditioning, M = diag(dinv) applied BEFORE A (TSL:908, 922): the kernel that forms p also
+// stores phat = dinv .* p (the SpMV's input), the one that forms s also stores shat, and x is advanced with phat / shat.
+template <typename T, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rr,
-    const double *__restrict__ part_rhr, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ p) {
+    const double *__restrict__ part_rhr, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ p,
+    const T *__restrict__ dinv, T *__restrict__ phat) {
     hipk_pre<T, 2> pre;  // r and q travel while the stop word is read and the partials are folded
     pre.issue(n, ch, blockIdx.x, {r, q});
     if (it >= scal->stop_it) return;
@@ -117,14 +120,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
             pv[k] = v[0][k] + t3;
         }
         hipk_st<T>(p, i, nv, pv);
+        if (PRE) {
+            T dv[VEC];
+            hipk_ld<T>(dinv, i, nv, dv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dv[k] = dv[k] * pv[k];  // TSL:908
+            hipk_st<T>(phat, i, nv, dv);
+        }
     });
 }
 
-template <typename T>
+template <typename T, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
     const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
-    double *__restrict__ part_ss) {
+    double *__restrict__ part_ss, const T *__restrict__ dinv, T *__restrict__ shat) {
     hipk_pre<T, 2> pre;
     pre.issue(n, ch, blockIdx.x, {r, q});
     if (it >= scal->stop_it) return;
@@ -157,17 +167,25 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
             if (k < nv) acc = fma((double)sv[k], (double)sv[k], acc);
         }
         hipk_st<T>(s, i, nv, sv);
+        if (PRE) {
+            T dv[VEC];
+            hipk_ld<T>(dinv, i, nv, dv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dv[k] = dv[k] * sv[k];  // TSL:922
+            hipk_st<T>(shat, i, nv, dv);
+        }
     });
     acc = hipk_block_sum(acc, sbuf);
     if (threadIdx.x == 0) part_ss[blockIdx.x] = acc;
 }
 
-template <typename T>
+template <typename T, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
     const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ rhat,
-    T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr) {
+    T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr,
+    const T *__restrict__ shat) {  // PRE: `p` is phat here; shat = M s
     hipk_pre<T, 1> pre;  // s up front; p, x, rhat, t follow after the fold (two early operands already cost the
     pre.issue(n, ch, blockIdx.x, {s});  // kernel its 8 workgroups per CU: 71 VGPRs)
     if (it >= scal->stop_it) return;
@@ -205,12 +223,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
                 rv[k] = sv[k];
             }
         } else {
-            T tv[VEC];
+            T tv[VEC], shv[VEC];
             hipk_ld<T>(t, i, nv, tv);
+            if (PRE) hipk_ld<T>(shat, i, nv, shv);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const T m0 = al * pv[k];
-                const T m1 = om * sv[k];
+                const T m1 = om * (PRE ? shv[k] : sv[k]);  // TSL:942: omega * shat
                 const T m2 = m0 + m1;
                 xv[k] = xv[k] + m2;
                 const T m3 = om * tv[k];
@@ -259,10 +278,15 @@ extern "C" size_t hipk_bicgstab_work_bytes(int64_t n, int dtype) {
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
     return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec;
 }
+extern "C" size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype) {
+    const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
+    const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
+    return hipk_bicgstab_work_bytes(n, dtype) + 2 * vec;  // + phat, shat
+}
 
-template <typename T>
-static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hipk_params *prm, hipk_stats *st,
-                                 hipStream_t stream) {
+template <typename T, bool PRE>
+static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char *work, const hipk_params *prm,
+                                 hipk_stats *st, hipStream_t stream) {
     const int64_t n = A->n_rows;
     const hipk_geom gm = A->geom;
     const size_t vec = hipk_align_up((size_t)n * sizeof(T), 256);
@@ -275,6 +299,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, co
     char *vbase = work + 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double);
     T *r = (T *)vbase, *rhat = (T *)(vbase + vec), *p = (T *)(vbase + 2 * vec), *q = (T *)(vbase + 3 * vec);
     T *s = (T *)(vbase + 4 * vec), *t = (T *)(vbase + 5 * vec);
+    T *phat = PRE ? (T *)(vbase + 6 * vec) : p, *shat = PRE ? (T *)(vbase + 7 * vec) : s;  // SpMV inputs (TSL:908, 922)
 
     const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;
     const float tolf = (float)prm->tol, atolf = (float)prm->atol;
@@ -309,7 +334,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, co
     HIPK_CHECK_HIP(hipGetLastError());
 
     hipk_spmv_args sq = sa, stt = sa;
-    sq.x = p;
+    sq.x = phat;
     sq.y = q;
     sq.mode = HIPK_SPMV_DOT_W;
     sq.w = rhat;
@@ -317,7 +342,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, co
     sq.part0 = part_rq;
     sq.part1 = part_spare;
     sq.stop_it = &scal->stop_it;
-    stt.x = s;
+    stt.x = shat;
     stt.y = t;
     stt.mode = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
     stt.w = s;
@@ -335,27 +360,28 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, co
         if (stop <= it) break;
         const int64_t end = (it + check < maxiter) ? it + check : maxiter;
         for (; it < end; ++it) {
-            hipk_bi_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr, part_rhr,
-                                                                            r, q, p);
+            hipk_bi_direction_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr,
+                                                                                 part_rhr, r, q, p, dinv, phat);
             sq.it = it;
             if ((rc = hipk_launch_spmv(A, sq, stream, &prof)) != HIPK_OK) return rc;
-            hipk_bi_supdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq, r,
-                                                                          q, s, part_ss);
+            hipk_bi_supdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq,
+                                                                               r, q, s, part_ss, dinv, shat);
             stt.it = it;
             if ((rc = hipk_launch_spmv(A, stt, stream)) != HIPK_OK) return rc;
-            hipk_bi_xupdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_ss,
-                                                                          part_ts, part_tt, p, s, t, rhat, x, r,
-                                                                          part_rr, part_rhr);
+            hipk_bi_xupdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_ss,
+                                                                               part_ts, part_tt, phat, s, t, rhat, x, r,
+                                                                               part_rr, part_rhr, shat);
         }
         HIPK_CHECK_HIP(hipGetLastError());
         HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
     }
     HIPK_CHECK_HIP(poll.drain(&stop));
 
-    // TSL:1007-1014
+    // TSL:1007-1014 (PRE: ||M (b - A x)||, the row scaling runs in the SpMV epilogue)
     sa.x = x;
     sa.y = t;
-    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY;
+    sa.mode = HIPK_SPMV_RESID | HIPK_SPMV_DOT_YY | (PRE ? HIPK_SPMV_SCALE : 0);
+    sa.dscale = dinv;
     sa.bsub = b;
     sa.part0 = part_spare;
     sa.part1 = part_ss;
@@ -391,7 +417,25 @@ extern "C" int hipk_bicgstab_solve(hipk_csr_t A, const void *b, void *x, void *w
     HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
     memset(st, 0, sizeof(*st));
     if (A->dtype == HIPK_F64)
-        return hipk_bicgstab_solve_t<double>(A, (const double *)b, (double *)x, (char *)work, prm, st,
-                                             (hipStream_t)stream);
-    return hipk_bicgstab_solve_t<float>(A, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream);
+        return hipk_bicgstab_solve_t<double, false>(A, nullptr, (const double *)b, (double *)x, (char *)work, prm, st,
+                                                    (hipStream_t)stream);
+    return hipk_bicgstab_solve_t<float, false>(A, nullptr, (const float *)b, (float *)x, (char *)work, prm, st,
+                                               (hipStream_t)stream);
+}
+
+extern "C" int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
+                                    const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && dinv && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && hipk_aligned16(dinv) && (((uintptr_t)work) & 255u) == 0,
+                 HIPK_ERR_ALIGN, "b/x/dinv must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_pbicgstab_work_bytes(A->n_rows, A->dtype), HIPK_ERR_WORKSPACE, "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_bicgstab_solve_t<double, true>(A, (const double *)dinv, (const double *)b, (double *)x, (char *)work, prm,
+                                                   st, (hipStream_t)stream);
+    return hipk_bicgstab_solve_t<float, true>(A, (const float *)dinv, (const float *)b, (float *)x, (char *)work, prm, st,
+                                              (hipStream_t)stream);
 }

@@ -28,7 +28,7 @@ SYMBOLS = [
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
-    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve",
+    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
     # step API (row-partitioned multi-GPU CG)
@@ -147,6 +147,9 @@ def lib():
     L.hipk_pcg_work_bytes.restype = ctypes.c_size_t
     L.hipk_pcg_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     L.hipk_pgmres_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    L.hipk_pbicgstab_work_bytes.argtypes = [i64, i32]
+    L.hipk_pbicgstab_work_bytes.restype = ctypes.c_size_t
+    L.hipk_pbicgstab_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     dbl = ctypes.c_double
     L.hipk_csr_create_ex.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, i32, vp]
     L.hipk_spmv_ex.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -387,8 +390,9 @@ def solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, *, tol: f
 
 
 def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
-              maxiter: Optional[int], check_every: int = 0) -> SolveStats:
-    """hipk_pcg_solve: CG with M = diag(dinv). `x` holds x0 on entry and the solution on return."""
+              maxiter: Optional[int], check_every: int = 0, method: str = "cg") -> SolveStats:
+    """hipk_pcg_solve / hipk_pbicgstab_solve (method "cg" / "bicgstab") with M = diag(dinv).
+    `x` holds x0 on entry and the solution on return."""
     if h.shape[0] != h.shape[1]:
         raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
     for t in (dinv, b, x):
@@ -399,14 +403,15 @@ def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor
     prm.check_every = int(check_every)
     prm.gpu_tolerances = 1
     L = lib()
-    wb = int(L.hipk_pcg_work_bytes(h.n, _dtype_code(h.dtype)))
+    name = {"cg": "pcg", "bicgstab": "pbicgstab"}[method]
+    wb = int(getattr(L, f"hipk_{name}_work_bytes")(h.n, _dtype_code(h.dtype)))
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
     st = Stats()
     with torch.cuda.device(h.device):
-        rc = L.hipk_pcg_solve(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm),
-                              ctypes.byref(st), _stream(h.device))
-    _check(rc, "hipk_pcg_solve")
-    return SolveStats(method="pcg_jacobi", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+        rc = getattr(L, f"hipk_{name}_solve")(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
+                                              ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
+    _check(rc, f"hipk_{name}_solve")
+    return SolveStats(method=f"{name}_jacobi", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,

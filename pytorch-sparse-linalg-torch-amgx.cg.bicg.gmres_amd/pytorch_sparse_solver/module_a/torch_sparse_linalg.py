@@ -158,7 +158,7 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
             st = _hipk.solve_pgmres(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
                                     solve_method=solve_method)
         else:
-            st = _hipk.solve_pcg(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter)
+            st = _hipk.solve_pcg(h, dinv, bb, x, tol=tol, atol=atol, maxiter=maxiter, method=method)
     else:
         st = _hipk.solve(method, h, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
                          solve_method=solve_method)
@@ -363,8 +363,8 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
     """Shared CG/BiCGStab wrapper (`_isolve`, TSL:968-1016)."""
     if _fast_ok(A, b, x0, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter)
-    if kind == 'cg' and _jacobi_of(M) is not None and _fast_ok(A, b, x0, None):
-        return _fast_solve('cg', A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
+    if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None):
+        return _fast_solve(kind, A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size
