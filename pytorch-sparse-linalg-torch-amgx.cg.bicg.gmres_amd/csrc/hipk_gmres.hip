@@ -18,6 +18,7 @@
 //     triangular solve TSL:630) in the same arithmetic order as the oracle.
 // Traffic of step k (fp64): B_spmv + 8n(k+2) [multi-dot] + 8n(k+3) [update] + 16n [normalise].
 #include <math.h>
+#include <stdlib.h>
 
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
@@ -82,17 +83,54 @@ __device__ __forceinline__ void hipk_block_sum8(double (&v)[8], int nb, double *
     (void)nb;
 }
 
+// Small systems (at most 8 reduction chunks, n <= 16384): an Arnoldi step is launch-bound (10 launches of ~4 us for a few
+// KB of data), so three of them are folded into their consumers.  hipk_fold8 is the spec's fold of g <= 8 partials
+// (hipk_reduce_parts: acc = 0.0 + part[t], then the tree v[t] += v[t+s], s = 128..1, of which only s = 4, 2, 1 touch
+// non-zero slots) evaluated by ONE thread: same additions, same order, same bits.
+__device__ __forceinline__ double hipk_fold8(const double *__restrict__ part, int g) {
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.0 + ((i < g) ? part[i] : 0.0);
+    return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+
+// second CGS pass iff ||r|| < ||q|| / sqrt(2)  (TSL:313-326); shared by hipk_gm_decide_kernel and the SMALL multi-dot
+__device__ __forceinline__ int hipk_gm_want_pass2(const hipk_gm_scal *scal, int k, double qq, double eps, double *qnorm_out) {
+    double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+    if (!(qnorm > eps)) qnorm = 0.0;
+    double rr = 0.0;
+    for (int j = 0; j <= k; ++j) rr = fma(scal->rvec[j], scal->rvec[j], rr);
+    double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+    if (!(rnorm > eps)) rnorm = 0.0;
+    *qnorm_out = qnorm;
+    return (rnorm < qnorm * HIPK_INV_SQRT2) ? 1 : 0;
+}
+
 // part[j*MAXP + c] = chunk partial of <V_j, w>, j = 0..k  (`_project_on_columns`, TSL:276-281)
 // grid = (chunks, ceil((k+1)/8)): a workgroup takes EIGHT columns of one chunk -- eight accumulators and eight
 // column streams per thread keep it at 8 workgroups per CU (31 accumulators in one workgroup: 2-4 per CU, several
 // rounds of workgroups); w's chunk is re-read by each column group from L2.  All eight loads of a step are issued
 // before their FMAs.  Per column the accumulation order is the spec's.
-template <typename T>
+// SMALL (g <= 8): the pass-2 launch takes the CGS2 decision itself (no hipk_gm_decide_kernel launch): every workgroup
+// derives it from the same partials, workgroup (0,0) publishes it for the kernels that follow.
+template <typename T, bool SMALL>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_kernel(
-    int64_t n, int ch, const hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
-    const T *__restrict__ w, double *__restrict__ part) {
+    int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    const T *__restrict__ w, double *__restrict__ part, const double *__restrict__ part_qq, int g, double eps) {
     if (k >= scal->stop_step) return;
-    if (pass == 1 && !scal->pass2) return;
+    if (pass == 1) {
+        if (SMALL) {
+            double qnorm;
+            const int want = hipk_gm_want_pass2(scal, k, hipk_fold8(part_qq, g), eps, &qnorm);
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+                scal->qnorm = qnorm;
+                scal->pass2 = want;
+            }
+            if (!want) return;
+        } else if (!scal->pass2) {
+            return;
+        }
+    }
     __shared__ double sbuf[8 * HIPK_THREADS];
     const int c = blockIdx.x;
     const int j0 = 8 * blockIdx.y;  // <= k by construction of the grid
@@ -135,15 +173,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_hreduce_kernel(hipk_gm_s
 }
 
 // q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305)
-template <typename T>
+// SMALL (g <= 8): h_j is folded here from the multi-dot partials (no hipk_gm_hreduce_kernel launch)
+template <typename T, bool SMALL>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
-    T *__restrict__ w, double *__restrict__ part_qq) {
+    T *__restrict__ w, double *__restrict__ part_qq, const double *__restrict__ part_md, int g) {
     if (k >= scal->stop_step) return;
     if (pass == 1 && !scal->pass2) return;
     __shared__ double sbuf[HIPK_THREADS];
     __shared__ double hs[HIPK_GM_LDH];
-    if (threadIdx.x < HIPK_GM_LDH) hs[threadIdx.x] = (threadIdx.x <= k) ? scal->hvec[threadIdx.x] : 0.0;
+    if (threadIdx.x < HIPK_GM_LDH) {
+        double hj = 0.0;
+        if (threadIdx.x <= k)
+            hj = SMALL ? hipk_fold8(part_md + (size_t)threadIdx.x * HIPK_MAX_PARTS, g) : scal->hvec[threadIdx.x];
+        hs[threadIdx.x] = hj;
+    }
     __syncthreads();
     const int c = blockIdx.x;
     double acc = 0.0;
@@ -193,14 +237,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_sc
     __shared__ double sbuf[HIPK_THREADS];
     const double qq = hipk_reduce_parts(part_qq, g, sbuf);
     if (threadIdx.x == 0) {
-        double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
-        if (!(qnorm > eps)) qnorm = 0.0;
-        double rr = 0.0;
-        for (int j = 0; j <= k; ++j) rr = fma(scal->rvec[j], scal->rvec[j], rr);
-        double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
-        if (!(rnorm > eps)) rnorm = 0.0;
+        double qnorm;
+        scal->pass2 = hipk_gm_want_pass2(scal, k, qq, eps, &qnorm);
         scal->qnorm = qnorm;
-        scal->pass2 = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1 : 0;
     }
 }
 
@@ -570,6 +609,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         return HIPK_ERR_ARG;
     }
     int64_t cycles = 0;
+    const bool small = gm.g <= 8 && !getenv("HIPK_GMRES_NO_SMALL");  // launch-bound systems: fewer launches per step
     int happy = 0;
     int64_t prof_valid = 0;
     rc = HIPK_OK;
@@ -587,11 +627,20 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             sw.it = k;
             if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
-                hipk_gm_multidot_kernel<T><<<dim3(gm.g, k / 8 + 1), HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V,
-                                                                                                ldv, w, part_md);
-                hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
-                hipk_gm_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_qq);
+                const dim3 mgrid(gm.g, k / 8 + 1);
+                if (small) {  // 7 instead of 10 launches per Arnoldi step (decide and the two hreduce folded away)
+                    hipk_gm_multidot_kernel<T, true><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                         part_md, part_qq, gm.g, eps_t);
+                    hipk_gm_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                      part_qq, part_md, gm.g);
+                } else {
+                    if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
+                    hipk_gm_multidot_kernel<T, false><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                          part_md, part_qq, gm.g, eps_t);
+                    hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
+                    hipk_gm_update_kernel<T, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                       part_qq, part_md, gm.g);
+                }
             }
             hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, k, w, part_qq,
                                                                             part_ww, eps_t);

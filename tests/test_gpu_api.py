@@ -147,3 +147,28 @@ def test_restart_above_31_uses_reference_semantics(hipk):
     b = torch.randn(60, dtype=torch.float64, generator=g).to(DEV)
     x, info = gmres(A, b, tol=1e-10, restart=40)
     assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-8
+
+
+@pytest.mark.gpu
+def test_gmres_small_system_launch_folding_is_bit_identical(monkeypatch):
+    """Systems of <= 8 reduction chunks fold the CGS2 decision and the h-vector reduction into their consumers
+    (7 instead of 10 launches per Arnoldi step): same bits as the general launch sequence."""
+    import torch
+    from pytorch_sparse_solver.module_a import get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_ldc_pressure_csr
+    for A, kw in ((create_ldc_pressure_csr(100, device="cuda:0"), dict(tol=1e-10, restart=30, maxiter=30)),
+                  (create_convdiff_2d_csr(90, 90, device="cuda:0"), dict(tol=1e-9, restart=12, maxiter=40, solve_method="incremental"))):
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(n))
+        if kw["restart"] == 30:
+            b -= b.mean()                                      # the Neumann pressure matrix is singular: compatible rhs
+        out = {}
+        for flag in ("0", "1"):
+            if flag == "1":
+                monkeypatch.setenv("HIPK_GMRES_NO_SMALL", "1")
+            else:
+                monkeypatch.delenv("HIPK_GMRES_NO_SMALL", raising=False)
+            x, info = gmres(A, b, **kw)
+            st = get_last_stats()
+            out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
+        assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:]
