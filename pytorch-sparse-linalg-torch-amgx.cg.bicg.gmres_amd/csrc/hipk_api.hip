@@ -342,8 +342,8 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
         h->n_huge = cnt_h;
     }
     // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
-    h->sell_chunked = 1;  // allow the chunk-per-workgroup form of the persistent kernel (HIPK_SPMV_SELL_CHUNKED=0: never)
-    if (const char *sc = getenv("HIPK_SPMV_SELL_CHUNKED")) h->sell_chunked = atoi(sc) != 0;
+    h->sell_chunked = 2;  // chunk-per-workgroup form when sell_chunked * chunks >= resident workgroups (0: never)
+    if (const char *sc = getenv("HIPK_SPMV_SELL_CHUNKED")) h->sell_chunked = atoi(sc) < 0 ? 0 : (atoi(sc) == 1 ? 2 : atoi(sc));
     h->sell_loop = 1;  // persistent sliced-ELL kernel: grid = sell_loop x the resident workgroups
     if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 1 ? 1 : (atoi(sl) > 4 ? 4 : atoi(sl));
     {
@@ -488,7 +488,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
             const int slots = h->n_cu * occ;
             // one workgroup per reduction chunk when the chunks about fill the machine in one round
-            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && 2 * a.g >= slots;
+            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots &&
+                                 h->sell_chunked * a.g >= slots;  // default: the chunks fill at least half of the slots
             int lgrid;
             if (chunked) {
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
