@@ -313,3 +313,56 @@ def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle):
     x32 = x.float()
     y32, y32p = both_paths(hipk, h32, x32, expect="offset_coded")
     assert np.array_equal(y32, y32p) and np.array_equal(y32, oracle.spmv32(crow, col, val.astype(np.float32), x32.cpu().numpy()))
+
+
+# ------------------------------------------------------------------ randomized structures through every path
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_structures_all_paths_agree_with_the_oracle(hipk, oracle, seed):
+    """Random banded / ragged / mixed matrices: whatever path the structure analysis picks (coded, offset-coded, CSR-ordered
+    codes, tile, tile-fast, row-per-wavefront) must give the oracle's bits for y and for the fused-dot chunk partials."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([37, 256, 300, 1025, 2049, 5000, 20_011]))
+    kind = seed % 5
+    if kind == 0:      # stencil with few values, some rows emptied
+        offs = np.unique(rng.integers(-40, 41, size=rng.integers(1, 9)))
+        vals = rng.standard_normal(len(offs)).round(1) + 0.05
+        crow, col, val = banded(n, offs, lambda r, k: vals[k])
+    elif kind == 1:    # stencil with random values (offset-coded)
+        offs = np.unique(rng.integers(-300, 301, size=rng.integers(2, 12)))
+        crow, col, val = banded(n, offs, lambda r, k: rng.standard_normal(len(r)))
+    elif kind == 2:    # ragged rows, few offsets relative to the row (CSR-ordered codes or tile)
+        lens = rng.integers(0, 33, n) * (rng.random(n) < 0.3)
+        crow = np.concatenate([[0], np.cumsum(lens)])
+        col = np.concatenate([np.sort((r + np.arange(l) * 3) % n) for r, l in enumerate(lens)]) if crow[-1] else np.zeros(0, np.int64)
+        val = np.ones(int(crow[-1])) * 0.5
+    elif kind == 3:    # random columns, short rows (plain tile kernels)
+        lens = rng.integers(0, 12, n)
+        crow = np.concatenate([[0], np.cumsum(lens)])
+        col = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]) if crow[-1] else np.zeros(0, np.int64)
+        val = rng.standard_normal(int(crow[-1]))
+    else:              # a few long rows among short ones
+        lens = np.where(rng.random(n) < 0.02, rng.integers(33, min(n, 600), n), rng.integers(1, 6, n))
+        crow = np.concatenate([[0], np.cumsum(lens)])
+        col = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens])
+        val = rng.standard_normal(int(crow[-1]))
+    crow, col, val = np.asarray(crow, np.int64), np.asarray(col, np.int64), np.asarray(val, np.float64)
+    h = make_handle(hipk, crow, col, val, n)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x, w, b = (torch.randn(n, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
+    auto = _spmv_ex_all_modes(hipk, h, x, w, b)
+    h.set_path(plain_only=True)
+    plain = _spmv_ex_all_modes(hipk, h, x, w, b)
+    for a, c in zip(auto, plain):
+        assert np.array_equal(a, c), h.path()
+    y_ref = b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy())
+    assert np.array_equal(auto[0], y_ref)
+    ch = int(hipk.lib().hipk_chunk_size(n))
+    G = int(hipk.lib().hipk_chunk_count(n))
+    p0 = np.zeros(G)
+    p1 = np.zeros(G)
+    wv = w.cpu().numpy()
+    for c in range(G):
+        sl = slice(c * ch, min(n, (c + 1) * ch))
+        p0[c] = oracle.dot_tiled(wv[sl], y_ref[sl])
+        p1[c] = oracle.dot_tiled(y_ref[sl], y_ref[sl])
+    assert np.array_equal(auto[1], p0) and np.array_equal(auto[2], p1)
