@@ -117,8 +117,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_insert_kernel(const in
     __shared__ hipk_dict_memo memo;
     hipk_memo_clear(memo);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the overflow flag is read once, with an ordinary (cacheable) load: an atomic load per row was 4 M round trips to
+    // one address.  A stale "no overflow" only means this thread finishes its few rows.
+    if (((volatile const int *)&tb->overflow)[0]) return;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
-        if (__hip_atomic_load(&tb->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         const int lo = crow[r], hi = crow[r + 1];
         for (int j = lo; j < hi; ++j) {
             const int off = col[j] - (int)r;
