@@ -172,3 +172,32 @@ def test_gmres_small_system_launch_folding_is_bit_identical(monkeypatch):
             st = get_last_stats()
             out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
         assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:]
+
+
+@pytest.mark.gpu
+def test_preconditioned_entry_points_validate_their_arguments():
+    import ctypes
+    import torch
+    from pytorch_sparse_solver import _hipk
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(12, 12, device="cuda:0")
+    h = _hipk.handle_for(A)
+    L = _hipk.lib()
+    n = 144
+    b = torch.ones(n, dtype=torch.float64, device="cuda:0")
+    x = torch.zeros_like(b)
+    d = torch.full((n,), 0.25, dtype=torch.float64, device="cuda:0")
+    prm, st = _hipk.Params(), _hipk.Stats()
+    prm.tol, prm.maxiter, prm.restart = 1e-8, -1, 10
+    s = torch.cuda.current_stream().cuda_stream
+    for fn, wb in ((L.hipk_pcg_solve, L.hipk_pcg_work_bytes(n, _hipk.HIPK_F64)),
+                   (L.hipk_pbicgstab_solve, L.hipk_pbicgstab_work_bytes(n, _hipk.HIPK_F64)),
+                   (L.hipk_pgmres_solve, L.hipk_gmres_work_bytes(n, 10, _hipk.HIPK_F64))):
+        work = torch.empty(int(wb), dtype=torch.uint8, device="cuda:0")
+        args = lambda **o: [o.get("h", h.ptr), o.get("d", d.data_ptr()), b.data_ptr(), o.get("x", x.data_ptr()), work.data_ptr(),
+                            o.get("wb", int(wb)), ctypes.byref(prm), ctypes.byref(st), s]
+        assert fn(*args()) == 0 and st.info == 0
+        assert fn(*args(d=None)) == _hipk.HIPK_ERR_ARG if hasattr(_hipk, "HIPK_ERR_ARG") else fn(*args(d=None)) < 0
+        assert fn(*args(wb=16)) < 0 and b"work too small" in L.hipk_last_error()
+        assert fn(*args(x=b.data_ptr())) < 0                      # b and x alias
+        assert fn(*args(d=d.data_ptr() + 8)) < 0                  # misaligned dinv

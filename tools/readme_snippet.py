@@ -1,0 +1,13 @@
+import sys; sys.path.insert(0, "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd")
+import torch
+from pytorch_sparse_solver.module_a import cg, gmres, get_last_stats
+from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+A = create_poisson_2d_csr(2000, 2000, device="cuda")            # CSR, N = 4M
+b = torch.ones(A.shape[0], dtype=torch.float64, device="cuda")
+x, info = cg(A, b, tol=1e-6)                                    # HIP fast path, info == 0
+print(info, get_last_stats().iterations)
+from pytorch_sparse_solver.module_a import JacobiPreconditioner
+x, info = cg(A, b, tol=1e-6, M=JacobiPreconditioner(A)); print(info, get_last_stats().method, get_last_stats().iterations)
+x, info = gmres(A, b, restart=30, maxiter=3, M=JacobiPreconditioner(A)); print(info, get_last_stats().method)
+from pytorch_sparse_solver import SparseSolver
+x, res = SparseSolver().solve(A, b, method='bicgstab', backend='module_a', tol=1e-6); print(res.converged, res.residual)
