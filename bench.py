@@ -105,10 +105,16 @@ def main():
     from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 
     nx = args.nx
-    if world > 1:
+    # HIPK_BENCH_DIST=1 runs the row-partitioned code path at world size 1 as well (rehearsal of the N > 1 branch on a
+    # one-GPU box: same classes, same RCCL calls, no peers)
+    use_dist = world > 1 or os.environ.get("HIPK_BENCH_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
-        dist.init_process_group("nccl", device_id=dev)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29581")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         prob = DistPoissonProblem(nx_per_rank=nx, ny=nx, rank=rank, world=world, device=dev)
 
         def barrier():
@@ -145,7 +151,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -159,7 +165,7 @@ def main():
     spmv_standalone = None
     kernels = None
     spmv_report = None
-    if world == 1:
+    if not use_dist:
         n = nx * nx
         sv = 8
         pmc = {}
@@ -239,7 +245,7 @@ def main():
             finally:
                 h.set_path(plain_only=False)
 
-    if world > 1:
+    if use_dist:
         # roofline leg at N > 1: this rank's local SpMV (no communication), HIP events on the launch stream
         xe = prob.ops.zeros(max(prob.n_ext, 1))
         xe.normal_(generator=torch.Generator(device=dev).manual_seed(rank))
@@ -276,10 +282,10 @@ def main():
             "kernels": kernels,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not use_dist:
             out["cpu_baseline"] = cpu_baseline(nx, args.cpu_iters)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
