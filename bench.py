@@ -108,6 +108,13 @@ def main():
     # HIPK_BENCH_DIST=1 runs the row-partitioned code path at world size 1 as well (rehearsal of the N > 1 branch on a
     # one-GPU box: same classes, same RCCL calls, no peers)
     use_dist = world > 1 or os.environ.get("HIPK_BENCH_DIST") == "1"
+    json_fd = None
+    if use_dist:
+        # RCCL prints a version banner to STDOUT when a communicator is created; the contract is ONE JSON line there.
+        # Everything but the final line goes to stderr: fd 1 is pointed at fd 2 until the result is printed.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
         from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
@@ -287,7 +294,12 @@ def main():
         }
         if not args.no_cpu_baseline and not use_dist:
             out["cpu_baseline"] = cpu_baseline(nx, args.cpu_iters)
-        print(json.dumps(out))
+        line = json.dumps(out)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (line + "\n").encode())
+        else:
+            print(line)
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
