@@ -372,8 +372,6 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     // coded form: short rows everywhere, mean row below the row-per-wavefront threshold, not disabled by the environment
     h->sell_chunked = 2;  // chunk-per-workgroup form when sell_chunked * chunks >= resident workgroups (0: never)
     if (const char *sc = getenv("HIPK_SPMV_SELL_CHUNKED")) h->sell_chunked = atoi(sc) < 0 ? 0 : (atoi(sc) == 1 ? 2 : atoi(sc));
-    h->sell_depth = 0;  // software-pipeline depth of the persistent kernel: 0 = by size, 2 / 3 forced (HIPK_SPMV_SELL_DEPTH)
-    if (const char *sd = getenv("HIPK_SPMV_SELL_DEPTH")) h->sell_depth = (atoi(sd) == 2 || atoi(sd) == 3) ? atoi(sd) : 0;
     h->sell_loop = 1;  // persistent sliced-ELL kernel: grid = sell_loop x the resident workgroups
     if (const char *sl = getenv("HIPK_SPMV_SELL_LOOP")) h->sell_loop = atoi(sl) < 1 ? 1 : (atoi(sl) > 4 ? 4 : atoi(sl));
     {
@@ -509,13 +507,10 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             // exact tile size for the common stencil widths, run-time size otherwise
             const int tpc = a.ch / 256;
             void (*kern)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_LOOP_D(T, C, V, D)                                                                                      \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V, D> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V, D> \
-     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V, D> : hipk_spmv_sell_loop_kernel<T, 0, C, V, D>)
-#define HIPK_PICK_LOOP_V(T, C, V) (depth3 ? HIPK_PICK_LOOP_D(T, C, V, 3) : HIPK_PICK_LOOP_D(T, C, V, 2))
+#define HIPK_PICK_LOOP_V(T, C, V)                                                                                   \
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V> \
+     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V> : hipk_spmv_sell_loop_kernel<T, 0, C, V>)
 #define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
-            // pipeline depth 3 once the CG working set (~38 B per row on this path) has outgrown the 256 MiB Infinity Cache
-            const bool depth3 = h->sell_depth == 3 || (h->sell_depth == 0 && h->n_rows > (int64_t)6 * 1000 * 1000);
             kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
@@ -534,7 +529,6 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             }
 #undef HIPK_PICK_LOOP
 #undef HIPK_PICK_LOOP_V
-#undef HIPK_PICK_LOOP_D
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);

@@ -433,11 +433,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
 //   row pointers, for stencils with variable coefficients.
-// DEPTH = 2: the next tile's codes travel while the current tile's gathers are outstanding.  DEPTH = 3: additionally the
-//   NEXT tile's gathers are issued before the current tile's arithmetic -- no better while the working set sits in the
-//   Infinity Cache (N = 4 M), but the request/gather waits grow with HBM latency on large systems (N = 64 M: 453 us
-//   at depth 2), so large systems take depth 3.
-template <typename T, int UNITS, bool CHUNKED, bool VALS, int DEPTH>
+template <typename T, int UNITS, bool CHUNKED, bool VALS>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
     static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
@@ -549,22 +545,37 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         return (idx < per && xcd * per + idx < ntiles) ? xcd * per + idx : ntiles;
     };
 
-    auto finish = [&](const req_t &q, int tl, const T(&xv)[NE]) {  // arithmetic, store and fused dots of tile tl
-        const int row = tl * HIPK_TILE + t;
+    // two tiles in flight per workgroup: the next tile's codes and epilogue operands travel while the current
+    // tile's x gathers are outstanding (a third stage -- gathers one tile ahead -- measured no better)
+    req_t rc, rn;
+    T xc[NE];
+    int tc = first_tile();
+    if (tc < ntiles) request(tc, rc);
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
+    doff[t] = dofs;
+    __syncthreads();
+
+    while (tc < ntiles) {
+        gather(rc, tc, xc);
+        const int tn = next_tile();
+        if (tn < ntiles) request(tn, rn);
+
+        const int row = tc * HIPK_TILE + t;
         T s = (T)0;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const unsigned ck = (q.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const T p = (VALS ? q.v[k] : dval[ck]) * xv[k];
+            const unsigned ck = (rc.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const T p = (VALS ? rc.v[k] : dval[ck]) * xc[k];
             const T s1 = s + p;
             s = (ck != HIPK_SELL_PAD) ? s1 : s;
         }
         if (UNITS == 0) {
-            const int groups = q.D + (q.Bp > 0 ? 1 : 0);
+            const int groups = rc.D + (rc.Bp > 0 ? 1 : 0);
             const int rowx = row < n32 ? row : n32 - 1;
             for (int g = G0; g < groups; ++g) {  // wider stencils: further groups of four codes
-                const unsigned cw = load_group(q.tp, q.D, q.Bp, g);
-                const int cap = 4 * q.D + q.Bp;
+                const unsigned cw = load_group(rc.tp, rc.D, rc.Bp, g);
+                const int cap = 4 * rc.D + rc.Bp;
                 T xw[4], vw[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
                     const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
                     xw[k] = *(const T *)(xb + bo);
                     vw[k] = (T)0;
-                    if (VALS && 4 * g + k < cap) vw[k] = hipk_ld_nt(q.vp + (size_t)(4 * g + k) * HIPK_TILE);
+                    if (VALS && 4 * g + k < cap) vw[k] = hipk_ld_nt(rc.vp + (size_t)(4 * g + k) * HIPK_TILE);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -586,15 +597,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         double d0 = 0.0, d1 = 0.0;
         if (row < n32) {
             T out = s;
-            if (mode & HIPK_SPMV_RESID) out = q.b - out;
-            if (mode & HIPK_SPMV_SCALE) out = q.d * out;
+            if (mode & HIPK_SPMV_RESID) out = rc.b - out;
+            if (mode & HIPK_SPMV_SCALE) out = rc.d * out;
             y[row] = out;
-            if (mode & HIPK_SPMV_DOT_W) d0 = (double)q.w * (double)out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)rc.w * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
         // fused dots: per-wavefront sums (shuffle tree 32..1) -> LDS (CHUNKED) or the tile-partial scratch
-        const int slot = CHUNKED ? (tl - t_first) * 4 + wave : 0;
-        const size_t tpi = (size_t)tl * 4 + wave;
+        const int slot = CHUNKED ? (tc - t_first) * 4 + wave : 0;
+        const size_t tpi = (size_t)tc * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
@@ -609,44 +620,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
                 if (CHUNKED) wsum1[slot] = d1; else a.tpart1[tpi] = d1;
             }
         }
-    };
-
-    req_t rc, rn;
-    T xc[NE];
-    int tc = first_tile();
-    if (tc < ntiles) request(tc, rc);
-    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
-    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
-    doff[t] = dofs;
-    __syncthreads();
-
-    if (DEPTH == 2) {
-        while (tc < ntiles) {
-            gather(rc, tc, xc);
-            const int tn = next_tile();
-            if (tn < ntiles) request(tn, rn);
-            finish(rc, tc, xc);
-            rc = rn;
-            tc = tn;
-        }
-    } else {
-        req_t rnn;
-        T xn[NE];
-        int tn = (tc < ntiles) ? next_tile() : ntiles;
-        if (tn < ntiles) request(tn, rn);
-        if (tc < ntiles) gather(rc, tc, xc);
-        while (tc < ntiles) {
-            const int tnn = (tn < ntiles) ? next_tile() : ntiles;
-            if (tnn < ntiles) request(tnn, rnn);
-            if (tn < ntiles) gather(rn, tn, xn);
-            finish(rc, tc, xc);
-            rc = rn;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) xc[k] = xn[k];
-            rn = rnn;
-            tc = tn;
-            tn = tnn;
-        }
+        rc = rn;
+        tc = tn;
     }
     if (CHUNKED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();

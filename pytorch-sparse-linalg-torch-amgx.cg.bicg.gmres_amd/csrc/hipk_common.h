@@ -102,7 +102,6 @@ struct hipk_csr_s {
     int64_t sell_bytes;     // bytes of all tiles
     int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)
     int n_cu;               // compute units of the device
-    int sell_depth;         // pipeline depth of the persistent coded kernel: 0 by size, 2 or 3 forced
     int sell_chunked;       // 1: the persistent kernel may take one reduction chunk per workgroup (no combine launch)
 };
 
