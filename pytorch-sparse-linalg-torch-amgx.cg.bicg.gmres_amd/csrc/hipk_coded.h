@@ -1,21 +1,21 @@
-// hipk_coded.h -- "coded" CSR SpMV: one byte per entry for matrices with few distinct (col - row, value) pairs.
+// hipk_coded.h -- "coded" SpMV forms: one byte per entry for matrices that repeat few (col - row, value) pairs or few
+// column offsets.
 //
 // Finite-difference / finite-volume matrices on structured grids -- what the reference's own builders produce
 // (utils/matrix_utils.py:193-257 Poisson, examples ldc_solver_common.py:90-135 pressure matrix) -- repeat a handful
 // of (column offset, coefficient) pairs millions of times.  hipk_csr_create builds, on the device, a dictionary of
-// the distinct pairs; when there are at most 256 and no row has more than 32 entries the handle keeps
-//     code[nnz]   uint8   index of entry j's pair in the dictionary
-//     rowlen[n]   uint8   entries of row i
-//     dict_off / dict_val (<= 256 entries)
-// next to the plain CSR arrays, and SpMV streams 1 B per entry + 1 B per row instead of 12 B + 4 B (fp64):
-// 88 MB instead of 320 MB per product at N = 4M.  The arithmetic is the plain kernel's, bit for bit: the
-// dictionary returns the very same value bits and x[row + off] is x[col]; row sums are formed from rounded
-// products in CSR order (rows have <= 32 entries, the spec's short-row rule), so the oracle needs no counterpart.
-//
-// Kernel: one workgroup per R consecutive 256-row tiles, thread t owning rows t, t+256, ..  Per tile the code bytes
-// are copied to LDS with 16-byte loads while the row lengths are scanned (wave shuffles + 4 wave totals), one
-// barrier, then each thread walks its rows: lanes of a wavefront hold consecutive rows, so every x gather of a
-// stencil is a coalesced 512-byte read.
+// the distinct pairs (hash table in global memory, a workgroup-local LDS memo in front of it); when there are few
+// enough and no row has more than 32 entries the handle keeps, next to the plain CSR arrays, one of three layouts
+// (hipk_csr_s::coded_layout):
+//   2  sliced-ELL planes of pair codes (<= 255 pairs): per 256-row tile, entries 4g..4g+3 of all rows as a plane of
+//      dwords, the remaining one or two entries as byte planes; persistent kernel hipk_spmv_sell_loop_kernel.
+//      SpMV streams 1 B per entry instead of 12 B + row pointers: 84 MB instead of 320 MB per product at N = 4M.
+//   3  the same planes holding OFFSET codes only, plus value planes (variable-coefficient stencils): 9 B per entry.
+//   1  pair codes in CSR order + byte row lengths (ragged matrices whose planes would be mostly padding, or exactly
+//      256 pairs): hipk_spmv_coded_kernel, codes staged through LDS, row starts from a scan of the lengths.
+// The arithmetic is the plain kernels', bit for bit: the dictionary returns the very same value bits and x[row + off]
+// is x[col]; row sums are formed from rounded products in CSR order (rows have <= 32 entries, the spec's short-row
+// rule), so the oracle needs no counterpart and every parity test runs on all paths.
 #pragma once
 #include "hipk_spmv.h"
 
