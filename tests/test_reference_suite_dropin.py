@@ -1,0 +1,37 @@
+"""Drop-in check (build container only): the REFERENCE's own test files, run unmodified against THIS package.
+
+The reference keeps its tests inside its package (src/pytorch_sparse_solver/tests/*.py); they import
+`pytorch_sparse_solver` by name.  Here this repository's package is imported first, so those imports resolve to it
+(asserted), and the reference's test functions exercise its solvers through the same call surface a user of the
+reference has.  Skipped where /root/reference does not exist (the GPU box); nothing is written into the reference
+tree (no bytecode, no pytest cache)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF_TESTS = "/root/reference/src/pytorch_sparse_solver/tests"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd")
+
+DRIVER = r'''
+import sys
+sys.dont_write_bytecode = True
+import pytorch_sparse_solver, pytorch_sparse_solver.module_a, pytorch_sparse_solver.solver, pytorch_sparse_solver.utils
+assert pytorch_sparse_solver.__file__.startswith(sys.argv[1]), pytorch_sparse_solver.__file__
+import pytest
+rc = pytest.main(["-p", "no:cacheprovider", "-q", "--rootdir=/tmp", "--import-mode=importlib", "-c", "/dev/null", sys.argv[2]])
+assert sys.modules["pytorch_sparse_solver"].__file__.startswith(sys.argv[1])
+sys.exit(int(rc))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", ["test_module_a.py", "test_unified.py", "test_gpu_validation.py"])
+def test_reference_test_file_passes_against_this_package(name):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, "-c", DRIVER, PKG, os.path.join(REF_TESTS, name)], cwd="/tmp", env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " passed" in r.stdout
