@@ -19,8 +19,11 @@ from .utils.matrix_utils import (
     compute_residual, compute_relative_residual,
 )
 
+__author__ = 'pytorch_sparse_solver for MI355X contributors'
+__license__ = 'Apache-2.0'
+
 __all__ = [
-    '__version__',
+    '__version__', '__author__', '__license__',
     'SparseSolver', 'SolverResult', 'SolverMethod', 'SolverBackend',
     'solve', 'cg', 'bicgstab', 'gmres', 'amg', 'direct_solve',
     'check_module_a_available', 'check_module_b_available', 'check_module_c_available',
