@@ -201,3 +201,30 @@ def test_preconditioned_entry_points_validate_their_arguments():
         assert fn(*args(wb=16)) < 0 and b"work too small" in L.hipk_last_error()
         assert fn(*args(x=b.data_ptr())) < 0                      # b and x alias
         assert fn(*args(d=d.data_ptr() + 8)) < 0                  # misaligned dinv
+
+
+@pytest.mark.gpu
+def test_handle_create_destroy_does_not_leak_device_memory():
+    """All three handle flavours (plain, pair-coded, offset-coded) release what they allocate."""
+    import gc
+    import torch
+    from pytorch_sparse_solver import _hipk
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr, create_variable_diffusion_2d_csr
+    mats = [create_poisson_2d_csr(700, 700, device="cuda:0"), create_variable_diffusion_2d_csr(700, 700, device="cuda:0")]
+    x = torch.ones(490_000, dtype=torch.float64, device="cuda:0")
+
+    def cycle(n):
+        for k in range(n):
+            A = mats[k % 2]
+            h = _hipk.CsrHandle(A.crow_indices(), A.col_indices(), A.values(), A.shape)
+            _hipk.spmv(h, x)
+            h.close()
+    cycle(4)
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(60)
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
