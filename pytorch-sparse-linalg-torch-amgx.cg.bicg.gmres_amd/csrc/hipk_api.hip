@@ -479,7 +479,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 hipk_rowdot_kernel<double><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
             else
                 hipk_rowdot_kernel<float><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
-            hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
+            if (!a.skip_combine) hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                 (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
                 a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
         }
@@ -532,7 +532,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);
-            if (!chunked && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
+            if (!chunked && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
                 hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                     (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
                     a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
@@ -548,7 +548,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             HIPK_LAUNCH_CODED(float, 1);
 #undef HIPK_LAUNCH_CODED
         if (prof) prof->after(stream);
-        if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+        if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
             hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                 (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
                 a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
@@ -571,7 +571,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             hipk_spmv_kernel<float, 2048, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
     }
     if (prof) prof->after(stream);
-    if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+    if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
             (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
             a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);

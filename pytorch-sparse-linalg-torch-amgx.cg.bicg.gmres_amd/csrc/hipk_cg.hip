@@ -14,6 +14,7 @@
 // iterations and the kernels of iterations >= stop_it return immediately, so the
 // solve stops at exactly the iteration the reference stops at.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -63,16 +64,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
 // partial sums and the fold's barriers.  Both kernels therefore request the first HIPK_BASE_CHUNK elements of
 // two operands BEFORE reading the stop word and folding the partials (hipk_pre, hipk_blas1.h; no store happens
 // until the stop test has passed).  Order of operations per element is unchanged.
-template <typename T>
+// SMALL (systems of <= 8 reduction chunks, launch-bound): <p,Ap> is folded here from the SpMV's per-wavefront tile
+// sums (hipk_fold_tiles8: part_pAp then points at them, `ntiles` tiles), the combine launch is skipped.
+template <typename T, bool SMALL = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
-    const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr) {
+    const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr,
+    int ntiles = 0) {
     const int c = blockIdx.x;
     hipk_pre<T, 2> pre;
     pre.issue(n, ch, c, {Ap, (const T *)r});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[HIPK_THREADS];
-    const double pAp = hipk_reduce_parts(part_pAp, g, sbuf);
+    const double pAp = SMALL ? hipk_fold_tiles8(part_pAp, ntiles, ch / HIPK_TILE, g, sbuf)
+                             : hipk_reduce_parts(part_pAp, g, sbuf);
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846
     double acc = 0.0;
@@ -91,11 +96,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     if (threadIdx.x == 0) part_rr[c] = acc;
 }
 
-template <typename T>
+template <typename T, bool SMALL = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
-    T *__restrict__ p, T *__restrict__ x) {
+    T *__restrict__ p, T *__restrict__ x, int ntiles = 0) {
     const int c = blockIdx.x;
     // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
     // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
@@ -104,7 +109,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double pAp, rr;
-    hipk_reduce_parts2(part_pAp, part_rr, g, pAp, rr, sbuf);
+    if (SMALL) {
+        pAp = hipk_fold_tiles8(part_pAp, ntiles, ch / HIPK_TILE, g, sbuf);
+        rr = hipk_reduce_parts(part_rr, g, sbuf);
+    } else {
+        hipk_reduce_parts2(part_pAp, part_rr, g, pAp, rr, sbuf);
+    }
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
@@ -211,6 +221,10 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     sa.part0 = part_a;
     sa.part1 = part_c;
     sa.stop_it = &scal->stop_it;
+    // launch-bound systems (<= 8 reduction chunks): no combine launch, the vector kernels fold the SpMV's tile sums
+    const bool small = gm.g <= 8 && !getenv("HIPK_CG_NO_SMALL");
+    const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    sa.skip_combine = small ? 1 : 0;
 
     hipk_poller poll(A->host_poll);
     HIPK_CHECK_HIP(poll.create());
@@ -225,11 +239,19 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             // params.profile selects which kernel the event pairs bracket: 1 SpMV, 2 update, 3 direction
             if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
             if (prm->profile == 2) prof.before(stream);
-            hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
+            if (small)
+                hipk_cg_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, A->tile_part, Ap, r,
+                                                                                  part_b, ntiles);
+            else
+                hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
             if (prm->profile == 2) prof.after(stream);
             if (prm->profile == 3) prof.before(stream);
-            hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
-                                                                            part_b, r, p, x);
+            if (small)
+                hipk_cg_direction_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter,
+                                                                                     A->tile_part, part_b, r, p, x, ntiles);
+            else
+                hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
+                                                                                part_b, r, p, x);
             if (prm->profile == 3) prof.after(stream);
         }
         HIPK_CHECK_HIP(hipGetLastError());
@@ -248,6 +270,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     sa.part0 = part_c;
     sa.part1 = part_b;
     sa.stop_it = nullptr;
+    sa.skip_combine = 0;
     if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
     ++matvecs;
     if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_a, stream)) != HIPK_OK) return rc;

@@ -61,6 +61,8 @@ struct hipk_spmv_args {
     int sell_w;           //   > 0: every tile has this size
     const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
+    int skip_combine;       // small systems: leave the fused dots as per-wavefront tile sums (hipk_csr_s::tile_part); the
+                            //   consumer folds them itself (hipk_fold_tiles8) -- one launch less per SpMV
 };
 
 #ifdef __HIPCC__
@@ -383,6 +385,30 @@ __device__ __forceinline__ double hipk_wave_fold(const double *__restrict__ tp, 
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_down(v, s);
     return v;  // valid in lane 0
+}
+
+// Small systems (g <= 8 reduction chunks): the value of a fused dot, folded by the CONSUMER workgroup from the
+// per-wavefront tile sums -- the combine kernel's chunk fold (one wavefront per chunk, two rounds for eight chunks) followed
+// by the spec's fold of g <= 8 chunk partials (acc = 0.0 + part, then the tree's s = 4, 2, 1 steps): the bits a combine
+// launch + hipk_reduce_parts would give.  All 256 threads must call it; cp: 8 doubles of LDS.
+__device__ __forceinline__ double hipk_fold_tiles8(const double *__restrict__ tp, int ntiles, int tpc, int g, double *cp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < 8; c += HIPK_THREADS / 64) {
+        double r = 0.0;
+        if (c < g) {
+            const int first = c * tpc;
+            const int cnt = (ntiles - first < tpc) ? ntiles - first : tpc;
+            r = hipk_wave_fold(tp + (size_t)first * 4, cnt, lane);
+        }
+        if (lane == 0) cp[c] = r;
+    }
+    __syncthreads();
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.0 + ((i < g) ? cp[i] : 0.0);
+    const double v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+    __syncthreads();
+    return v;
 }
 
 static __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_combine_kernel(const double *__restrict__ tp0,

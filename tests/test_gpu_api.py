@@ -228,3 +228,29 @@ def test_handle_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+@pytest.mark.gpu
+def test_cg_small_system_path_without_combine_launch_is_bit_identical(monkeypatch):
+    """Systems of <= 8 reduction chunks: the CG vector kernels fold the SpMV's tile sums themselves (3 instead of 4
+    launches per iteration) -- same bits as the general launch sequence, on the coded, tile and row-per-wavefront paths."""
+    import torch
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr, create_variable_diffusion_2d_csr
+    g = torch.Generator().manual_seed(0)
+    G = torch.randn(300, 300, dtype=torch.float64, generator=g)
+    dense = (G @ G.T + 300 * torch.eye(300, dtype=torch.float64)).to("cuda:0")      # dense-as-CSR: row per wavefront
+    for A in (create_poisson_2d_csr(100, 100, device="cuda:0"), create_variable_diffusion_2d_csr(90, 70, device="cuda:0"),
+              create_poisson_2d_csr(3, 3, device="cuda:0"), dense):
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(n))
+        out = {}
+        for flag in ("0", "1"):
+            if flag == "1":
+                monkeypatch.setenv("HIPK_CG_NO_SMALL", "1")
+            else:
+                monkeypatch.delenv("HIPK_CG_NO_SMALL", raising=False)
+            x, info = cg(A, b, tol=1e-10)
+            st = get_last_stats()
+            out[flag] = (x.clone(), info, st.iterations, st.residual_norm, st.recurrence_rs)
+        assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:] and out["0"][1] == 0
