@@ -14,6 +14,7 @@
 // = 2 B_spmv + 120 n bytes per iteration.  The full-vector `torch.where` selects of the
 // reference (TSL:944, 950) become a wave-uniform branch.
 #include <math.h>
+#include <stdlib.h>
 
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
@@ -134,13 +135,18 @@ template <typename T, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
     const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
-    double *__restrict__ part_ss, const T *__restrict__ dinv, T *__restrict__ shat) {
+    double *__restrict__ part_ss, const T *__restrict__ dinv, T *__restrict__ shat, int small_ntiles) {
     hipk_pre<T, 2> pre;
     pre.issue(n, ch, blockIdx.x, {r, q});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rho_new, rq;
-    hipk_reduce_parts2(part_rhr, part_rq, g, rho_new, rq, sbuf);
+    if (small_ntiles > 0) {  // small systems: <rhat,q> from the SpMV's tile sums, no combine launch (hipk_fold_tiles8)
+        rq = hipk_fold_tiles8(part_rq, small_ntiles, ch / HIPK_TILE, g, sbuf);
+        rho_new = hipk_reduce_parts(part_rhr, g, sbuf);
+    } else {
+        hipk_reduce_parts2(part_rhr, part_rq, g, rho_new, rq, sbuf);
+    }
     const double alpha_new = rho_new / rq;  // TSL:910
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (fabs(alpha_new) < hipk_eps<T>::v) {  // TSL:913-915
@@ -185,14 +191,19 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
     const T *__restrict__ p, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ rhat,
     T *__restrict__ x, T *__restrict__ r, double *__restrict__ part_rr, double *__restrict__ part_rhr,
-    const T *__restrict__ shat) {  // PRE: `p` is phat here; shat = M s
+    const T *__restrict__ shat, int small_ntiles) {  // PRE: `p` is phat here; shat = M s
     hipk_pre<T, 1> pre;  // s up front; p, x, rhat, t follow after the fold (two early operands already cost the
     pre.issue(n, ch, blockIdx.x, {s});  // kernel its 8 workgroups per CU: 71 VGPRs)
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     const double ss = hipk_reduce_parts(part_ss, g, sbuf);
     double ts, tt;
-    hipk_reduce_parts2(part_ts, part_tt, g, ts, tt, sbuf);
+    if (small_ntiles > 0) {  // part_ts / part_tt point at the two tile-sum arrays of the second SpMV
+        ts = hipk_fold_tiles8(part_ts, small_ntiles, ch / HIPK_TILE, g, sbuf);
+        tt = hipk_fold_tiles8(part_tt, small_ntiles, ch / HIPK_TILE, g, sbuf);
+    } else {
+        hipk_reduce_parts2(part_ts, part_tt, g, ts, tt, sbuf);
+    }
     const double atol2 = scal->atol2;
     const double alpha_new = scal->alpha_new, rho_new = scal->rho_new;
     const bool exit_early = ss < atol2;                                      // TSL:920 (strict)
@@ -351,6 +362,12 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     stt.part1 = part_tt;
     stt.stop_it = &scal->stop_it;
 
+    // launch-bound systems (<= 8 reduction chunks): both SpMVs skip their combine launch, the consumers fold the tile sums
+    const bool small = gm.g <= 8 && !getenv("HIPK_BICGSTAB_NO_SMALL");
+    const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    const double *tsum0 = A->tile_part, *tsum1 = A->tile_part + 4 * (size_t)nt;
+    sq.skip_combine = stt.skip_combine = small ? 1 : 0;
+
     hipk_poller poll(A->host_poll);
     HIPK_CHECK_HIP(poll.create());
     int64_t it = 0, stop = INT64_MAX;
@@ -364,13 +381,14 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                                                                                  part_rhr, r, q, p, dinv, phat);
             sq.it = it;
             if ((rc = hipk_launch_spmv(A, sq, stream, &prof)) != HIPK_OK) return rc;
-            hipk_bi_supdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq,
-                                                                               r, q, s, part_ss, dinv, shat);
+            hipk_bi_supdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr,
+                                                                               small ? tsum0 : part_rq,
+                                                                               r, q, s, part_ss, dinv, shat, small ? nt : 0);
             stt.it = it;
             if ((rc = hipk_launch_spmv(A, stt, stream)) != HIPK_OK) return rc;
-            hipk_bi_xupdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_ss,
-                                                                               part_ts, part_tt, phat, s, t, rhat, x, r,
-                                                                               part_rr, part_rhr, shat);
+            hipk_bi_xupdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                n, gm.ch, gm.g, scal, it, maxiter, part_ss, small ? tsum0 : part_ts, small ? tsum1 : part_tt, phat, s, t, rhat,
+                x, r, part_rr, part_rhr, shat, small ? nt : 0);
         }
         HIPK_CHECK_HIP(hipGetLastError());
         HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));

@@ -267,11 +267,16 @@ __device__ __forceinline__ void hipk_givens(double a, double b, double &cs, doub
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     int64_t n, int ch, int g, hipk_gm_scal *__restrict__ scal, int k, T *__restrict__ w,
-    const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps) {
+    const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps, int small_ntiles) {
     if (k >= scal->stop_step) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double qq, ww;
-    hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
+    if (small_ntiles > 0) {  // small systems: ||A v||^2 straight from the SpMV's tile sums (no combine launch)
+        ww = hipk_fold_tiles8(part_ww, small_ntiles, ch / HIPK_TILE, g, sbuf);
+        qq = hipk_reduce_parts(part_qq, g, sbuf);
+    } else {
+        hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
+    }
     double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
     double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
     if (!(norm0 > eps)) norm0 = 0.0;
@@ -620,6 +625,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             hipk_spmv_args sw = sa;
             sw.x = V + (int64_t)k * ldv;
             sw.y = w;
+            sw.skip_combine = small ? 1 : 0;  // small systems: hipk_gm_normalize_kernel folds the tile sums itself
             sw.mode = HIPK_SPMV_DOT_YY | scale_bit;  // w = M(A v_k), ||w||^2 of the scaled vector (TSL:351-352)
             sw.part0 = part_spare;
             sw.part1 = part_ww;
@@ -642,8 +648,9 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                                                                                        part_qq, part_md, gm.g);
                 }
             }
-            hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, k, w, part_qq,
-                                                                            part_ww, eps_t);
+            const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+            hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                n, gm.ch, gm.g, scal, k, w, part_qq, small ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t, small ? nt : 0);
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||

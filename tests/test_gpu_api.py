@@ -254,3 +254,26 @@ def test_cg_small_system_path_without_combine_launch_is_bit_identical(monkeypatc
             st = get_last_stats()
             out[flag] = (x.clone(), info, st.iterations, st.residual_norm, st.recurrence_rs)
         assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:] and out["0"][1] == 0
+
+
+@pytest.mark.gpu
+def test_bicgstab_small_system_path_without_combine_launches_is_bit_identical(monkeypatch):
+    import torch
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_ldc_pressure_csr
+    for A, M in ((create_convdiff_2d_csr(100, 100, device="cuda:0"), False), (create_ldc_pressure_csr(64, device="cuda:0"), False),
+                 (create_convdiff_2d_csr(60, 90, device="cuda:0"), True)):
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(n))
+        b -= b.mean()
+        kw = dict(M=JacobiPreconditioner(A)) if M else {}
+        out = {}
+        for flag in ("0", "1"):
+            if flag == "1":
+                monkeypatch.setenv("HIPK_BICGSTAB_NO_SMALL", "1")
+            else:
+                monkeypatch.delenv("HIPK_BICGSTAB_NO_SMALL", raising=False)
+            x, info = bicgstab(A, b, tol=1e-9, maxiter=400, **kw)
+            st = get_last_stats()
+            out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.breakdown)
+        assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:]
