@@ -131,7 +131,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     });
 }
 
-template <typename T, bool PRE>
+template <typename T, bool PRE, bool SMALL>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, const double *__restrict__ part_rhr,
     const double *__restrict__ part_rq, const T *__restrict__ r, const T *__restrict__ q, T *__restrict__ s,
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rho_new, rq;
-    if (small_ntiles > 0) {  // small systems: <rhat,q> from the SpMV's tile sums, no combine launch (hipk_fold_tiles8)
+    if (SMALL) {  // small systems: <rhat,q> from the SpMV's tile sums, no combine launch (hipk_fold_tiles8); a compile-time
+                  // switch: the fold's registers would cost the large-system instantiation its 8 workgroups per CU
         rq = hipk_fold_tiles8(part_rq, small_ntiles, ch / HIPK_TILE, g, sbuf);
         rho_new = hipk_reduce_parts(part_rhr, g, sbuf);
     } else {
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
     if (threadIdx.x == 0) part_ss[blockIdx.x] = acc;
 }
 
-template <typename T, bool PRE>
+template <typename T, bool PRE, bool SMALL>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_ss, const double *__restrict__ part_ts, const double *__restrict__ part_tt,
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     __shared__ double sbuf[2 * HIPK_THREADS];
     const double ss = hipk_reduce_parts(part_ss, g, sbuf);
     double ts, tt;
-    if (small_ntiles > 0) {  // part_ts / part_tt point at the two tile-sum arrays of the second SpMV
+    if (SMALL) {  // part_ts / part_tt point at the two tile-sum arrays of the second SpMV
         ts = hipk_fold_tiles8(part_ts, small_ntiles, ch / HIPK_TILE, g, sbuf);
         tt = hipk_fold_tiles8(part_tt, small_ntiles, ch / HIPK_TILE, g, sbuf);
     } else {
@@ -381,14 +382,20 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                                                                                  part_rhr, r, q, p, dinv, phat);
             sq.it = it;
             if ((rc = hipk_launch_spmv(A, sq, stream, &prof)) != HIPK_OK) return rc;
-            hipk_bi_supdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr,
-                                                                               small ? tsum0 : part_rq,
-                                                                               r, q, s, part_ss, dinv, shat, small ? nt : 0);
+            if (small)
+                hipk_bi_supdate_kernel<T, PRE, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, tsum0, r,
+                                                                                        q, s, part_ss, dinv, shat, nt);
+            else
+                hipk_bi_supdate_kernel<T, PRE, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq,
+                                                                                         r, q, s, part_ss, dinv, shat, 0);
             stt.it = it;
             if ((rc = hipk_launch_spmv(A, stt, stream)) != HIPK_OK) return rc;
-            hipk_bi_xupdate_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(
-                n, gm.ch, gm.g, scal, it, maxiter, part_ss, small ? tsum0 : part_ts, small ? tsum1 : part_tt, phat, s, t, rhat,
-                x, r, part_rr, part_rhr, shat, small ? nt : 0);
+            if (small)
+                hipk_bi_xupdate_kernel<T, PRE, true><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                    n, gm.ch, gm.g, scal, it, maxiter, part_ss, tsum0, tsum1, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, nt);
+            else
+                hipk_bi_xupdate_kernel<T, PRE, false><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                    n, gm.ch, gm.g, scal, it, maxiter, part_ss, part_ts, part_tt, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, 0);
         }
         HIPK_CHECK_HIP(hipGetLastError());
         HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
