@@ -33,6 +33,7 @@ struct hipk_bi_scal {
     int64_t iters;
     int32_t code;      // 0 / -10 / -11  (TSL:903, 914, 935)
     int32_t extra_mv;  // SpMVs run by an iteration that then broke down
+    int64_t *host_sig; // pinned host word the loop reports to (hipk_pacer, hipk_solve.h), or null
 };
 
 template <typename T>
@@ -50,7 +51,7 @@ template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, const double *__restrict__ part_rr,
     const double *__restrict__ part_bb, double *__restrict__ part_rhr, const T *__restrict__ r, T *__restrict__ rhat,
-    T *__restrict__ p, T *__restrict__ q, double tol2, double atol_sq, int64_t maxiter) {
+    T *__restrict__ p, T *__restrict__ q, double tol2, double atol_sq, int64_t maxiter, int64_t *host_sig) {
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rr, bs;
     hipk_reduce_parts2(part_rr, part_bb, g, rr, bs, sbuf);
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
             scal->bs = bs;
             scal->rs_last = 0.0;
             scal->stop_it = (maxiter <= 0) ? 0 : INT64_MAX;
+            scal->host_sig = host_sig;
+            if (maxiter <= 0) hipk_signal(host_sig, HIPK_SIG_STOP);
             scal->iters = 0;
             scal->code = 0;
             scal->extra_mv = 0;
@@ -97,13 +100,17 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_direction_kernel(
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (lead) scal->rs_last = rs;
     if (rs <= scal->atol2) {  // TSL:894-896
-        if (lead) scal->stop_it = it;
+        if (lead) {
+            scal->stop_it = it;
+            hipk_signal(scal->host_sig, HIPK_SIG_STOP | it);
+        }
         return;
     }
     if (fabs(rho_new) < hipk_eps<T>::v * fabs(rho)) {  // TSL:902-904
         if (lead) {
             scal->stop_it = it;
             scal->code = -10;
+            hipk_signal(scal->host_sig, HIPK_SIG_STOP | it);
         }
         return;
     }
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_supdate_kernel(
             scal->stop_it = it;
             scal->code = -11;
             scal->extra_mv = 1;
+            hipk_signal(scal->host_sig, HIPK_SIG_STOP | it);
         }
         return;
     }
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
             scal->stop_it = it;
             scal->code = -11;
             scal->extra_mv = 2;
+            hipk_signal(scal->host_sig, HIPK_SIG_STOP | it);
         }
         return;
     }
@@ -267,7 +276,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
         scal->alpha = alpha_new;
         scal->omega = omega_new;
         scal->iters = it + 1;
-        if (exit_early || it + 1 >= maxiter) scal->stop_it = it + 1;  // TSL:961, loop bound :892
+        const bool done = (exit_early || it + 1 >= maxiter);  // TSL:961, loop bound :892
+        if (done) scal->stop_it = it + 1;
+        hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
     }
 }
 
@@ -341,8 +352,10 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     sa.part1 = part_rr;
     if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
     if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
+    hipk_pacer pace(A->host_poll, &scal->stop_it, check);
+    HIPK_CHECK_HIP(pace.create());
     hipk_bi_start_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, part_rr, part_bb, part_rhr, r,
-                                                                rhat, p, q, tol2, atol_sq, maxiter);
+                                                                rhat, p, q, tol2, atol_sq, maxiter, pace.device_sig());
     HIPK_CHECK_HIP(hipGetLastError());
 
     hipk_spmv_args sq = sa, stt = sa;
@@ -369,15 +382,11 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     const double *tsum0 = A->tile_part, *tsum1 = A->tile_part + 4 * (size_t)nt;
     sq.skip_combine = stt.skip_combine = small ? 1 : 0;
 
-    hipk_poller poll(A->host_poll);
-    HIPK_CHECK_HIP(poll.create());
     int64_t it = 0, stop = INT64_MAX;
-    HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
-    while (it < maxiter) {
-        HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
+    for (; it < maxiter; ++it) {
+        HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
-        const int64_t end = (it + check < maxiter) ? it + check : maxiter;
-        for (; it < end; ++it) {
+        {
             hipk_bi_direction_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr,
                                                                                  part_rhr, r, q, p, dinv, phat);
             sq.it = it;
@@ -397,10 +406,9 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                 hipk_bi_xupdate_kernel<T, PRE, false><<<gm.g, HIPK_THREADS, 0, stream>>>(
                     n, gm.ch, gm.g, scal, it, maxiter, part_ss, part_ts, part_tt, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, 0);
         }
-        HIPK_CHECK_HIP(hipGetLastError());
-        HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+        if ((it & 31) == 31) HIPK_CHECK_HIP(hipGetLastError());
     }
-    HIPK_CHECK_HIP(poll.drain(&stop));
+    HIPK_CHECK_HIP(hipGetLastError());
 
     // TSL:1007-1014 (PRE: ||M (b - A x)||, the row scaling runs in the SpMV epilogue)
     sa.x = x;

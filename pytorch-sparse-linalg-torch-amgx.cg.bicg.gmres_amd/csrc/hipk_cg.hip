@@ -29,7 +29,7 @@ struct hipk_cg_scal {
     double res2;       // true ||b - A x||^2 after the loop  (TSL:1008)
     double xx;         // <x,x>                               (TSL:1013)
     int64_t stop_it;   // iterations >= stop_it are no-ops
-    int64_t pad;
+    int64_t *host_sig; // pinned host word the direction kernel reports to (hipk_pacer), or null
 };
 
 // gamma0 = <r0,r0>, bs = <b,b>, atol2; p = r0.
@@ -37,7 +37,7 @@ template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, const double *__restrict__ part_rr,
     const double *__restrict__ part_bb, const T *__restrict__ r, T *__restrict__ p, double tol2, double atol_sq,
-    int64_t maxiter) {
+    int64_t maxiter, int64_t *host_sig = nullptr) {
     __shared__ double sbuf[2 * HIPK_THREADS];
     double gamma0, bs;
     hipk_reduce_parts2(part_rr, part_bb, g, gamma0, bs, sbuf);  // g = partial count of ALL ranks
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
         scal->atol2 = atol2;
         scal->bs = bs;
         // TSL:841: `if k >= maxiter or rs <= atol2: break` evaluated before the first SpMV
-        scal->stop_it = (maxiter <= 0 || gamma0 <= atol2) ? 0 : INT64_MAX;
+        const bool done = (maxiter <= 0 || gamma0 <= atol2);
+        scal->stop_it = done ? 0 : INT64_MAX;
+        scal->host_sig = host_sig;
+        if (done) hipk_signal(host_sig, HIPK_SIG_STOP);
     }
 }
 
@@ -136,7 +139,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
         scal->gamma[(it + 1) & 1] = rr;  // TSL:853
         // TSL:841 for the NEXT pass: stop when k+1 >= maxiter or rs <= atol2.
         // Workgroups of THIS launch compare against `it`, so they are unaffected.
-        if (it + 1 >= maxiter || rr <= scal->atol2) scal->stop_it = it + 1;
+        const bool done = (it + 1 >= maxiter || rr <= scal->atol2);
+        if (done) scal->stop_it = it + 1;
+        hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
     }
 }
 
@@ -207,12 +212,14 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
     ++matvecs;
     if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_a, stream)) != HIPK_OK) return rc;
+    hipk_pacer pace(A->host_poll, &scal->stop_it, check);
+    HIPK_CHECK_HIP(pace.create());
     hipk_cg_start_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, part_b, part_a, r, p, tol2,
-                                                                atol_sq, maxiter);
+                                                                atol_sq, maxiter, pace.device_sig());
     HIPK_CHECK_HIP(hipGetLastError());
 
-    // ---- iteration loop: enqueue `check` iterations, then an async read of stop_it;
-    // two batches stay in flight so the GPU never waits for the host.
+    // ---- iteration loop: the host enqueues iterations a few ahead of the GPU and stops when the direction kernel
+    // reports the stop (hipk_pacer, hipk_solve.h); launches past the stop are no-ops on the device.
     sa.x = p;
     sa.y = Ap;
     sa.mode = HIPK_SPMV_DOT_W;
@@ -226,15 +233,11 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     sa.skip_combine = small ? 1 : 0;
 
-    hipk_poller poll(A->host_poll);
-    HIPK_CHECK_HIP(poll.create());
     int64_t it = 0, stop = INT64_MAX;
-    HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
-    while (it < maxiter) {
-        HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
+    for (; it < maxiter; ++it) {
+        HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
-        const int64_t end = (it + check < maxiter) ? it + check : maxiter;
-        for (; it < end; ++it) {
+        {
             sa.it = it;
             // params.profile selects which kernel the event pairs bracket: 1 SpMV, 2 update, 3 direction
             if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
@@ -254,12 +257,9 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                                                                                 part_b, r, p, x);
             if (prm->profile == 3) prof.after(stream);
         }
-        HIPK_CHECK_HIP(hipGetLastError());
-        HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+        if ((it & 63) == 63) HIPK_CHECK_HIP(hipGetLastError());
     }
-    HIPK_CHECK_HIP(poll.drain(&stop));
-    const int64_t iterations = (stop < it) ? stop : it;
-    matvecs += iterations;
+    HIPK_CHECK_HIP(hipGetLastError());
 
     // ---- TSL:1007-1014: true residual, ||x||
     sa.x = x;
@@ -284,6 +284,8 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
 
+    const int64_t iterations = (hs.stop_it < it) ? hs.stop_it : it;  // the device's stop word is authoritative
+    matvecs += iterations;
     hipk_finish_isolve_stats(st, prm, hs.bs, hs.res2, hs.xx, iterations, matvecs);
     st->recurrence_rs = hs.gamma[iterations & 1];
     st->breakdown = 0;
@@ -396,14 +398,15 @@ extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, voi
 struct hipk_pcg_scal {
     double atol2, bs, res2, xx, rs_last;
     int64_t stop_it;
-    int64_t pad[2];
+    int64_t *host_sig;  // as in hipk_cg_scal
+    int64_t pad;
 };
 
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_pcg_start_kernel(
     int64_t n, int ch, int g, hipk_pcg_scal *__restrict__ scal, const double *__restrict__ part_rr,
     const double *__restrict__ part_bb, const T *__restrict__ r, const T *__restrict__ dinv, T *__restrict__ p,
-    double *__restrict__ part_rz, double tol2, double atol_sq, int64_t maxiter) {
+    double *__restrict__ part_rz, double tol2, double atol_sq, int64_t maxiter, int64_t *host_sig) {
     __shared__ double sbuf[2 * HIPK_THREADS];
     double rr0, bs;
     hipk_reduce_parts2(part_rr, part_bb, g, rr0, bs, sbuf);
@@ -429,7 +432,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_pcg_start_kernel(
         scal->atol2 = atol2;
         scal->bs = bs;
         scal->rs_last = rr0;
-        scal->stop_it = (maxiter <= 0 || rr0 <= atol2) ? 0 : INT64_MAX;  // TSL:841 before the first SpMV
+        const bool done = (maxiter <= 0 || rr0 <= atol2);  // TSL:841 before the first SpMV
+        scal->stop_it = done ? 0 : INT64_MAX;
+        scal->host_sig = host_sig;
+        if (done) hipk_signal(host_sig, HIPK_SIG_STOP);
     }
 }
 
@@ -505,7 +511,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_pcg_direction_kernel(
     });
     if (c == 0 && threadIdx.x == 0) {
         scal->rs_last = rr;
-        if (it + 1 >= maxiter || rr <= scal->atol2) scal->stop_it = it + 1;  // TSL:841 for the next pass
+        const bool done = (it + 1 >= maxiter || rr <= scal->atol2);  // TSL:841 for the next pass
+        if (done) scal->stop_it = it + 1;
+        hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
     }
 }
 
@@ -595,8 +603,10 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
     ++matvecs;
     if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_d, stream)) != HIPK_OK) return rc;
+    hipk_pacer pace(A->host_poll, &scal->stop_it, check);
+    HIPK_CHECK_HIP(pace.create());
     hipk_pcg_start_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, part_b, part_d, r, dinv, p, part_z[0],
-                                                                 tol2, atol_sq, maxiter);
+                                                                 tol2, atol_sq, maxiter, pace.device_sig());
     HIPK_CHECK_HIP(hipGetLastError());
 
     sa.x = p;
@@ -608,15 +618,11 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     sa.part1 = part_c;
     sa.stop_it = &scal->stop_it;
 
-    hipk_poller poll(A->host_poll);
-    HIPK_CHECK_HIP(poll.create());
     int64_t it = 0, stop = INT64_MAX;
-    HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
-    while (it < maxiter) {
-        HIPK_CHECK_HIP(poll.wait_oldest_if_full(&stop));
+    for (; it < maxiter; ++it) {
+        HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
-        const int64_t end = (it + check < maxiter) ? it + check : maxiter;
-        for (; it < end; ++it) {
+        {
             sa.it = it;
             if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
             hipk_pcg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, part_z[it & 1], Ap,
@@ -625,12 +631,9 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
                                                                              part_z[it & 1], part_z[(it + 1) & 1], part_b, r,
                                                                              dinv, p, x);
         }
-        HIPK_CHECK_HIP(hipGetLastError());
-        HIPK_CHECK_HIP(poll.post(&scal->stop_it, it, stream));
+        if ((it & 63) == 63) HIPK_CHECK_HIP(hipGetLastError());
     }
-    HIPK_CHECK_HIP(poll.drain(&stop));
-    const int64_t iterations = (stop < it) ? stop : it;
-    matvecs += iterations;
+    HIPK_CHECK_HIP(hipGetLastError());
 
     // TSL:1007-1014 with M: ||M (b - A x)||, ||x||
     sa.x = x;
@@ -652,6 +655,8 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
 
+    const int64_t iterations = (hs.stop_it < it) ? hs.stop_it : it;
+    matvecs += iterations;
     hipk_finish_isolve_stats(st, prm, hs.bs, hs.res2, hs.xx, iterations, matvecs);
     st->recurrence_rs = hs.rs_last;
     st->breakdown = 0;

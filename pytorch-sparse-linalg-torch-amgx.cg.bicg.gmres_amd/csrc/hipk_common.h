@@ -80,7 +80,8 @@ struct hipk_csr_s {
     const void *val;  // device, nnz, borrowed
     hipk_geom geom;   // chunking of the row space
     int device;
-    // pinned host word block used by solves to poll the device stop word
+    // pinned host word block used by solves to follow the device loop: words 0-1 are the poller's read slots,
+    // word 2 is the signal word the loop's deciding kernel stores to (hipk_pacer, hipk_solve.h)
     int64_t *host_poll;  // hipHostMalloc, 16 x int64
     double *tile_part;   // device, 2 x 4 x ceil(n_rows/256): per-wavefront sums of the fused dots (4 per tile)
     int *huge_rows;      // device, owned or null: rows with more entries than the LDS product buffer, handled by a

@@ -1,7 +1,9 @@
 // hipk_solve.h -- host-side helpers shared by the device-resident solve loops.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 
+#include <chrono>
 #include <vector>
 
 #include "hipk_common.h"
@@ -176,6 +178,84 @@ struct hipk_poller {
             hipError_t e = hipEventSynchronize(ev[head]);
             if (e != hipSuccess) return e;
             harvest(stop);
+        }
+        return hipSuccess;
+    }
+};
+
+// ---- pacing of a device-resident loop -------------------------------------------------------------------------
+// The loop's deciding kernel (one thread of it) reports to a word of PINNED HOST memory: the number of completed
+// iterations, or HIPK_SIG_STOP | stop_it once the stop rule has fired (hipk_signal).  The host reads that word
+// before enqueueing an iteration -- a plain load, no stream operation -- and (a) keeps at most `window` iterations
+// queued ahead of the GPU, (b) stops enqueueing as soon as the loop has stopped.  A short solve (15 iterations of a
+// 100-row system) therefore launches 15 + window iterations instead of two polling batches of 64: 1.4 -> 0.4 ms.
+// If the word does not move for 200 ms (another stream hogging the GPU, or a platform on which device stores to
+// pinned memory are not visible before the kernel ends) the pacer falls back to the stream-ordered poller above.
+#define HIPK_SIG_STOP ((int64_t)1 << 62)
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void hipk_signal(int64_t *sig, int64_t v) {
+    if (sig) __hip_atomic_store(sig, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
+struct hipk_pacer {
+    hipk_poller poll;
+    int64_t *sig;             // pinned host word (device-visible at the same address), or null
+    const int64_t *dev_stop;  // device stop word, for the fallback
+    int64_t check, window, next_post = 0;
+    bool live;
+    // pinned: the handle's 16-word block; words 0-1 belong to the poller, word 2 is the signal
+    hipk_pacer(int64_t *pinned, const int64_t *dev_stop_word, int64_t check_every, int64_t win = 8)
+        : poll(pinned), sig(pinned + 2), dev_stop(dev_stop_word), check(check_every), window(win) {
+        const char *e = getenv("HIPK_HOST_SIGNAL");
+        live = !(e && e[0] == '0');
+        if (!live) sig = nullptr;
+        if (const char *w = getenv("HIPK_PACE_WINDOW")) {
+            const long v = atol(w);
+            if (v >= 1 && v <= 4096) window = v;
+        }
+    }
+    hipError_t create() {
+        if (sig) __atomic_store_n(sig, (int64_t)0, __ATOMIC_RELEASE);  // before the start kernel is enqueued
+        return poll.create();
+    }
+    int64_t *device_sig() const { return sig; }
+    // Call before enqueueing iteration `it`; *stop <= it afterwards means: do not enqueue it.
+    hipError_t gate(int64_t it, hipStream_t s, int64_t *stop) {
+        if (live) {
+            int64_t v = __atomic_load_n(sig, __ATOMIC_ACQUIRE);
+            if (!(v & HIPK_SIG_STOP) && v < it - window) {
+                int64_t last = v;
+                auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 1;; ++spins) {
+                    v = __atomic_load_n(sig, __ATOMIC_ACQUIRE);
+                    if ((v & HIPK_SIG_STOP) || v >= it - window) break;
+                    if ((spins & 1023u) == 0) {
+                        const auto now = std::chrono::steady_clock::now();
+                        if (v != last) {
+                            last = v;
+                            t0 = now;
+                        } else if (now - t0 > std::chrono::milliseconds(200)) {
+                            live = false;
+                            next_post = it;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (v & HIPK_SIG_STOP) {
+                const int64_t at = v & ~HIPK_SIG_STOP;
+                if (at < *stop) *stop = at;
+                return hipSuccess;
+            }
+            if (live) return hipSuccess;
+        }
+        if (it >= next_post) {  // stream-ordered polling, two reads in flight
+            hipError_t e = poll.post(dev_stop, it, s);
+            if (e != hipSuccess) return e;
+            next_post = it + check;
+            return poll.wait_oldest_if_full(stop);
         }
         return hipSuccess;
     }

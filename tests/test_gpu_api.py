@@ -277,3 +277,36 @@ def test_bicgstab_small_system_path_without_combine_launches_is_bit_identical(mo
             st = get_last_stats()
             out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.breakdown)
         assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:]
+
+
+@pytest.mark.gpu
+def test_host_signal_pacing_and_stream_polling_agree(monkeypatch):
+    """The loop's deciding kernel reports progress / the stop to a pinned host word (hipk_pacer); with
+    HIPK_HOST_SIGNAL=0 the host follows the loop with stream-ordered reads of the device stop word instead.
+    Same x bits, same counts, for stops at iteration 0, short solves, maxiter cut-offs and long solves."""
+    import torch
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_poisson_2d_csr,
+                                                          create_variable_diffusion_2d_csr)
+    dev = "cuda:0"
+    cases = []
+    for nx, kw in ((10, dict(tol=1e-8)), (10, dict(tol=1e-8, maxiter=3)), (10, dict(tol=1e-8, maxiter=0)),
+                   (10, dict(tol=1.0)), (150, dict(tol=1e-10)), (300, dict(tol=1e-6, maxiter=70))):
+        cases.append((cg, create_poisson_2d_csr(nx, nx, device=dev), kw, None))
+        cases.append((bicgstab, create_convdiff_2d_csr(nx, nx, device=dev), kw, None))
+    Av = create_variable_diffusion_2d_csr(60, 50, device=dev)
+    cases.append((cg, Av, dict(tol=1e-9), "jacobi"))
+    cases.append((bicgstab, Av, dict(tol=1e-9), "jacobi"))
+    for f, A, kw, pre in cases:
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+        if pre:
+            kw = dict(kw, M=JacobiPreconditioner(A))
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HIPK_HOST_SIGNAL", flag)
+            x, info = f(A, b, **kw)
+            st = get_last_stats()
+            out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.recurrence_rs, st.breakdown)
+        assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (f.__name__, n, kw, out["0"][1:], out["1"][1:])
+    monkeypatch.delenv("HIPK_HOST_SIGNAL", raising=False)
