@@ -59,7 +59,7 @@ typedef struct {
     int64_t maxiter;       /* CG/BiCGStab: iterations; GMRES: restart cycles. <0 => 10*n (TSL:982-984)      */
     int32_t restart;       /* GMRES Krylov dimension (TSL:642)                                             */
     int32_t gmres_method;  /* hipk_gmres_method                                                            */
-    int32_t check_every;   /* host polls the device stop word every this many iterations (<=0: default)    */
+    int32_t check_every;   /* stream-ordered polling interval of the fallback pacing (<=0: default), see below */
     int32_t gpu_tolerances;/* 1: GMRES uses the `device.type=='cuda'` tolerance branch (TSL:737-740)       */
     int32_t profile;       /* 1: bracket every SpMV launch with events and report stats.spmv_ms_avg;
                               CG only: 2 = the update kernel, 3 = the direction kernel instead              */
@@ -153,7 +153,10 @@ int hipk_xpby(int64_t n, const void *x, double b, void *y, int dtype, hipk_strea
 /* ---- whole solves (device-resident loops) ------------------------------------
  * x: in = x0, out = solution.  b is not modified.  `work` >= *_work_bytes.
  * The loop stops at exactly the iteration the reference stops at (device-side
- * stop word; the host only polls it every check_every iterations).            */
+ * stop word: launches past it are no-ops).  The host follows the loop through a
+ * pinned word the deciding kernel stores to and keeps a few iterations queued
+ * ahead; HIPK_HOST_SIGNAL=0 (or a word that stops moving) selects stream-ordered
+ * reads of the stop word every check_every iterations instead.                */
 size_t hipk_cg_work_bytes(int64_t n, int dtype);
 /* `_isolve(_cg_solve)`: TSL:806-856 + 968-1016. */
 int hipk_cg_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,

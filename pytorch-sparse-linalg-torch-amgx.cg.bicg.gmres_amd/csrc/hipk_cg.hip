@@ -10,8 +10,8 @@
 // = B_spmv + 64 n bytes per iteration: the x update rides on the pass that already streams p, 8 n bytes
 // less than the 72 n of SURVEY 8d; the arithmetic per element is unchanged.  Every workgroup re-derives alpha/beta from the chunk
 // partials of the previous kernel with the fixed tree, so no grid barrier, no atomics
-// and no host round trip are needed; the host only polls `stop_it` every check_every
-// iterations and the kernels of iterations >= stop_it return immediately, so the
+// and no host round trip are needed; the host follows the loop through a pinned word the direction kernel
+// stores to (hipk_pacer, hipk_solve.h) and the kernels of iterations >= stop_it return immediately, so the
 // solve stops at exactly the iteration the reference stops at.
 #include <math.h>
 #include <stdlib.h>
