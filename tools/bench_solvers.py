@@ -60,6 +60,10 @@ def main():
             run(f"config4_ldc_nx{lnx}_gmres30_{m}", gmres, L, bl, tol=1e-10, maxiter=1000 if lnx == 100 else 20,
                 restart=30, solve_method=m)
         run(f"config4_ldc_nx{lnx}_bicgstab", bicgstab, L, bl, tol=1e-10, maxiter=1000)
+        # config 4 as BASELINE words it: fp32 storage (an extension here, the reference raises on an fp32 A)
+        L32 = torch.sparse_csr_tensor(L.crow_indices(), L.col_indices(), L.values().float(), size=L.shape)
+        run(f"config4_ldc_nx{lnx}_gmres30_batched_fp32", gmres, L32, bl.float(), tol=1e-5,
+            maxiter=1000 if lnx == 100 else 20, restart=30, solve_method="batched")
 
 
 if __name__ == "__main__":
