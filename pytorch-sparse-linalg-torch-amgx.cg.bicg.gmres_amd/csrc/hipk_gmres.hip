@@ -161,6 +161,154 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_kernel(
     }
 }
 
+// Small systems, chunk = HIPK_BASE_CHUNK: the update kernel above is one 256-thread workgroup per chunk walking its
+// 4 (fp64) / 2 (fp32) chunk-loop steps one after the other, each a dependent round of column loads -- 8 + 0.43 k us at
+// n = 10^4 with five CUs busy.  Here the workgroup has one 256-thread group PER STEP (1024 / 512 threads): all column
+// loads of the chunk are in flight at once.  Arithmetic per element is unchanged; the per-thread <w,w> chain of the
+// spec (step 0's elements first, then step 1's, ...) is handed from group to group through LDS.
+template <typename T>
+__global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_update_wide_kernel(
+    int64_t n, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    T *__restrict__ w, double *__restrict__ part_qq, const double *__restrict__ part_md, int g) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr int NIT = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    __shared__ double chain[HIPK_THREADS];
+    __shared__ double hs[HIPK_GM_LDH];
+    const int t = threadIdx.x & (HIPK_THREADS - 1), q = threadIdx.x / HIPK_THREADS;
+    if (threadIdx.x < HIPK_GM_LDH) {
+        double hj = 0.0;
+        if (threadIdx.x <= k) hj = hipk_fold8(part_md + (size_t)threadIdx.x * HIPK_MAX_PARTS, g);
+        hs[threadIdx.x] = hj;
+    }
+    __syncthreads();
+    const int c = blockIdx.x;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t end = (base + HIPK_BASE_CHUNK < n) ? base + HIPK_BASE_CHUNK : n;
+    const int64_t i = base + (int64_t)VEC * t + (int64_t)q * VEC * HIPK_THREADS;
+    const int nv = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
+    T wv[VEC];
+    if (nv > 0) {
+        hipk_ld<T>((const T *)w, i, nv, wv);
+        double sacc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sacc[e] = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < HIPK_GM_LDH; j0 += 8) {
+            if (j0 <= k) {
+                T vv[8][VEC];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) {
+                        const double hj = hs[j0 + b];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) sacc[e] = fma((double)vv[b][e], hj, sacc[e]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wv[e] = (T)((double)wv[e] - sacc[e]);
+        hipk_st<T>(w, i, nv, wv);
+    }
+#pragma unroll
+    for (int qq = 0; qq < NIT; ++qq) {  // the spec's per-thread chain, one chunk-loop step per group
+        if (q == qq) {
+            double a = (qq == 0) ? 0.0 : chain[t];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (e < nv) a = fma((double)wv[e], (double)wv[e], a);
+            chain[t] = a;
+        }
+        __syncthreads();
+    }
+    // the spec's tree over the 256 chains (hipk_block_sum), every thread of the wide workgroup at the barriers
+    if (threadIdx.x < 128) chain[threadIdx.x] = chain[threadIdx.x] + chain[threadIdx.x + 128];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double a = chain[threadIdx.x] + chain[threadIdx.x + 64];
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) a = a + __shfl_down(a, sh);
+        if (threadIdx.x == 0) {
+            part_qq[c] = a;
+            if (c == 0) {
+                for (int j = 0; j <= k; ++j) scal->rvec[j] = ((pass == 0) ? 0.0 : scal->rvec[j]) + hs[j];
+            }
+        }
+    }
+}
+
+// The multidot of small systems in the same wide form (one 256-thread group per chunk-loop step, 8 chains per thread
+// handed on through LDS).
+template <typename T>
+__global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_multidot_wide_kernel(
+    int64_t n, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    const T *__restrict__ w, double *__restrict__ part, const double *__restrict__ part_qq, int g, double eps) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr int NIT = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);
+    const int c = blockIdx.x;
+    const int j0 = 8 * blockIdx.y;  // <= k by construction of the grid
+    const int t = threadIdx.x & (HIPK_THREADS - 1), q = threadIdx.x / HIPK_THREADS;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t end = (base + HIPK_BASE_CHUNK < n) ? base + HIPK_BASE_CHUNK : n;
+    const int64_t i = base + (int64_t)VEC * t + (int64_t)q * VEC * HIPK_THREADS;
+    const int nv = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
+    if (k >= scal->stop_step) return;
+    if (pass == 1) {
+        double qnorm;
+        const int want = hipk_gm_want_pass2(scal, k, hipk_fold8(part_qq, g), eps, &qnorm);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            scal->qnorm = qnorm;
+            scal->pass2 = want;
+        }
+        if (!want) return;
+    }
+    __shared__ double chain[8 * HIPK_THREADS];
+    T wv[VEC];
+    T vv[8][VEC];
+    if (nv > 0) {
+        hipk_ld<T>(w, i, nv, wv);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+    }
+#pragma unroll
+    for (int qq = 0; qq < NIT; ++qq) {
+        if (q == qq) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                double a = (qq == 0) ? 0.0 : chain[b * HIPK_THREADS + t];
+                if (j0 + b <= k) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (e < nv) a = fma((double)vv[b][e], (double)wv[e], a);
+                }
+                chain[b * HIPK_THREADS + t] = a;
+            }
+        }
+        __syncthreads();
+    }
+    // hipk_block_sum8's tree, every thread of the wide workgroup at the barriers
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            chain[b * HIPK_THREADS + threadIdx.x] = chain[b * HIPK_THREADS + threadIdx.x] + chain[b * HIPK_THREADS + threadIdx.x + 128];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            double a = chain[b * HIPK_THREADS + threadIdx.x] + chain[b * HIPK_THREADS + threadIdx.x + 64];
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) a = a + __shfl_down(a, sh);
+            if (threadIdx.x == 0 && j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = a;
+        }
+    }
+}
+
 // hvec[j] = fixed-order sum of part[j][0..g)   (one workgroup per j)
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_hreduce_kernel(hipk_gm_scal *__restrict__ scal, int k, int pass,
                                                                        int g, const double *__restrict__ part) {
@@ -268,6 +416,8 @@ template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     int64_t n, int ch, int g, hipk_gm_scal *__restrict__ scal, int k, T *__restrict__ w,
     const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps, int small_ntiles) {
+    hipk_pre<T, 1> pre;  // w travels while the stop word is read and the partials are folded
+    pre.issue(n, ch, blockIdx.x, {(const T *)w});
     if (k >= scal->stop_step) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double qq, ww;
@@ -283,12 +433,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     const double thr = eps * norm0;
     const bool use = norm1 > thr;
     const T nrm = (T)norm1;
-    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+    pre.run([&](int64_t i, int nv, T(&v)[1][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T wv[VEC];
-        hipk_ld<T>((const T *)w, i, nv, wv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) wv[e] = use ? wv[e] / nrm : (T)0;
+        for (int e = 0; e < VEC; ++e) wv[e] = use ? v[0][e] / nrm : (T)0;
         hipk_st<T>(w, i, nv, wv);
     });
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -615,6 +764,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     }
     int64_t cycles = 0;
     const bool small = gm.g <= 8 && !getenv("HIPK_GMRES_NO_SMALL");  // launch-bound systems: fewer launches per step
+    const bool wide = small && gm.ch == HIPK_BASE_CHUNK && !getenv("HIPK_GMRES_NO_WIDE");  // hipk_gm_update_wide_kernel
     int happy = 0;
     int64_t prof_valid = 0;
     rc = HIPK_OK;
@@ -635,10 +785,18 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             for (int pass = 0; pass < 2; ++pass) {
                 const dim3 mgrid(gm.g, k / 8 + 1);
                 if (small) {  // 7 instead of 10 launches per Arnoldi step (decide and the two hreduce folded away)
-                    hipk_gm_multidot_kernel<T, true><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                         part_md, part_qq, gm.g, eps_t);
-                    hipk_gm_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                      part_qq, part_md, gm.g);
+                    if (wide)
+                        hipk_gm_multidot_wide_kernel<T><<<mgrid, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(
+                            n, scal, k, pass, V, ldv, w, part_md, part_qq, gm.g, eps_t);
+                    else
+                        hipk_gm_multidot_kernel<T, true><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                             part_md, part_qq, gm.g, eps_t);
+                    if (wide)
+                        hipk_gm_update_wide_kernel<T><<<gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(
+                            n, scal, k, pass, V, ldv, w, part_qq, part_md, gm.g);
+                    else
+                        hipk_gm_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                          part_qq, part_md, gm.g);
                 } else {
                     if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
                     hipk_gm_multidot_kernel<T, false><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
