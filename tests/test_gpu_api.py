@@ -310,3 +310,35 @@ def test_host_signal_pacing_and_stream_polling_agree(monkeypatch):
             out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.recurrence_rs, st.breakdown)
         assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (f.__name__, n, kw, out["0"][1:], out["1"][1:])
     monkeypatch.delenv("HIPK_HOST_SIGNAL", raising=False)
+
+
+@pytest.mark.gpu
+def test_gmres_wide_small_system_kernels_are_bit_identical(monkeypatch):
+    """Small systems with 2048-row chunks run the GMRES multi-dot / update with one 256-thread group per chunk-loop
+    step (1024 threads fp64, 512 fp32); HIPK_GMRES_NO_WIDE=1 selects the 256-thread kernels: same bits, ragged tails,
+    second CGS passes and fp32 storage included."""
+    import torch
+    from pytorch_sparse_solver.module_a import gmres, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_ldc_pressure_csr
+    dev = "cuda:0"
+    mats = [create_convdiff_2d_csr(100, 100, device=dev), create_ldc_pressure_csr(47, device=dev),
+            create_convdiff_2d_csr(7, 5, device=dev), create_convdiff_2d_csr(128, 128, device=dev)]
+    for A in mats:
+        n = A.shape[0]
+        for dt in (torch.float64, torch.float32):
+            Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(),
+                                                                        A.values().float(), size=A.shape)
+            b = torch.randn(n, dtype=dt, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+            for method in ("batched", "incremental"):
+                out = {}
+                for flag in ("0", "1"):
+                    if flag == "1":
+                        monkeypatch.setenv("HIPK_GMRES_NO_WIDE", "1")
+                    else:
+                        monkeypatch.delenv("HIPK_GMRES_NO_WIDE", raising=False)
+                    x, info = gmres(Ad, b, tol=1e-9 if dt == torch.float64 else 1e-4, restart=30, maxiter=6,
+                                    solve_method=method)
+                    st = get_last_stats()
+                    out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
+                assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (n, dt, method)
+    monkeypatch.delenv("HIPK_GMRES_NO_WIDE", raising=False)
