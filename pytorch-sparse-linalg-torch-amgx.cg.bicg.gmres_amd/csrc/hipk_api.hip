@@ -224,6 +224,25 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
                     h->crow, h->col, (const T *)h->val, h->n_rows, tb, h->tile_off, h->code, (T *)h->sell_vals);
                 e = hipGetLastError();
             }
+            // tiles whose rows all carry the same code bytes (constant-coefficient stencils: all but the grid-line ends)
+            const char *uenv = getenv("HIPK_SPMV_UNIFORM");
+            if (e == hipSuccess && !(uenv && uenv[0] == '0')) {
+                int *ucount = nullptr;
+                e = hipMalloc((void **)&h->tile_ucode, sizeof(unsigned long long) * (size_t)ntiles + 2 * sizeof(int));
+                if (e == hipSuccess) {
+                    ucount = (int *)(h->tile_ucode + ntiles);
+                    e = hipMemsetAsync(ucount, 0, 2 * sizeof(int), stream);
+                }
+                if (e == hipSuccess) {
+                    hipk_tile_uniform_kernel<<<ntiles, HIPK_THREADS, 0, stream>>>(h->code, h->tile_off, ntiles, h->tile_ucode,
+                                                                                  ucount);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(&h->n_uniform_tiles, ucount, sizeof(int), hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(&h->uniform_units, ucount + 1, sizeof(int), hipMemcpyDeviceToHost, stream);
+            }
         } else {
             (void)hipFree(tw);
         }
@@ -247,6 +266,12 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
         h->n_codes = nc;
         h->coded_layout = OFFS_ONLY ? 3 : (sell ? 2 : 1);
     }
+    if (h->tile_ucode && (fail || 4 * (int64_t)h->n_uniform_tiles < ntiles)) {  // too few uniform tiles to pay for the test
+        (void)hipFree(h->tile_ucode);
+        h->tile_ucode = nullptr;
+        h->n_uniform_tiles = 0;
+        h->uniform_units = 0;
+    }
     return hipSuccess;
 }
 
@@ -256,6 +281,10 @@ static void hipk_drop_coded(hipk_csr_s *h) {
     if (h->dict_off) (void)hipFree(h->dict_off);
     if (h->dict_val) (void)hipFree(h->dict_val);
     if (h->tile_off) (void)hipFree(h->tile_off);
+    if (h->tile_ucode) (void)hipFree(h->tile_ucode);
+    h->tile_ucode = nullptr;
+    h->n_uniform_tiles = 0;
+    h->uniform_units = 0;
     if (h->sell_vals) (void)hipFree(h->sell_vals);
     h->sell_vals = nullptr;
     h->tile_off = nullptr;
@@ -434,11 +463,14 @@ extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
 extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
     if (!h) return -1;
     const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
+    // tiles whose rows share their code bytes: one 8-byte word per tile is read instead of their code planes
+    const int64_t ntl = (h->n_rows + 255) / 256;
+    const int64_t uni = h->tile_ucode ? ntl * 8 - (int64_t)h->uniform_units * HIPK_TILE : 0;
     if (hipk_csr_spmv_path(h) == HIPK_PATH_OFFSET_CODED)  // code + value planes (+ plane offsets unless uniform) + x + y
-        return h->sell_bytes * (1 + sv) + (h->sell_w > 0 ? 0 : ((h->n_rows + 255) / 256) * 8) + 2 * h->n_rows * sv;
+        return h->sell_bytes * (1 + sv) + uni + (h->sell_w > 0 ? 0 : ntl * 8) + 2 * h->n_rows * sv;
     if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED) {
         if (h->coded_layout == 2)  // byte planes (+ two plane offsets per tile unless uniform) + x + y
-            return h->sell_bytes + (h->sell_w > 0 ? 0 : ((h->n_rows + 255) / 256) * 8) + 2 * h->n_rows * sv;
+            return h->sell_bytes + uni + (h->sell_w > 0 ? 0 : ntl * 8) + 2 * h->n_rows * sv;
         return h->nnz + h->n_rows + ((h->n_rows + 255) / 256) * 8 + 2 * h->n_rows * sv;  // code + rowlen + bounds
     }
     return hipk_csr_spmv_bytes(h);
@@ -502,14 +534,16 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         a.sell_w = h->sell_w;
         const bool sell = h->coded_layout >= 2;
         a.sell_vals = h->sell_vals;
+        a.tile_ucode = h->tile_ucode;
         if (sell) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
             // exact tile size for the common stencil widths, run-time size otherwise
             const int tpc = a.ch / 256;
             void (*kern)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_LOOP_V(T, C, V)                                                                                   \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V> \
-     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V> : hipk_spmv_sell_loop_kernel<T, 0, C, V>)
+#define HIPK_PICK_LOOP_U(T, C, V, U)                                                                                      \
+    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V, U> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V, U> \
+     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V, U> : hipk_spmv_sell_loop_kernel<T, 0, C, V, U>)
+#define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
 #define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
             kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
@@ -529,6 +563,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             }
 #undef HIPK_PICK_LOOP
 #undef HIPK_PICK_LOOP_V
+#undef HIPK_PICK_LOOP_U
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);

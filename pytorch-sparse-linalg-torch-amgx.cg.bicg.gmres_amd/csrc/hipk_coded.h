@@ -372,6 +372,49 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_width_kernel(const int
     }
 }
 
+// Uniform tiles: on a constant-coefficient stencil almost every tile's 256 rows carry the SAME code bytes (all but
+// the tiles that contain a grid-line end).  ucode[tile] = those bytes (two groups of four, padding 0xFF) when the
+// tile has at most two groups and all rows agree, else 0 (no valid tile packs to 0: codes of a row are distinct).
+// The SpMV then takes a uniform tile's codes from one scalar load and never reads its planes.
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_uniform_kernel(const unsigned char *__restrict__ code,
+                                                                         const int *__restrict__ tile_off, int ntiles,
+                                                                         unsigned long long *__restrict__ ucode,
+                                                                         int *__restrict__ count) {
+    const int tl = blockIdx.x, t = threadIdx.x;
+    const int o0 = tile_off[tl], o1 = tile_off[tl + 1];
+    const int D = (o1 - o0) >> 2, Bp = (o1 - o0) & 3;
+    const unsigned char *tp = code + (size_t)o0 * HIPK_TILE;
+    unsigned c[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        unsigned w = 0xFFFFFFFFu;
+        if (g < D) {
+            w = ((const unsigned *)tp)[g * HIPK_TILE + t];
+        } else if (g == D) {
+            const unsigned char *bp = tp + (size_t)D * 1024 + t;
+            if (Bp >= 1) w = (w & 0xFFFFFF00u) | bp[0];
+            if (Bp >= 2) w = (w & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
+        }
+        c[g] = w;
+    }
+    __shared__ unsigned first[2];
+    if (t == 0) {
+        first[0] = c[0];
+        first[1] = c[1];
+    }
+    __syncthreads();
+    const int groups = D + (Bp > 0 ? 1 : 0);
+    const int same = __syncthreads_and(c[0] == first[0] && c[1] == first[1]);
+    if (t == 0) {
+        const bool ok = same && groups <= 2 && groups >= 1;
+        ucode[tl] = ok ? ((unsigned long long)c[0] | ((unsigned long long)c[1] << 32)) : 0ull;
+        if (ok) {
+            atomicAdd(count, 1);
+            atomicAdd(count + 1, o1 - o0);
+        }
+    }
+}
+
 // code of row r, entry k -> its byte in r's tile (the planes are prefilled with HIPK_SELL_PAD)
 template <typename T, bool OFFS_ONLY>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
@@ -433,7 +476,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
 //   row pointers, for stencils with variable coefficients.
-template <typename T, int UNITS, bool CHUNKED, bool VALS>
+template <typename T, int UNITS, bool CHUNKED, bool VALS, bool UNI = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
     static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
@@ -488,7 +531,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         const T *vp;  // VALS: this thread's element of the tile's value plane 0
     };
     const T *__restrict__ vals = (const T *)a.sell_vals;
-    auto request = [&](int tl, req_t &q) {  // tile tl's first G0 groups and epilogue operands
+    // UNI: uc = the tile's shared code bytes (0: read the planes), fetched one tile ahead of the request
+    auto request = [&](int tl, req_t &q, unsigned long long uc) {  // tile tl's first G0 groups and epilogue operands
         const int r0 = tl * HIPK_TILE;
         if (UNITS > 0) {
             q.D = UNITS >> 2;
@@ -501,8 +545,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             q.Bp = (o1 - o0) & 3;
             q.tp = code + (size_t)o0 * HIPK_TILE;
         }
+        if (UNI && uc != 0ull) {
+            q.c[0] = (unsigned)uc;
+            if (G0 > 1) q.c[G0 - 1] = (unsigned)(uc >> 32);
+        } else {
 #pragma unroll
-        for (int g = 0; g < G0; ++g) q.c[g] = load_group(q.tp, q.D, q.Bp, g);
+            for (int g = 0; g < G0; ++g) q.c[g] = load_group(q.tp, q.D, q.Bp, g);
+        }
         if (VALS) {
             q.vp = vals + (size_t)(q.tp - code) + t;  // same prefix: a tile of U units has U value planes
             const int cap = 4 * q.D + q.Bp;
@@ -550,7 +599,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     req_t rc, rn;
     T xc[NE];
     int tc = first_tile();
-    if (tc < ntiles) request(tc, rc);
+    const unsigned long long *__restrict__ ucode = a.tile_ucode;
+    auto ldu = [&](int tl) -> unsigned long long {  // wave-uniform: kept in scalar registers
+        const unsigned long long u = ucode[tl];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (unsigned long long)lo | ((unsigned long long)hi << 32);
+    };
+    unsigned long long uc = 0ull, un = 0ull;
+    int tn = ntiles;
+    if (UNI) {
+        if (tc < ntiles) uc = ldu(tc);
+        tn = next_tile();
+        if (tn < ntiles) un = ldu(tn);
+    }
+    if (tc < ntiles) request(tc, rc, uc);
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
     doff[t] = dofs;
@@ -558,8 +621,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
 
     while (tc < ntiles) {
         gather(rc, tc, xc);
-        const int tn = next_tile();
-        if (tn < ntiles) request(tn, rn);
+        int t2 = ntiles;
+        unsigned long long u2 = 0ull;
+        if (UNI) {  // the tile after next: its shared code word is requested now, used by the next iteration's request
+            t2 = next_tile();
+            if (t2 < ntiles) u2 = ldu(t2);
+        } else {
+            tn = next_tile();
+        }
+        if (tn < ntiles) request(tn, rn, un);
 
         const int row = tc * HIPK_TILE + t;
         T s = (T)0;
@@ -622,6 +692,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
         rc = rn;
         tc = tn;
+        if (UNI) {
+            tn = t2;
+            un = u2;
+        }
     }
     if (CHUNKED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();

@@ -99,6 +99,9 @@ struct hipk_csr_s {
                             // 3: sliced-ELL planes of OFFSET codes + value planes (sell_vals)
     void *sell_vals;        // device, sell_bytes values of `dtype`, owned (layout 3)
     int *tile_off;          // device, ntiles + 1 (sliced-ELL)
+    unsigned long long *tile_ucode;  // device, ntiles: code bytes shared by all 256 rows of a tile (0: rows differ);
+    int n_uniform_tiles;             //   null unless enough tiles are uniform (constant-coefficient stencils)
+    int uniform_units;               //   256-byte units of code planes the uniform tiles own (never read by the SpMV)
     int sell_w;             // uniform tile size in units of 256 B, or 0
     int64_t sell_bytes;     // bytes of all tiles
     int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)

@@ -60,6 +60,7 @@ struct hipk_spmv_args {
     const int *tile_off;  // sliced-ELL layout: prefix sum of the tile sizes (units of 256 bytes), ntiles + 1
     int sell_w;           //   > 0: every tile has this size
     const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
+    const unsigned long long *tile_ucode;  // per tile: the 8 code bytes every row of the tile shares, 0 = rows differ
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
     int skip_combine;       // small systems: leave the fused dots as per-wavefront tile sums (hipk_csr_s::tile_part); the
                             //   consumer folds them itself (hipk_fold_tiles8) -- one launch less per SpMV

@@ -366,3 +366,36 @@ def test_fuzz_structures_all_paths_agree_with_the_oracle(hipk, oracle, seed):
         p0[c] = oracle.dot_tiled(wv[sl], y_ref[sl])
         p1[c] = oracle.dot_tiled(y_ref[sl], y_ref[sl])
     assert np.array_equal(auto[1], p0) and np.array_equal(auto[2], p1)
+
+
+@pytest.mark.parametrize("case", ["poisson", "convdiff", "vardiff", "ldc", "wide11"])
+def test_uniform_tile_shortcut_on_and_off(hipk, oracle, case, monkeypatch):
+    """Tiles whose 256 rows share their code bytes are served from one 8-byte word per tile (hipk_tile_uniform_kernel);
+    HIPK_SPMV_UNIFORM=0 reads every tile's planes.  Same bits, fewer bytes streamed."""
+    from pytorch_sparse_solver.utils import matrix_utils as mu
+    if case == "wide11":                                                  # 11 entries per row: three code groups, never uniform
+        n = 40_000
+        crow, col, val = banded(n, [-500, -9, -4, -2, -1, 0, 1, 2, 4, 9, 500], lambda r, k: 1.0 + k)
+    else:
+        # grid lines much longer than a 256-row tile, so that most tiles hold no line end
+        A = {"poisson": lambda: mu.create_poisson_2d_csr(41, 3001, device="cpu"),
+             "convdiff": lambda: mu.create_convdiff_2d_csr(37, 3000, device="cpu"),
+             "vardiff": lambda: mu.create_variable_diffusion_2d_csr(2100, 2100, device="cpu"),
+             "ldc": lambda: mu.create_ldc_pressure_csr(1100, device="cpu")}[case]()
+        n = A.shape[0]
+        crow, col, val = (A.crow_indices().numpy().astype(np.int64), A.col_indices().numpy().astype(np.int64),
+                          A.values().numpy())
+    x = np.random.default_rng(11).standard_normal(n)
+    ref = oracle.spmv(crow, col, val, x)
+    fb = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIPK_SPMV_UNIFORM", flag)
+        h = make_handle(hipk, crow, col, val, n)
+        assert h.path() in ("coded", "offset_coded")
+        y = hipk.spmv(h, torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert np.array_equal(y, ref)
+        fb[flag] = h.format_bytes()
+    if case == "wide11":
+        assert fb["1"] == fb["0"]
+    else:
+        assert fb["1"] < fb["0"]
