@@ -156,7 +156,10 @@ int hipk_xpby(int64_t n, const void *x, double b, void *y, int dtype, hipk_strea
  * stop word: launches past it are no-ops).  The host follows the loop through a
  * pinned word the deciding kernel stores to and keeps a few iterations queued
  * ahead; HIPK_HOST_SIGNAL=0 (or a word that stops moving) selects stream-ordered
- * reads of the stop word every check_every iterations instead.                */
+ * reads of the stop word every check_every iterations instead.
+ * A handle owns scratch that its solves and fused-dot products share (per-tile
+ * partial sums, the pinned signal words): run ONE whole solve / hipk_spmv_ex
+ * with dot modes per handle at a time; plain hipk_spmv calls may overlap.      */
 size_t hipk_cg_work_bytes(int64_t n, int dtype);
 /* `_isolve(_cg_solve)`: TSL:806-856 + 968-1016. */
 int hipk_cg_solve(hipk_csr_t A, const void *b, void *x, void *work, size_t work_bytes,

@@ -9,6 +9,7 @@ from __future__ import annotations
 import collections
 import ctypes
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -199,6 +200,9 @@ class CsrHandle:
         if self.crow.numel() != self.shape[0] + 1 or self.col.numel() != self.val.numel():
             raise HipkError("inconsistent CSR component sizes")
         self._h = ctypes.c_void_p()
+        # the handle owns scratch its solves share (tile sums of the fused dots, the pinned signal words): one solve
+        # at a time per handle; ctypes drops the GIL during a solve, so threads are serialised here
+        self._lock = threading.Lock()
         with torch.cuda.device(self.device):
             rc = lib().hipk_csr_create(ctypes.byref(self._h), self.shape[0], self.shape[1], self.val.numel(),
                                        self.crow.data_ptr(), self.col.data_ptr(), self.crow.element_size(),
@@ -353,7 +357,7 @@ def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Par
     work = torch.empty(work_bytes, dtype=torch.uint8, device=h.device)
     st = Stats()
     fn = getattr(L, f"hipk_{method}_solve")
-    with torch.cuda.device(h.device):
+    with h._lock, torch.cuda.device(h.device):
         rc = fn(h.ptr, b.data_ptr(), x.data_ptr(), work.data_ptr(), work_bytes, ctypes.byref(prm), ctypes.byref(st),
                 _stream(h.device))
     _check(rc, f"hipk_{method}_solve")
@@ -407,7 +411,7 @@ def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor
     wb = int(getattr(L, f"hipk_{name}_work_bytes")(h.n, _dtype_code(h.dtype)))
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
     st = Stats()
-    with torch.cuda.device(h.device):
+    with h._lock, torch.cuda.device(h.device):
         rc = getattr(L, f"hipk_{name}_solve")(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
                                               ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
     _check(rc, f"hipk_{name}_solve")
@@ -435,7 +439,7 @@ def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Ten
     wb = int(L.hipk_gmres_work_bytes(h.n, int(restart), _dtype_code(h.dtype)))
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
     st = Stats()
-    with torch.cuda.device(h.device):
+    with h._lock, torch.cuda.device(h.device):
         rc = L.hipk_pgmres_solve(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
                                  ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
     _check(rc, "hipk_pgmres_solve")

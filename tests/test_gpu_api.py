@@ -342,3 +342,36 @@ def test_gmres_wide_small_system_kernels_are_bit_identical(monkeypatch):
                     out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
                 assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (n, dt, method)
     monkeypatch.delenv("HIPK_GMRES_NO_WIDE", raising=False)
+
+
+@pytest.mark.gpu
+def test_threads_solving_on_one_handle_are_serialised():
+    """ctypes releases the GIL during a solve; the binding's per-handle lock keeps solves that share the handle's
+    scratch (tile sums, pinned signal words) from overlapping: four threads, same matrix, same bits as one thread."""
+    import threading
+    import torch
+    from pytorch_sparse_solver.module_a import bicgstab, cg
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(120, 120, device="cuda:0")
+    n = A.shape[0]
+    bs = [torch.randn(n, dtype=torch.float64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(i))
+          for i in range(4)]
+    ref = [(cg(A, b, tol=1e-9)[0].clone(), bicgstab(A, b, tol=1e-9)[0].clone()) for b in bs]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            res = None
+            for _ in range(5):
+                res = (cg(A, bs[i], tol=1e-9)[0].clone(), bicgstab(A, bs[i], tol=1e-9)[0].clone())
+            out[i] = res
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for i in range(4):
+        assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1])
