@@ -232,6 +232,18 @@ int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev
                       int64_t maxiter, const double *part_pAp, const double *part_rr, const void *r, void *p,
                       void *x, int dtype, hipk_stream_t stream);
 
+/* CG with a CALLABLE preconditioner (`M` of cg(), TSL:821, 849): the host runs
+ *   hipk_spmv_ex(p -> Ap, <p,Ap>) | hipk_cg_update | z = M(r) (the caller's own device code, same stream) |
+ *   hipk_dot_parts(r, z) | hipk_cgm_direction
+ * gamma = <r,z> steers alpha / beta, the stop test uses <r,r> (TSL:835-841). */
+int hipk_cgm_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rz,
+                   const double *part_rr, const double *part_bb, const void *z, void *p, int dtype,
+                   double tol, double atol, int64_t maxiter, hipk_stream_t stream);
+/* x += alpha p; p = z + beta p; gamma <- <r,z>; stop test on <r,r> */
+int hipk_cgm_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it, int64_t maxiter,
+                       const double *part_pAp, const double *part_rz, const double *part_rr, const void *z,
+                       void *p, void *x, int dtype, hipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,6 +387,115 @@ extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, voi
     return HIPK_OK;
 }
 
+// ---- step API for CG with a CALLABLE preconditioner ("arbitrary callable M between fused kernels") ----
+// The host drives  SpMV+<p,Ap> | hipk_cg_update (r, <r,r>) | z = M(r) by the caller, any device code on the same
+// stream | hipk_dot_parts(r, z) | hipk_cgm_direction.  gamma = <r,z> steers alpha and beta, the stop test uses
+// rs = <r,r> (TSL:835-841); the arithmetic per element is hipk_pcg_direction_kernel's with z read instead of formed,
+// so M = (r -> dinv * r) reproduces hipk_pcg_solve bit for bit.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cgm_start_kernel(
+    int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, const double *__restrict__ part_rz,
+    const double *__restrict__ part_rr, const double *__restrict__ part_bb, const T *__restrict__ z, T *__restrict__ p,
+    double tol2, double atol_sq, int64_t maxiter) {
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double gamma0, rr0;
+    hipk_reduce_parts2(part_rz, part_rr, g, gamma0, rr0, sbuf);
+    const double bs = hipk_reduce_parts(part_bb, g, sbuf);
+    hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
+        T zv[hipk_vec<T>::VEC];
+        hipk_ld<T>(z, i, nv, zv);
+        hipk_st<T>(p, i, nv, zv);  // p0 = z0 (TSL:822)
+    });
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double a2 = tol2 * bs;
+        const double atol2 = (a2 > atol_sq) ? a2 : atol_sq;
+        scal->gamma[0] = gamma0;
+        scal->gamma[1] = 0.0;
+        scal->atol2 = atol2;
+        scal->bs = bs;
+        scal->stop_it = (maxiter <= 0 || rr0 <= atol2) ? 0 : INT64_MAX;  // TSL:841 before the first SpMV
+        scal->host_sig = nullptr;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cgm_direction_kernel(
+    int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
+    const double *__restrict__ part_pAp, const double *__restrict__ part_rz, const double *__restrict__ part_rr,
+    const T *__restrict__ z, T *__restrict__ p, T *__restrict__ x) {
+    const int c = blockIdx.x;
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, c, {z, (const T *)p});
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double pAp, gamma_new;
+    hipk_reduce_parts2(part_pAp, part_rz, g, pAp, gamma_new, sbuf);
+    const double rr = hipk_reduce_parts(part_rr, g, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T alpha = (T)(gamma / pAp);       // the bits hipk_cg_update_kernel derived
+    const T beta = (T)(gamma_new / gamma);  // TSL:851
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T xv[VEC], pv[VEC];
+        hipk_ld<T>((const T *)x, i, nv, xv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * v[1][k];
+            xv[k] = xv[k] + m0;  // TSL:847
+            const T m = beta * v[1][k];
+            pv[k] = v[0][k] + m;  // TSL:852
+        }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(p, i, nv, pv);
+    });
+    if (c == 0 && threadIdx.x == 0) {
+        scal->gamma[(it + 1) & 1] = gamma_new;
+        if (it + 1 >= maxiter || rr <= scal->atol2) scal->stop_it = it + 1;  // TSL:841 for the next pass
+    }
+}
+
+extern "C" int hipk_cgm_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rz,
+                              const double *part_rr, const double *part_bb, const void *z, void *p, int dtype,
+                              double tol, double atol, int64_t maxiter, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_rz && part_rr && part_bb && z && p, HIPK_ERR_ARG, "null argument");
+    const float tolf = (float)tol, atolf = (float)atol;
+    const double tol2 = (double)(tolf * tolf), atol_sq = (double)(atolf * atolf);
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cgm_start_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev,
+                                                                          part_rz, part_rr, part_bb, (const double *)z,
+                                                                          (double *)p, tol2, atol_sq, maxiter);
+    else
+        hipk_cgm_start_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev,
+                                                                         part_rz, part_rr, part_bb, (const float *)z,
+                                                                         (float *)p, tol2, atol_sq, maxiter);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cgm_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it, int64_t maxiter,
+                                  const double *part_pAp, const double *part_rz, const double *part_rr, const void *z,
+                                  void *p, void *x, int dtype, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_pAp && part_rz && part_rr && z && p && x, HIPK_ERR_ARG, "null argument");
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cgm_direction_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(
+            n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev, it, maxiter, part_pAp, part_rz, part_rr, (const double *)z,
+            (double *)p, (double *)x);
+    else
+        hipk_cgm_direction_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(
+            n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev, it, maxiter, part_pAp, part_rz, part_rr, (const float *)z,
+            (float *)p, (float *)x);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
 // =====================================================================================================
 // CG with a Jacobi preconditioner, M = diag(dinv)  (TSL:806-856 with `M is not _identity`).
 // z = M r is never stored: the update kernel forms it for <r,z>, the direction kernel forms it again (same

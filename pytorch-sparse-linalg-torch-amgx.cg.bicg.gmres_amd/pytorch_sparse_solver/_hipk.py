@@ -35,6 +35,8 @@ SYMBOLS = [
     # step API (row-partitioned multi-GPU CG)
     "hipk_csr_create_ex", "hipk_spmv_ex", "hipk_dot_parts", "hipk_reduce_parts", "hipk_gather",
     "hipk_cg_scal_bytes", "hipk_cg_start", "hipk_cg_update", "hipk_cg_direction",
+    # step API: CG with a callable preconditioner
+    "hipk_cgm_start", "hipk_cgm_direction",
 ]
 
 
@@ -161,6 +163,8 @@ def lib():
     L.hipk_cg_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
     L.hipk_cg_update.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, vp, i32, vp]
     L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, i32, vp]
+    L.hipk_cgm_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
+    L.hipk_cgm_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, vp]
     _lib = L
     return L
 
@@ -448,3 +452,85 @@ def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Ten
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
                       event_overhead_ms=st.event_overhead_ms)
+
+
+def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                      maxiter: Optional[int]) -> SolveStats:
+    """CG with a CALLABLE preconditioner on the fused kernels (`_cg_solve` with M, TSL:806-856).
+
+    The loop is driven from here through the step API: SpMV + <p,Ap> | hipk_cg_update (r, <r,r>) | z = M(r) -- the
+    caller's own device code, enqueued on the current stream, no synchronisation -- | <r,z> | hipk_cgm_direction.
+    Scalars and the stop word live on the device; the host looks at the stop word every 8, 16, 32, 64, 64, ...
+    iterations.  With M = (r -> dinv * r) the result equals hipk_pcg_solve's bit for bit.
+    `x` holds x0 on entry and the solution on return; `M` maps a 1-D tensor like b to one of the same shape."""
+    if h.shape[0] != h.shape[1]:
+        raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
+    for t in (b, x):
+        assert t.is_contiguous() and t.dtype == h.dtype and t.numel() == h.n and t.device == h.device
+    L = lib()
+    n, dev, dt = h.n, h.device, _dtype_code(h.dtype)
+    ch, G = int(L.hipk_chunk_size(n)), int(L.hipk_chunk_count(n))
+    maxit = 10 * n if maxiter is None else int(maxiter)
+    MODE_DOT_W, MODE_DOT_YY, MODE_RESID = 1, 2, 4
+
+    def apply_M(v):
+        z = M(v)
+        if not isinstance(z, torch.Tensor) or z.shape != v.shape:
+            raise ValueError("the preconditioner must map a vector to a vector of the same shape")
+        return z.to(device=dev, dtype=h.dtype).contiguous()
+
+    with h._lock, torch.cuda.device(dev):
+        s = _stream(dev)
+        r, p, Ap = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+        parts = torch.zeros(6 * 2048, dtype=torch.float64, device=dev)
+        part_pAp, part_rr, part_rz, part_bb, spare, part_xx = (parts[i * 2048:(i + 1) * 2048] for i in range(6))
+        scal = torch.zeros(int(L.hipk_cg_scal_bytes()) // 8, dtype=torch.float64, device=dev)
+        stop_word = scal[6:7].view(torch.int64)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        # r0 = b - A x0, <r0,r0>; <b,b>; z0 = M r0, <r0,z0>; p0 = z0   (TSL:815-826)
+        _check(L.hipk_spmv_ex(h.ptr, x.data_ptr(), r.data_ptr(), MODE_RESID | MODE_DOT_YY, None, b.data_ptr(),
+                              spare.data_ptr(), part_rr.data_ptr(), None, 0, s), "hipk_spmv_ex")
+        _check(L.hipk_dot_parts(n, ch, b.data_ptr(), b.data_ptr(), dt, part_bb.data_ptr(), s), "hipk_dot_parts")
+        z = apply_M(r)
+        _check(L.hipk_dot_parts(n, ch, r.data_ptr(), z.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
+        _check(L.hipk_cgm_start(n, ch, G, scal.data_ptr(), part_rz.data_ptr(), part_rr.data_ptr(), part_bb.data_ptr(),
+                                z.data_ptr(), p.data_ptr(), dt, float(tol), float(atol), maxit, s), "hipk_cgm_start")
+        it, stop, batch = 0, 1 << 62, 8
+        while it < maxit:
+            stop = int(stop_word.item())                      # one synchronisation per batch
+            if stop <= it:
+                break
+            end = min(maxit, it + batch)
+            batch = min(64, 2 * batch)
+            while it < end:
+                _check(L.hipk_spmv_ex(h.ptr, p.data_ptr(), Ap.data_ptr(), MODE_DOT_W, p.data_ptr(), None,
+                                      part_pAp.data_ptr(), spare.data_ptr(), stop_word.data_ptr(), it, s), "hipk_spmv_ex")
+                _check(L.hipk_cg_update(n, ch, G, scal.data_ptr(), it, part_pAp.data_ptr(), Ap.data_ptr(), r.data_ptr(),
+                                        part_rr.data_ptr(), dt, s), "hipk_cg_update")
+                z = apply_M(r)                                 # past the stop this works on a converged r: harmless
+                _check(L.hipk_dot_parts(n, ch, r.data_ptr(), z.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
+                _check(L.hipk_cgm_direction(n, ch, G, scal.data_ptr(), it, maxit, part_pAp.data_ptr(), part_rz.data_ptr(),
+                                            part_rr.data_ptr(), z.data_ptr(), p.data_ptr(), x.data_ptr(), dt, s),
+                       "hipk_cgm_direction")
+                it += 1
+        stop = int(stop_word.item())
+        iterations = min(stop, it)
+        # TSL:1007-1014 with M: ||M (b - A x)||, ||x||
+        _check(L.hipk_spmv_ex(h.ptr, x.data_ptr(), Ap.data_ptr(), MODE_RESID, None, b.data_ptr(), spare.data_ptr(),
+                              spare.data_ptr(), None, 0, s), "hipk_spmv_ex")
+        zr = apply_M(Ap)
+        _check(L.hipk_dot_parts(n, ch, zr.data_ptr(), zr.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
+        _check(L.hipk_dot_parts(n, ch, x.data_ptr(), x.data_ptr(), dt, part_xx.data_ptr(), s), "hipk_dot_parts")
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        for k, prt in enumerate((part_rz, part_xx, part_bb, part_rr)):
+            _check(L.hipk_reduce_parts(prt.data_ptr(), G, out[k:k + 1].data_ptr(), s), "hipk_reduce_parts")
+        e1.record()
+        res2, xx, bs, rs = (float(v) for v in out.cpu())
+    b_norm, res_norm = max(bs, 0.0) ** 0.5, max(res2, 0.0) ** 0.5
+    x_norm = max(xx, 0.0) ** 0.5 if xx == xx else float("nan")
+    thr = max(float(torch.tensor(tol, dtype=torch.float32)) * b_norm, float(torch.tensor(atol, dtype=torch.float32)))
+    info = -1 if (x_norm != x_norm or res_norm > thr) else 0
+    return SolveStats(method="cg_callable_M", iterations=iterations, matvecs=iterations + 2, info=info, breakdown=0,
+                      b_norm=b_norm, residual_norm=res_norm, x_norm=x_norm, threshold=thr, recurrence_rs=rs,
+                      solve_ms=e0.elapsed_time(e1), spmv_ms_avg=0.0, spmv_profiled=0)

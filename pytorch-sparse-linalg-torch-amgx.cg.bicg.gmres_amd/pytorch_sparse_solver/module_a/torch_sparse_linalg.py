@@ -25,6 +25,7 @@ never returns (iteration counts) is available from `get_last_stat
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Callable, Optional, Tuple, Union
 
 import torch
@@ -162,6 +163,26 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
     else:
         st = _hipk.solve(method, h, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
                          solve_method=solve_method)
+    _set_stats(st)
+    return x, int(st.info)
+
+
+def _fast_solve_cg_callable(A, b, x0, tol, atol, maxiter, M):
+    """cg() with an arbitrary preconditioner `M` (callable or matrix) and a device CSR/dense `A`: the fused kernels
+    run the iteration, `M` is called between them on the same stream (`_hipk.solve_cg_callable`)."""
+    from .. import _hipk
+
+    if A.shape[0] != A.shape[1]:
+        raise ValueError(f'linear operator must be a square matrix, but has shape: {A.shape}')
+    if x0 is not None and x0.shape != b.shape:
+        raise ValueError(f'arrays in x0 and b must have matching shapes: {x0.shape} vs {b.shape}')
+    if A.shape[1] != b.numel():
+        raise RuntimeError(f'size mismatch, got input ({A.shape[0]}x{A.shape[1]}), vec ({b.numel()})')
+    h = _hipk.handle_for(A)
+    work_dtype = torch.float64 if h.dtype == torch.float64 else torch.float32
+    bb = b.detach().to(work_dtype).contiguous()
+    x = torch.zeros_like(bb) if x0 is None else x0.detach().to(work_dtype).clone().contiguous()
+    st = _hipk.solve_cg_callable(h, _normalize_matvec(M), bb, x, tol=tol, atol=atol, maxiter=maxiter)
     _set_stats(st)
     return x, int(st.info)
 
@@ -365,6 +386,8 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter)
     if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
+    if kind == 'cg' and M is not None and _fast_ok(A, b, x0, None) and os.environ.get('HIPK_CG_CALLABLE_M', '1') != '0':
+        return _fast_solve_cg_callable(A, b, x0, tol, atol, maxiter, M)   # any other M: fused kernels around the callable
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size

@@ -184,3 +184,60 @@ def test_bicgstab_jacobi_large_nonsymmetric(hipk, oracle):
     ref = oracle.bicgstab_jacobi(crow, col, val, M.dinv.cpu().numpy(), b.cpu().numpy(), tol=1e-10, maxiter=40)
     oracle.set_threads(1)
     assert np.array_equal(x.cpu().numpy(), ref.x) and (st.iterations, st.matvecs) == (ref.iterations, ref.matvecs)
+
+
+# ---- cg() with an arbitrary callable M: fused kernels around the callable (_hipk.solve_cg_callable) ----
+@pytest.mark.parametrize("r", RUNS, ids=rid)
+def test_cg_with_a_callable_M_equals_the_jacobi_fast_path_and_the_reference(hipk, oracle, r):
+    """M = (v -> dinv * v) as a plain Python callable takes the step-API path; it has to reproduce the oracle (and so
+    hipk_pcg_solve) bit for bit, and the reference's own counts and x."""
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, cg, get_last_stats
+    d = np.load(os.path.join(GOLD, r["case"] + ".npz"))
+    A = dev_csr(d)
+    dinv_t = JacobiPreconditioner(A).dinv
+    x0 = torch.from_numpy(d["x0"]).to(DEV) if r["has_x0"] else None
+    calls = []
+
+    def M(v):
+        calls.append(1)
+        return dinv_t * v
+    x, info = cg(A, torch.from_numpy(d["b"]).to(DEV), x0=x0, M=M, **r["kwargs"])
+    st = get_last_stats()
+    assert st.method == "cg_callable_M" and len(calls) >= st.iterations + 2
+    ref = oracle.pcg_jacobi(d["crow"], d["col"], d["val"], dinv_t.cpu().numpy(), d["b"],
+                            x0=d["x0"] if r["has_x0"] else None, **r["kwargs"])
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert st.residual_norm == ref.residual_norm
+    assert info == r["info"] and st.matvecs == r["matvecs"]
+    x_ref = d[r["tag"] + "_x"]
+    assert np.linalg.norm(x.cpu().numpy() - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+
+
+def test_cg_with_matrix_M_and_generic_path_agree(hipk, monkeypatch):
+    """A dense matrix as M (the reference accepts tensors, TSL:176-208) and a non-diagonal callable: the fused path
+    and the generic torch-op path (HIPK_CG_CALLABLE_M=0) stop at the same iteration with the same x to rounding."""
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    A = create_variable_diffusion_2d_csr(40, 30, device=DEV)
+    n = A.shape[0]
+    b = torch.randn(n, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    Ad = A.to_dense()
+    Minv = torch.diag(1.0 / torch.diagonal(Ad)) + 1e-3 * torch.eye(n, dtype=torch.float64, device=DEV)   # SPD matrix M
+    tri = torch.tril(Ad)
+
+    def gauss_seidel_sym(v):                                         # symmetric Gauss-Seidel: (D+L)^-T D (D+L)^-1
+        y = torch.linalg.solve_triangular(tri, v.unsqueeze(-1), upper=False)
+        y = torch.diagonal(Ad).unsqueeze(-1) * y
+        return torch.linalg.solve_triangular(tri.T, y, upper=True).squeeze(-1)
+    for M in (Minv, gauss_seidel_sym):
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HIPK_CG_CALLABLE_M", flag)
+            x, info = cg(A, b, M=M, tol=1e-10)
+            st = get_last_stats()
+            out[flag] = (x.clone(), info, st.iterations, st.method)
+        assert out["1"][3] == "cg_callable_M" and out["0"][3] != "cg_callable_M"
+        assert out["1"][1] == out["0"][1] == 0 and abs(out["1"][2] - out["0"][2]) <= 4      # different summation orders
+        assert torch.linalg.norm(out["1"][0] - out["0"][0]) <= 1e-8 * torch.linalg.norm(out["0"][0])
+    monkeypatch.delenv("HIPK_CG_CALLABLE_M", raising=False)
