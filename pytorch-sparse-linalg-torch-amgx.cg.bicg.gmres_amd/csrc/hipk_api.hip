@@ -234,7 +234,7 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
                     e = hipMemsetAsync(ucount, 0, 2 * sizeof(int), stream);
                 }
                 if (e == hipSuccess) {
-                    hipk_tile_uniform_kernel<<<ntiles, HIPK_THREADS, 0, stream>>>(h->code, h->tile_off, ntiles, h->tile_ucode,
+                    hipk_tile_uniform_kernel<<<(ntiles + 15) / 16, HIPK_THREADS, 0, stream>>>(h->code, h->tile_off, ntiles, h->tile_ucode,
                                                                                   ucount);
                     e = hipGetLastError();
                 }

@@ -380,7 +380,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_uniform_kernel(const u
                                                                          const int *__restrict__ tile_off, int ntiles,
                                                                          unsigned long long *__restrict__ ucode,
                                                                          int *__restrict__ count) {
-    const int tl = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
+    __shared__ unsigned first[2];
+    int n_ok = 0, units_ok = 0;  // thread 0: this workgroup's tally (one pair of atomics per 16 tiles, not per tile)
+    for (int tl = blockIdx.x * 16; tl < ntiles && tl < blockIdx.x * 16 + 16; ++tl) {
     const int o0 = tile_off[tl], o1 = tile_off[tl + 1];
     const int D = (o1 - o0) >> 2, Bp = (o1 - o0) & 3;
     const unsigned char *tp = code + (size_t)o0 * HIPK_TILE;
@@ -397,21 +400,25 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_uniform_kernel(const u
         }
         c[g] = w;
     }
-    __shared__ unsigned first[2];
     if (t == 0) {
         first[0] = c[0];
         first[1] = c[1];
     }
     __syncthreads();
     const int groups = D + (Bp > 0 ? 1 : 0);
-    const int same = __syncthreads_and(c[0] == first[0] && c[1] == first[1]);
+    const int same = __syncthreads_and(c[0] == first[0] && c[1] == first[1]);  // also fences `first` for the next tile
     if (t == 0) {
         const bool ok = same && groups <= 2 && groups >= 1;
         ucode[tl] = ok ? ((unsigned long long)c[0] | ((unsigned long long)c[1] << 32)) : 0ull;
         if (ok) {
-            atomicAdd(count, 1);
-            atomicAdd(count + 1, o1 - o0);
+            ++n_ok;
+            units_ok += o1 - o0;
         }
+    }
+    }
+    if (t == 0 && n_ok > 0) {
+        atomicAdd(count, n_ok);
+        atomicAdd(count + 1, units_ok);
     }
 }
 
