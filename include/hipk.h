@@ -193,6 +193,13 @@ int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, vo
 size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype);
 int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
                          const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* BiCGStab with the CALLER's preconditioner: M(user, in_dev, out_dev) enqueues out = M(in) (vectors of the handle's
+ * dtype, n elements) on `stream` and returns 0; it is called for p and s of every iteration (TSL:908, 922) and once
+ * for the final residual (TSL:1007).  Workspace as hipk_pbicgstab_work_bytes.  With M = diag(dinv) the iterates equal
+ * hipk_pbicgstab_solve's bit for bit. */
+typedef int (*hipk_precond_fn)(void *user, const void *in_dev, void *out_dev);
+int hipk_pbicgstab_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
+                            size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the

@@ -307,9 +307,13 @@ extern "C" size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype) {
     return hipk_bicgstab_work_bytes(n, dtype) + 2 * vec;  // + phat, shat
 }
 
+// cb != null (PRE = false): the preconditioner is the CALLER's device code -- cb(user, in, out) enqueues out = M(in) on
+// `stream` -- applied where the Jacobi variant scales in-kernel: phat = M(p) before the first SpMV, shat = M(s) before the
+// second (TSL:908, 922), M(b - A x) for the final test (TSL:1007).  Same kernels, same order of operations.
 template <typename T, bool PRE>
 static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char *work, const hipk_params *prm,
-                                 hipk_stats *st, hipStream_t stream) {
+                                 hipk_stats *st, hipStream_t stream, hipk_precond_fn cb = nullptr, void *user = nullptr) {
+    const bool ext = cb != nullptr;
     const int64_t n = A->n_rows;
     const hipk_geom gm = A->geom;
     const size_t vec = hipk_align_up((size_t)n * sizeof(T), 256);
@@ -322,7 +326,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     char *vbase = work + 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double);
     T *r = (T *)vbase, *rhat = (T *)(vbase + vec), *p = (T *)(vbase + 2 * vec), *q = (T *)(vbase + 3 * vec);
     T *s = (T *)(vbase + 4 * vec), *t = (T *)(vbase + 5 * vec);
-    T *phat = PRE ? (T *)(vbase + 6 * vec) : p, *shat = PRE ? (T *)(vbase + 7 * vec) : s;  // SpMV inputs (TSL:908, 922)
+    T *phat = (PRE || ext) ? (T *)(vbase + 6 * vec) : p, *shat = (PRE || ext) ? (T *)(vbase + 7 * vec) : s;  // SpMV inputs (TSL:908, 922)
 
     const int64_t maxiter = (prm->maxiter < 0) ? 10 * n : prm->maxiter;
     const float tolf = (float)prm->tol, atolf = (float)prm->atol;
@@ -389,6 +393,10 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         {
             hipk_bi_direction_kernel<T, PRE><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rr,
                                                                                  part_rhr, r, q, p, dinv, phat);
+            if (ext && cb(user, p, phat) != 0) {
+                hipk_set_error("hipk_pbicgstab_solve_cb: the preconditioner callback failed");
+                return HIPK_ERR_ARG;
+            }
             sq.it = it;
             if ((rc = hipk_launch_spmv(A, sq, stream, &prof)) != HIPK_OK) return rc;
             if (small)
@@ -397,13 +405,24 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             else
                 hipk_bi_supdate_kernel<T, PRE, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_rhr, part_rq,
                                                                                          r, q, s, part_ss, dinv, shat, 0);
+            if (ext && cb(user, s, shat) != 0) {
+                hipk_set_error("hipk_pbicgstab_solve_cb: the preconditioner callback failed");
+                return HIPK_ERR_ARG;
+            }
             stt.it = it;
             if ((rc = hipk_launch_spmv(A, stt, stream)) != HIPK_OK) return rc;
-            if (small)
-                hipk_bi_xupdate_kernel<T, PRE, true><<<gm.g, HIPK_THREADS, 0, stream>>>(
+            // x advances with phat / shat (TSL:942): the PRE form of the kernel also when they come from the callback
+            if (small && (PRE || ext))
+                hipk_bi_xupdate_kernel<T, true, true><<<gm.g, HIPK_THREADS, 0, stream>>>(
                     n, gm.ch, gm.g, scal, it, maxiter, part_ss, tsum0, tsum1, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, nt);
+            else if (small)
+                hipk_bi_xupdate_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                    n, gm.ch, gm.g, scal, it, maxiter, part_ss, tsum0, tsum1, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, nt);
+            else if (PRE || ext)
+                hipk_bi_xupdate_kernel<T, true, false><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                    n, gm.ch, gm.g, scal, it, maxiter, part_ss, part_ts, part_tt, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, 0);
             else
-                hipk_bi_xupdate_kernel<T, PRE, false><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                hipk_bi_xupdate_kernel<T, false, false><<<gm.g, HIPK_THREADS, 0, stream>>>(
                     n, gm.ch, gm.g, scal, it, maxiter, part_ss, part_ts, part_tt, phat, s, t, rhat, x, r, part_rr, part_rhr, shat, 0);
         }
         if ((it & 31) == 31) HIPK_CHECK_HIP(hipGetLastError());
@@ -420,6 +439,13 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     sa.part1 = part_ss;
     sa.stop_it = nullptr;
     if ((rc = hipk_launch_spmv(A, sa, stream)) != HIPK_OK) return rc;
+    if (ext) {  // ||M (b - A x)||^2 of the caller's M
+        if (cb(user, t, phat) != 0) {
+            hipk_set_error("hipk_pbicgstab_solve_cb: the preconditioner callback failed");
+            return HIPK_ERR_ARG;
+        }
+        if ((rc = hipk_launch_dot_parts(n, phat, phat, A->dtype, part_ss, stream)) != HIPK_OK) return rc;
+    }
     if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
     hipk_bi_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, gm.g, part_ss, part_bb);
     HIPK_CHECK_HIP(hipGetLastError());
@@ -471,4 +497,21 @@ extern "C" int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *
                                                    st, (hipStream_t)stream);
     return hipk_bicgstab_solve_t<float, true>(A, (const float *)dinv, (const float *)b, (float *)x, (char *)work, prm, st,
                                               (hipStream_t)stream);
+}
+
+extern "C" int hipk_pbicgstab_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
+                                       size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && M && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
+                 "b/x must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_pbicgstab_work_bytes(A->n_rows, A->dtype), HIPK_ERR_WORKSPACE, "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_bicgstab_solve_t<double, false>(A, nullptr, (const double *)b, (double *)x, (char *)work, prm, st,
+                                                    (hipStream_t)stream, M, user);
+    return hipk_bicgstab_solve_t<float, false>(A, nullptr, (const float *)b, (float *)x, (char *)work, prm, st,
+                                               (hipStream_t)stream, M, user);
 }

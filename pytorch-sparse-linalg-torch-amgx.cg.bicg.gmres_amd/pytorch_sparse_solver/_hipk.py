@@ -29,7 +29,7 @@ SYMBOLS = [
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
-    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve",
+    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve", "hipk_pbicgstab_solve_cb",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
     # step API (row-partitioned multi-GPU CG)
@@ -95,6 +95,10 @@ class HipkError(RuntimeError):
     pass
 
 
+# hipk_precond_fn (include/hipk.h): int M(void *user, const void *in_dev, void *out_dev)
+PRECOND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+
 _lib = None
 
 
@@ -153,6 +157,8 @@ def lib():
     L.hipk_pbicgstab_work_bytes.argtypes = [i64, i32]
     L.hipk_pbicgstab_work_bytes.restype = ctypes.c_size_t
     L.hipk_pbicgstab_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    L.hipk_pbicgstab_solve_cb.argtypes = [vp, PRECOND_FN, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params),
+                                          ctypes.POINTER(Stats), vp]
     dbl = ctypes.c_double
     L.hipk_csr_create_ex.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, i32, vp]
     L.hipk_spmv_ex.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -534,3 +540,58 @@ def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol:
     return SolveStats(method="cg_callable_M", iterations=iterations, matvecs=iterations + 2, info=info, breakdown=0,
                       b_norm=b_norm, residual_norm=res_norm, x_norm=x_norm, threshold=thr, recurrence_rs=rs,
                       solve_ms=e0.elapsed_time(e1), spmv_ms_avg=0.0, spmv_profiled=0)
+
+
+def solve_bicgstab_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                            maxiter: Optional[int], check_every: int = 0) -> SolveStats:
+    """hipk_pbicgstab_solve_cb: the device-resident BiCGStab loop with a CALLABLE preconditioner (TSL:859-964 with M).
+
+    The C loop calls back here where the reference applies M -- phat = M(p), shat = M(s), M(b - A x) -- with pointers
+    into the workspace; they are wrapped as views of the workspace tensor (no copy in), `M` runs on the current
+    stream, its result is copied into the output slot.  No synchronisation inside the loop."""
+    if h.shape[0] != h.shape[1]:
+        raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
+    for t in (b, x):
+        assert t.is_contiguous() and t.dtype == h.dtype and t.numel() == h.n and t.device == h.device
+    L = lib()
+    prm = Params()
+    prm.tol, prm.atol = float(tol), float(atol)
+    prm.maxiter = -1 if maxiter is None else int(maxiter)
+    prm.check_every = int(check_every)
+    prm.gpu_tolerances = 1
+    wb = int(L.hipk_pbicgstab_work_bytes(h.n, _dtype_code(h.dtype)))
+    work = torch.empty(wb, dtype=torch.uint8, device=h.device)
+    base, nbytes = work.data_ptr(), h.n * work.new_empty(0, dtype=h.dtype).element_size()
+    errors = []
+
+    def view(ptr):
+        off = int(ptr) - base
+        if off < 0 or off + nbytes > wb:
+            raise HipkError("preconditioner callback: pointer outside the workspace")
+        return work[off:off + nbytes].view(h.dtype)
+
+    def callback(_user, in_ptr, out_ptr):
+        try:
+            vin, vout = view(in_ptr), view(out_ptr)
+            z = M(vin)
+            if not isinstance(z, torch.Tensor) or z.shape != vin.shape:
+                raise ValueError("the preconditioner must map a vector to a vector of the same shape")
+            vout.copy_(z)
+            return 0
+        except BaseException as e:  # never let an exception unwind through the C frames
+            errors.append(e)
+            return 1
+    cb = PRECOND_FN(callback)
+    st = Stats()
+    with h._lock, torch.cuda.device(h.device):
+        rc = L.hipk_pbicgstab_solve_cb(h.ptr, cb, None, b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
+                                       ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
+    if errors:
+        torch.cuda.synchronize(h.device)
+        raise errors[0]
+    _check(rc, "hipk_pbicgstab_solve_cb")
+    return SolveStats(method="bicgstab_callable_M", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+                      breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
+                      threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
+                      spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
+                      event_overhead_ms=st.event_overhead_ms)

@@ -241,3 +241,48 @@ def test_cg_with_matrix_M_and_generic_path_agree(hipk, monkeypatch):
         assert out["1"][1] == out["0"][1] == 0 and abs(out["1"][2] - out["0"][2]) <= 4      # different summation orders
         assert torch.linalg.norm(out["1"][0] - out["0"][0]) <= 1e-8 * torch.linalg.norm(out["0"][0])
     monkeypatch.delenv("HIPK_CG_CALLABLE_M", raising=False)
+
+
+@pytest.mark.parametrize("r", BI, ids=rid)
+def test_bicgstab_with_a_callable_M_equals_the_jacobi_fast_path(hipk, oracle, r):
+    """bicgstab(M=<python callable>) runs the device-resident loop with a callback where the reference applies M
+    (hipk_pbicgstab_solve_cb): with M = (v -> dinv * v) the iterates are the oracle's bit for bit."""
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, get_last_stats
+    d = np.load(os.path.join(GOLD, r["case"] + ".npz"))
+    A = dev_csr(d)
+    dinv_t = JacobiPreconditioner(A).dinv
+    x0 = torch.from_numpy(d["x0"]).to(DEV) if r["has_x0"] else None
+    x, info = bicgstab(A, torch.from_numpy(d["b"]).to(DEV), x0=x0, M=lambda v: dinv_t * v, **r["kwargs"])
+    st = get_last_stats()
+    assert st.method == "bicgstab_callable_M"
+    ref = oracle.bicgstab_jacobi(d["crow"], d["col"], d["val"], dinv_t.cpu().numpy(), d["b"],
+                                 x0=d["x0"] if r["has_x0"] else None, **r["kwargs"])
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert (info, st.iterations, st.matvecs, st.breakdown) == (ref.info, ref.iterations, ref.matvecs, ref.breakdown)
+    assert abs(st.residual_norm - ref.residual_norm) <= 1e-12 * max(ref.residual_norm, 1e-300)   # chunk dot vs tiled dot
+    assert info == r["info"]
+
+
+def test_callable_M_that_raises_propagates_and_leaves_the_handle_usable(hipk):
+    from pytorch_sparse_solver.module_a import bicgstab, cg
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(50, 50, device=DEV)
+    b = torch.ones(2500, dtype=torch.float64, device=DEV)
+
+    class Boom(Exception):
+        pass
+    calls = []
+
+    def bad(v):
+        calls.append(1)
+        if len(calls) > 3:
+            raise Boom("preconditioner failed")
+        return v
+    for f in (bicgstab, cg):
+        calls.clear()
+        with pytest.raises(Boom):
+            f(A, b, M=bad, tol=1e-10)
+        x, info = f(A, b, tol=1e-8)                                  # the handle (and its lock) are fine afterwards
+        assert info == 0
+    with pytest.raises(ValueError):
+        bicgstab(A, b, M=lambda v: v[:10], tol=1e-8)
