@@ -200,6 +200,11 @@ int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x,
 typedef int (*hipk_precond_fn)(void *user, const void *in_dev, void *out_dev);
 int hipk_pbicgstab_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
                             size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* GMRES with the CALLER's preconditioner, applied after every A (left preconditioning: v = M(A v) TSL:351,
+ * M(b - A x) TSL:791/766, ptol from ||M b|| TSL:750).  M is called in place (in_dev == out_dev) on workspace
+ * vectors.  Workspace as hipk_gmres_work_bytes. */
+int hipk_pgmres_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
+                         size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the

@@ -678,9 +678,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_scaled_sq_kernel(int64_t
 
 // dinv != nullptr: left Jacobi preconditioning -- every A(.) is followed by M(.) = dinv .* (.) (TSL:351, 791, 766), applied
 // by the SpMV epilogue (HIPK_SPMV_SCALE) before its fused dots; ptol from ||M b|| (TSL:750).  Mirrored by orc_gmres_jacobi.
+// cb != nullptr (dinv == nullptr): M is the CALLER's device code, cb(user, in, out) enqueues out = M(in) on `stream`.  It runs
+// in place on the vector the SpMV just wrote; the squared norm the Jacobi form fuses into the SpMV epilogue is then a
+// chunked dot of the preconditioned vector (one more pass over it).
 template <typename T>
 static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char *work, const hipk_params *prm,
-                              hipk_stats *st, hipStream_t stream) {
+                              hipk_stats *st, hipStream_t stream, hipk_precond_fn cb = nullptr, void *user = nullptr) {
+    const bool ext = cb != nullptr;
     const int64_t n = A->n_rows;
     const hipk_geom gm = A->geom;
     const int m = prm->restart;
@@ -717,6 +721,14 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     const int scale_bit = dinv ? HIPK_SPMV_SCALE : 0;
     int rc;
     int64_t matvecs = 0;
+    // ext: v <- M(v) by the caller, part[c] = chunk partials of <v,v>
+    auto precondition = [&](T *v, double *part) -> int {
+        if (cb(user, v, v) != 0) {
+            hipk_set_error("hipk_pgmres_solve_cb: the preconditioner callback failed");
+            return HIPK_ERR_ARG;
+        }
+        return hipk_launch_dot_parts(n, v, v, A->dtype, part, stream);
+    };
 
     // residual = M(b - A x0) into column 0, unit residual + norm (TSL:791-792); <b,b>
     hipk_spmv_args sr = sa;
@@ -729,6 +741,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     if ((rc = hipk_launch_dot_parts(n, b, b, A->dtype, part_bb, stream)) != HIPK_OK) return rc;
     if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) return rc;
     ++matvecs;
+    if (ext && (rc = precondition(V, part_res)) != HIPK_OK) return rc;
     hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb, eps_t);
     HIPK_CHECK_HIP(hipGetLastError());
     double head[2];
@@ -746,8 +759,13 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     const double base_atol = (double)(float)(eps * (prm->gpu_tolerances ? 1000 : 100) * (double)n);
     const double atol_eff = hipk_tmax(adaptive * b_norm, hipk_tmax((double)(float)prm->atol, base_atol));
     double mb_norm = b_norm;  // ||M b|| (TSL:750)
-    if (dinv) {
-        hipk_gm_scaled_sq_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, b, dinv, part_spare);
+    if (dinv || ext) {
+        if (ext) {  // M b through the spare vector (the callback sees workspace vectors only)
+            HIPK_CHECK_HIP(hipMemcpyAsync(tmp, b, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            if ((rc = precondition(tmp, part_spare)) != HIPK_OK) return rc;
+        } else {
+            hipk_gm_scaled_sq_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, b, dinv, part_spare);
+        }
         double *mb_dev = part_xx;  // the <x,x> slot is unused until the end of the solve
         if ((rc = hipk_launch_finish1(part_spare, gm.g, mb_dev, stream)) != HIPK_OK) return rc;
         double mb2 = 0.0;
@@ -776,12 +794,13 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             sw.x = V + (int64_t)k * ldv;
             sw.y = w;
             sw.skip_combine = small ? 1 : 0;  // small systems: hipk_gm_normalize_kernel folds the tile sums itself
-            sw.mode = HIPK_SPMV_DOT_YY | scale_bit;  // w = M(A v_k), ||w||^2 of the scaled vector (TSL:351-352)
+            sw.mode = ext ? 0 : (HIPK_SPMV_DOT_YY | scale_bit);  // w = M(A v_k), ||w||^2 of the scaled vector (TSL:351-352)
             sw.part0 = part_spare;
             sw.part1 = part_ww;
             sw.stop_it = &scal->stop_step;
             sw.it = k;
             if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
+            if (ext && (rc = precondition(w, part_ww)) != HIPK_OK) break;  // w = M(A v_k), ||w||^2 (TSL:351-352)
             for (int pass = 0; pass < 2; ++pass) {
                 const dim3 mgrid(gm.g, k / 8 + 1);
                 if (small) {  // 7 instead of 10 launches per Arnoldi step (decide and the two hreduce folded away)
@@ -808,7 +827,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             }
             const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
             hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(
-                n, gm.ch, gm.g, scal, k, w, part_qq, small ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t, small ? nt : 0);
+                n, gm.ch, gm.g, scal, k, w, part_qq, (small && !ext) ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t,
+                (small && !ext) ? nt : 0);
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -837,6 +857,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         }
         if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) break;
         ++matvecs;
+        if (ext && (rc = precondition(V, part_res)) != HIPK_OK) break;
         hipk_gm_resnorm_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, V, part_res, part_bb, eps_t);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) {
@@ -855,6 +876,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     sf.y = tmp;
     if ((rc = hipk_launch_spmv(A, sf, stream)) != HIPK_OK) return rc;
     ++matvecs;
+    if (ext && (rc = precondition(tmp, part_res)) != HIPK_OK) return rc;
     if ((rc = hipk_launch_dot_parts(n, x, x, A->dtype, part_xx, stream)) != HIPK_OK) return rc;
     hipk_gm_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, gm.g, part_res, part_xx);
     HIPK_CHECK_HIP(hipGetLastError());
@@ -920,4 +942,26 @@ extern "C" int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, 
                                           (hipStream_t)stream);
     return hipk_gmres_solve_t<float>(A, (const float *)dinv, (const float *)b, (float *)x, (char *)work, prm, st,
                                      (hipStream_t)stream);
+}
+
+extern "C" int hipk_pgmres_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
+                                    size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream) {
+    HIPK_REQUIRE(A && M && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
+    HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
+                 "Unsupported solve_method");
+    HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
+                 "b/x must be 16-byte and work 256-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_gmres_work_bytes(A->n_rows, prm->restart, A->dtype), HIPK_ERR_WORKSPACE,
+                 "work too small");
+    HIPK_REQUIRE(b != x, HIPK_ERR_ARG, "b and x must not alias");
+    memset(st, 0, sizeof(*st));
+    if (A->dtype == HIPK_F64)
+        return hipk_gmres_solve_t<double>(A, nullptr, (const double *)b, (double *)x, (char *)work, prm, st,
+                                          (hipStream_t)stream, M, user);
+    return hipk_gmres_solve_t<float>(A, nullptr, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream, M,
+                                     user);
 }

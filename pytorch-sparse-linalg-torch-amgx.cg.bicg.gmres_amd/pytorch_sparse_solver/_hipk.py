@@ -29,7 +29,7 @@ SYMBOLS = [
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
-    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve", "hipk_pbicgstab_solve_cb",
+    "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve", "hipk_pbicgstab_solve_cb", "hipk_pgmres_solve_cb",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
     # step API (row-partitioned multi-GPU CG)
@@ -159,6 +159,7 @@ def lib():
     L.hipk_pbicgstab_solve.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     L.hipk_pbicgstab_solve_cb.argtypes = [vp, PRECOND_FN, vp, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(Params),
                                           ctypes.POINTER(Stats), vp]
+    L.hipk_pgmres_solve_cb.argtypes = L.hipk_pbicgstab_solve_cb.argtypes
     dbl = ctypes.c_double
     L.hipk_csr_create_ex.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, i32, vp]
     L.hipk_spmv_ex.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -544,11 +545,24 @@ def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol:
 
 def solve_bicgstab_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
                             maxiter: Optional[int], check_every: int = 0) -> SolveStats:
-    """hipk_pbicgstab_solve_cb: the device-resident BiCGStab loop with a CALLABLE preconditioner (TSL:859-964 with M).
+    """hipk_pbicgstab_solve_cb: the device-resident BiCGStab loop with a CALLABLE preconditioner (TSL:859-964 with M)."""
+    return _solve_with_callback("bicgstab", h, M, b, x, tol=tol, atol=atol, maxiter=maxiter, check_every=check_every)
 
-    The C loop calls back here where the reference applies M -- phat = M(p), shat = M(s), M(b - A x) -- with pointers
-    into the workspace; they are wrapped as views of the workspace tensor (no copy in), `M` runs on the current
-    stream, its result is copied into the output slot.  No synchronisation inside the loop."""
+
+def solve_gmres_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                         maxiter: Optional[int], restart: int = 20, solve_method: str = "batched") -> SolveStats:
+    """hipk_pgmres_solve_cb: GMRES with a CALLABLE preconditioner applied after every A (TSL:641-803 with M)."""
+    return _solve_with_callback("gmres", h, M, b, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                                solve_method=solve_method)
+
+
+def _solve_with_callback(kind: str, h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                         maxiter: Optional[int], check_every: int = 0, restart: int = 20,
+                         solve_method: str = "batched") -> SolveStats:
+    """The C loop calls back here where the reference applies M -- BiCGStab: phat = M(p), shat = M(s), M(b - A x);
+    GMRES: M(A v), M(b - A x), M b -- with pointers into the workspace; they are wrapped as views of the workspace
+    tensor (no copy in), `M` runs on the current stream, its result is copied into the output slot.  No
+    synchronisation inside the loop."""
     if h.shape[0] != h.shape[1]:
         raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
     for t in (b, x):
@@ -559,7 +573,14 @@ def solve_bicgstab_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *
     prm.maxiter = -1 if maxiter is None else int(maxiter)
     prm.check_every = int(check_every)
     prm.gpu_tolerances = 1
-    wb = int(L.hipk_pbicgstab_work_bytes(h.n, _dtype_code(h.dtype)))
+    if kind == "gmres":
+        prm.restart = int(restart)
+        prm.gmres_method = {"batched": GMRES_BATCHED, "incremental": GMRES_INCREMENTAL}[solve_method]
+        wb = int(L.hipk_gmres_work_bytes(h.n, int(restart), _dtype_code(h.dtype)))
+        fn = L.hipk_pgmres_solve_cb
+    else:
+        wb = int(L.hipk_pbicgstab_work_bytes(h.n, _dtype_code(h.dtype)))
+        fn = L.hipk_pbicgstab_solve_cb
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
     base, nbytes = work.data_ptr(), h.n * work.new_empty(0, dtype=h.dtype).element_size()
     errors = []
@@ -584,13 +605,13 @@ def solve_bicgstab_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *
     cb = PRECOND_FN(callback)
     st = Stats()
     with h._lock, torch.cuda.device(h.device):
-        rc = L.hipk_pbicgstab_solve_cb(h.ptr, cb, None, b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
-                                       ctypes.byref(prm), ctypes.byref(st), _stream(h.device))
+        rc = fn(h.ptr, cb, None, b.data_ptr(), x.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st),
+                _stream(h.device))
     if errors:
         torch.cuda.synchronize(h.device)
         raise errors[0]
-    _check(rc, "hipk_pbicgstab_solve_cb")
-    return SolveStats(method="bicgstab_callable_M", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+    _check(rc, f"hipk_p{kind}_solve_cb")
+    return SolveStats(method=f"{kind}_callable_M", iterations=st.iterations, matvecs=st.matvecs, info=st.info,
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,

@@ -167,10 +167,10 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
     return x, int(st.info)
 
 
-def _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M):
-    """cg() / bicgstab() with an arbitrary preconditioner `M` (callable or matrix) and a device CSR/dense `A`: the fused
-    kernels run the iteration, `M` is called between them on the same stream (`_hipk.solve_cg_callable` through the step
-    API, `_hipk.solve_bicgstab_callable` through the C loop's callback)."""
+def _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M, restart=20, solve_method='batched'):
+    """cg() / bicgstab() / gmres() with an arbitrary preconditioner `M` (callable or matrix) and a device CSR/dense `A`:
+    the fused kernels run the iteration, `M` is called between them on the same stream (`_hipk.solve_cg_callable` through
+    the step API, `_hipk.solve_bicgstab_callable` / `solve_gmres_callable` through the C loops' callback)."""
     from .. import _hipk
 
     if A.shape[0] != A.shape[1]:
@@ -183,8 +183,12 @@ def _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M):
     work_dtype = torch.float64 if h.dtype == torch.float64 else torch.float32
     bb = b.detach().to(work_dtype).contiguous()
     x = torch.zeros_like(bb) if x0 is None else x0.detach().to(work_dtype).clone().contiguous()
-    run = _hipk.solve_cg_callable if kind == 'cg' else _hipk.solve_bicgstab_callable
-    st = run(h, _normalize_matvec(M), bb, x, tol=tol, atol=atol, maxiter=maxiter)
+    if kind == 'gmres':
+        st = _hipk.solve_gmres_callable(h, _normalize_matvec(M), bb, x, tol=tol, atol=atol, maxiter=maxiter,
+                                        restart=restart, solve_method=solve_method)
+    else:
+        run = _hipk.solve_cg_callable if kind == 'cg' else _hipk.solve_bicgstab_callable
+        st = run(h, _normalize_matvec(M), bb, x, tol=tol, atol=atol, maxiter=maxiter)
     _set_stats(st)
     return x, int(st.info)
 
@@ -499,6 +503,11 @@ def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
     if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method,
                            jacobi=_jacobi_of(M))
+    if (M is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31
+            and os.environ.get('HIPK_CG_CALLABLE_M', '1') != '0'):
+        if solve_method not in ('batched', 'incremental'):
+            raise ValueError(f"Unsupported solve_method: {solve_method}")
+        return _fast_solve_callable('gmres', A, b, x0, tol, atol, maxiter, M, restart=restart, solve_method=solve_method)
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size

@@ -286,3 +286,23 @@ def test_callable_M_that_raises_propagates_and_leaves_the_handle_usable(hipk):
         assert info == 0
     with pytest.raises(ValueError):
         bicgstab(A, b, M=lambda v: v[:10], tol=1e-8)
+
+
+@pytest.mark.parametrize("r", GM, ids=rid)
+def test_gmres_with_a_callable_M_matches_the_jacobi_fast_path(hipk, oracle, r):
+    """gmres(M=<python callable>): the device-resident cycle with a callback after every SpMV (hipk_pgmres_solve_cb).
+    ||M(.)||^2 is a chunked dot here and a tiled dot fused into the SpMV on the Jacobi path, so residual norms (and
+    through beta = ||r|| the basis) agree to rounding, not bit for bit: same counts, x to 1e-9 of the oracle's."""
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, get_last_stats, gmres
+    d = np.load(os.path.join(GOLD, r["case"] + ".npz"))
+    A = dev_csr(d)
+    dinv_t = JacobiPreconditioner(A).dinv
+    x0 = torch.from_numpy(d["x0"]).to(DEV) if r["has_x0"] else None
+    x, info = gmres(A, torch.from_numpy(d["b"]).to(DEV), x0=x0, M=lambda v: dinv_t * v, **r["kwargs"])
+    st = get_last_stats()
+    assert st.method == "gmres_callable_M"
+    ref = oracle.gmres_jacobi(d["crow"], d["col"], d["val"], dinv_t.cpu().numpy(), d["b"],
+                              x0=d["x0"] if r["has_x0"] else None, gpu_tolerances=True, **r["kwargs"])
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
+    assert np.linalg.norm(x.cpu().numpy() - ref.x) <= 1e-9 * np.linalg.norm(ref.x)
+    assert abs(st.residual_norm - ref.residual_norm) <= 1e-6 * max(ref.residual_norm, 1e-30) + 1e-14 * st.b_norm
