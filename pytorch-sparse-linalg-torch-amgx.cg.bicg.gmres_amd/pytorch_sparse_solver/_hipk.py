@@ -194,6 +194,29 @@ def _dtype_code(dt: torch.dtype) -> int:
     raise HipkError(f"unsupported dtype {dt}")
 
 
+class _SolveLock:
+    """threading.Lock that refuses re-entry from the thread that holds it: a preconditioner callable that solves
+    with the SAME matrix object would otherwise dead-lock (and would share the handle's scratch with the outer solve)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._owner = None
+
+    def __enter__(self):
+        me = threading.get_ident()
+        if self._owner == me:
+            raise HipkError("nested solve on the same matrix from inside a preconditioner: the handle's scratch is in use "
+                            "by the outer solve -- give the inner solver its own copy of the matrix (A.clone())")
+        self._lock.acquire()
+        self._owner = me
+        return self
+
+    def __exit__(self, *exc):
+        self._owner = None
+        self._lock.release()
+        return False
+
+
 class CsrHandle:
     """Owns a hipk_csr_t and keeps the tensors it borrows alive."""
 
@@ -213,7 +236,7 @@ class CsrHandle:
         self._h = ctypes.c_void_p()
         # the handle owns scratch its solves share (tile sums of the fused dots, the pinned signal words): one solve
         # at a time per handle; ctypes drops the GIL during a solve, so threads are serialised here
-        self._lock = threading.Lock()
+        self._lock = _SolveLock()
         with torch.cuda.device(self.device):
             rc = lib().hipk_csr_create(ctypes.byref(self._h), self.shape[0], self.shape[1], self.val.numel(),
                                        self.crow.data_ptr(), self.col.data_ptr(), self.crow.element_size(),

@@ -306,3 +306,18 @@ def test_gmres_with_a_callable_M_matches_the_jacobi_fast_path(hipk, oracle, r):
     assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs)
     assert np.linalg.norm(x.cpu().numpy() - ref.x) <= 1e-9 * np.linalg.norm(ref.x)
     assert abs(st.residual_norm - ref.residual_norm) <= 1e-6 * max(ref.residual_norm, 1e-30) + 1e-14 * st.b_norm
+
+
+def test_inner_solve_as_preconditioner_needs_its_own_matrix_object(hipk):
+    """M = a few CG sweeps with the same operator (inexact inner solve): with the SAME tensor the binding refuses the
+    nested use of the handle with a clear error instead of dead-locking; with a clone it runs on the fused path."""
+    from pytorch_sparse_solver import _hipk
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    A = create_poisson_2d_csr(40, 40, device=DEV)
+    b = torch.ones(1600, dtype=torch.float64, device=DEV)
+    with pytest.raises(_hipk.HipkError, match="nested solve"):
+        cg(A, b, M=lambda r: cg(A, r, tol=1e-2)[0], tol=1e-8)
+    A2 = create_poisson_2d_csr(40, 40, device=DEV)                   # its own storage -> its own handle
+    x, info = cg(A, b, M=lambda r: cg(A2, r, tol=1e-14, maxiter=200)[0], tol=1e-8)
+    assert info == 0 and get_last_stats().method == "cg_callable_M" and get_last_stats().iterations <= 3
