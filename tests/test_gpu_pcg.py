@@ -321,3 +321,29 @@ def test_inner_solve_as_preconditioner_needs_its_own_matrix_object(hipk):
     A2 = create_poisson_2d_csr(40, 40, device=DEV)                   # its own storage -> its own handle
     x, info = cg(A, b, M=lambda r: cg(A2, r, tol=1e-14, maxiter=200)[0], tol=1e-8)
     assert info == 0 and get_last_stats().method == "cg_callable_M" and get_last_stats().iterations <= 3
+
+
+def test_callable_M_fp32_storage_equals_the_jacobi_paths(hipk):
+    """fp32 matrix and vectors: the callable-M paths run in fp32 storage like the Jacobi ones (dots in fp64):
+    cg / bicgstab bit-identical to them, gmres to rounding."""
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, cg, get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    A64 = create_variable_diffusion_2d_csr(70, 60, device=DEV)
+    A = torch.sparse_csr_tensor(A64.crow_indices(), A64.col_indices(), A64.values().float(), size=A64.shape)
+    n = A.shape[0]
+    b = torch.randn(n, dtype=torch.float32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    J = JacobiPreconditioner(A)
+    dinv = J.dinv
+    assert dinv.dtype == torch.float32
+    for f, kw, exact in ((cg, dict(tol=1e-5), True), (bicgstab, dict(tol=1e-5), True),
+                         (gmres, dict(tol=1e-5, restart=30, maxiter=40), False)):
+        xj, ij = f(A, b, M=J, **kw)
+        sj = get_last_stats()
+        xc, ic = f(A, b, M=lambda v: dinv * v, **kw)
+        sc = get_last_stats()
+        assert sc.method.endswith("callable_M") and xc.dtype == torch.float32
+        assert (ij, sj.iterations) == (ic, sc.iterations)
+        if exact:
+            assert torch.equal(xj, xc)
+        else:
+            assert torch.linalg.norm(xj.double() - xc.double()) <= 1e-5 * torch.linalg.norm(xj.double())
