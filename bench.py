@@ -188,7 +188,7 @@ def main():
             return pst.spmv_ms_avg * 1e3, pst.spmv_profiled, pst.event_overhead_ms * 1e3
 
         path = h.path()
-        spmv_name = {"coded": "hipk_spmv_sell_loop_kernel<double,5,true> (coded SpMV + fused <p,Ap> chunk partials)",
+        spmv_name = {"coded": "hipk_spmv_sell_loop_kernel<double,5,true,false,true> (coded SpMV, uniform tiles from one word per tile, + fused <p,Ap> chunk partials)",
                      "tile_fast": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, path)
         legs = [("spmv", 1, spmv_name, spmv_bytes, "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
                 ("cg_update", 2, "hipk_cg_update_kernel<double> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
