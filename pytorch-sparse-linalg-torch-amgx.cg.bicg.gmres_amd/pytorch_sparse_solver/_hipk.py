@@ -486,30 +486,42 @@ def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Ten
 
 def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
                       maxiter: Optional[int]) -> SolveStats:
-    """CG with a CALLABLE preconditioner on the fused kernels (`_cg_solve` with M, TSL:806-856).
-
-    The loop is driven from here through the step API: SpMV + <p,Ap> | hipk_cg_update (r, <r,r>) | z = M(r) -- the
-    caller's own device code, enqueued on the current stream, no synchronisation -- | <r,z> | hipk_cgm_direction.
-    Scalars and the stop word live on the device; the host looks at the stop word every 8, 16, 32, 64, 64, ...
-    iterations.  With M = (r -> dinv * r) the result equals hipk_pcg_solve's bit for bit.
-    `x` holds x0 on entry and the solution on return; `M` maps a 1-D tensor like b to one of the same shape."""
+    """CG with a CALLABLE preconditioner on the fused kernels (`_cg_solve` with M, TSL:806-856):
+    `solve_cg_stepwise` with the handle's SpMV.  With M = (r -> dinv * r) the result equals hipk_pcg_solve's
+    bit for bit."""
     if h.shape[0] != h.shape[1]:
         raise ValueError(f"linear operator must be a square matrix, but has shape: {h.shape}")
-    for t in (b, x):
-        assert t.is_contiguous() and t.dtype == h.dtype and t.numel() == h.n and t.device == h.device
+    return solve_cg_stepwise(h, None, M, b, x, tol=tol, atol=atol, maxiter=maxiter)
+
+
+def solve_cg_stepwise(h: Optional[CsrHandle], A_fn, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
+                      maxiter: Optional[int]) -> SolveStats:
+    """CG driven from the host through the step API, for operands the device-resident loop cannot call itself:
+    a CALLABLE preconditioner `M` (h given) and/or a MATRIX-FREE operator `A_fn` (h None) -- `_cg_solve`, TSL:806-856.
+
+    Per iteration: Ap = A p with <p,Ap> (fused into hipk_spmv_ex, or A_fn + hipk_dot_parts) | hipk_cg_update (r, <r,r>) |
+    [z = M(r), <r,z>] | hipk_cg_direction / hipk_cgm_direction.  `A_fn` / `M` are the caller's own device code,
+    enqueued on the current stream; scalars and the stop word live on the device, the host looks at the stop word
+    every 8, 16, 32, 64, 64, ... iterations.  `x` holds x0 on entry and the solution on return."""
+    assert (h is None) != (A_fn is None)
+    assert b.is_contiguous() and x.is_contiguous() and b.is_cuda and x.dtype == b.dtype and x.shape == b.shape
+    assert b.dtype in (torch.float64, torch.float32)
+    if h is not None:
+        assert b.dtype == h.dtype and b.numel() == h.n and b.device == h.device
     L = lib()
-    n, dev, dt = h.n, h.device, _dtype_code(h.dtype)
+    n, dev, dt = b.numel(), b.device, _dtype_code(b.dtype)
     ch, G = int(L.hipk_chunk_size(n)), int(L.hipk_chunk_count(n))
     maxit = 10 * n if maxiter is None else int(maxiter)
     MODE_DOT_W, MODE_DOT_YY, MODE_RESID = 1, 2, 4
 
-    def apply_M(v):
-        z = M(v)
+    def apply(fn, v, what):
+        z = fn(v)
         if not isinstance(z, torch.Tensor) or z.shape != v.shape:
-            raise ValueError("the preconditioner must map a vector to a vector of the same shape")
-        return z.to(device=dev, dtype=h.dtype).contiguous()
+            raise ValueError(f"the {what} must map a vector to a vector of the same shape")
+        return z.to(device=dev, dtype=b.dtype).contiguous()
 
-    with h._lock, torch.cuda.device(dev):
+    import contextlib
+    with (h._lock if h is not None else contextlib.nullcontext()), torch.cuda.device(dev):
         s = _stream(dev)
         r, p, Ap = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
         parts = torch.zeros(6 * 2048, dtype=torch.float64, device=dev)
@@ -518,14 +530,29 @@ def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol:
         stop_word = scal[6:7].view(torch.int64)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        # r0 = b - A x0, <r0,r0>; <b,b>; z0 = M r0, <r0,z0>; p0 = z0   (TSL:815-826)
-        _check(L.hipk_spmv_ex(h.ptr, x.data_ptr(), r.data_ptr(), MODE_RESID | MODE_DOT_YY, None, b.data_ptr(),
-                              spare.data_ptr(), part_rr.data_ptr(), None, 0, s), "hipk_spmv_ex")
-        _check(L.hipk_dot_parts(n, ch, b.data_ptr(), b.data_ptr(), dt, part_bb.data_ptr(), s), "hipk_dot_parts")
-        z = apply_M(r)
-        _check(L.hipk_dot_parts(n, ch, r.data_ptr(), z.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
-        _check(L.hipk_cgm_start(n, ch, G, scal.data_ptr(), part_rz.data_ptr(), part_rr.data_ptr(), part_bb.data_ptr(),
-                                z.data_ptr(), p.data_ptr(), dt, float(tol), float(atol), maxit, s), "hipk_cgm_start")
+
+        def dot_parts(u, v, part):
+            _check(L.hipk_dot_parts(n, ch, u.data_ptr(), v.data_ptr(), dt, part.data_ptr(), s), "hipk_dot_parts")
+
+        def residual(out, part_yy):                                  # out = b - A x  (+ <out,out> partials)
+            if h is not None:
+                _check(L.hipk_spmv_ex(h.ptr, x.data_ptr(), out.data_ptr(), MODE_RESID | MODE_DOT_YY, None, b.data_ptr(),
+                                      spare.data_ptr(), part_yy.data_ptr(), None, 0, s), "hipk_spmv_ex")
+            else:
+                torch.sub(b, apply(A_fn, x, "operator"), out=out)
+                dot_parts(out, out, part_yy)
+
+        # r0 = b - A x0, <r0,r0>; <b,b>; [z0 = M r0, <r0,z0>]; p0 = z0 (or r0)   (TSL:815-826)
+        residual(r, part_rr)
+        dot_parts(b, b, part_bb)
+        if M is not None:
+            z = apply(M, r, "preconditioner")
+            dot_parts(r, z, part_rz)
+            _check(L.hipk_cgm_start(n, ch, G, scal.data_ptr(), part_rz.data_ptr(), part_rr.data_ptr(), part_bb.data_ptr(),
+                                    z.data_ptr(), p.data_ptr(), dt, float(tol), float(atol), maxit, s), "hipk_cgm_start")
+        else:
+            _check(L.hipk_cg_start(n, ch, G, scal.data_ptr(), part_rr.data_ptr(), part_bb.data_ptr(), r.data_ptr(),
+                                   p.data_ptr(), dt, float(tol), float(atol), maxit, s), "hipk_cg_start")
         it, stop, batch = 0, 1 << 62, 8
         while it < maxit:
             stop = int(stop_word.item())                      # one synchronisation per batch
@@ -534,26 +561,39 @@ def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol:
             end = min(maxit, it + batch)
             batch = min(64, 2 * batch)
             while it < end:
-                _check(L.hipk_spmv_ex(h.ptr, p.data_ptr(), Ap.data_ptr(), MODE_DOT_W, p.data_ptr(), None,
-                                      part_pAp.data_ptr(), spare.data_ptr(), stop_word.data_ptr(), it, s), "hipk_spmv_ex")
+                if h is not None:
+                    _check(L.hipk_spmv_ex(h.ptr, p.data_ptr(), Ap.data_ptr(), MODE_DOT_W, p.data_ptr(), None,
+                                          part_pAp.data_ptr(), spare.data_ptr(), stop_word.data_ptr(), it, s),
+                           "hipk_spmv_ex")
+                else:
+                    Ap = apply(A_fn, p, "operator")
+                    dot_parts(p, Ap, part_pAp)
                 _check(L.hipk_cg_update(n, ch, G, scal.data_ptr(), it, part_pAp.data_ptr(), Ap.data_ptr(), r.data_ptr(),
                                         part_rr.data_ptr(), dt, s), "hipk_cg_update")
-                z = apply_M(r)                                 # past the stop this works on a converged r: harmless
-                _check(L.hipk_dot_parts(n, ch, r.data_ptr(), z.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
-                _check(L.hipk_cgm_direction(n, ch, G, scal.data_ptr(), it, maxit, part_pAp.data_ptr(), part_rz.data_ptr(),
-                                            part_rr.data_ptr(), z.data_ptr(), p.data_ptr(), x.data_ptr(), dt, s),
-                       "hipk_cgm_direction")
+                if M is not None:
+                    z = apply(M, r, "preconditioner")          # past the stop this works on a converged r: harmless
+                    dot_parts(r, z, part_rz)
+                    _check(L.hipk_cgm_direction(n, ch, G, scal.data_ptr(), it, maxit, part_pAp.data_ptr(),
+                                                part_rz.data_ptr(), part_rr.data_ptr(), z.data_ptr(), p.data_ptr(),
+                                                x.data_ptr(), dt, s), "hipk_cgm_direction")
+                else:
+                    _check(L.hipk_cg_direction(n, ch, G, scal.data_ptr(), it, maxit, part_pAp.data_ptr(),
+                                               part_rr.data_ptr(), r.data_ptr(), p.data_ptr(), x.data_ptr(), dt, s),
+                           "hipk_cg_direction")
                 it += 1
         stop = int(stop_word.item())
         iterations = min(stop, it)
-        # TSL:1007-1014 with M: ||M (b - A x)||, ||x||
-        _check(L.hipk_spmv_ex(h.ptr, x.data_ptr(), Ap.data_ptr(), MODE_RESID, None, b.data_ptr(), spare.data_ptr(),
-                              spare.data_ptr(), None, 0, s), "hipk_spmv_ex")
-        zr = apply_M(Ap)
-        _check(L.hipk_dot_parts(n, ch, zr.data_ptr(), zr.data_ptr(), dt, part_rz.data_ptr(), s), "hipk_dot_parts")
-        _check(L.hipk_dot_parts(n, ch, x.data_ptr(), x.data_ptr(), dt, part_xx.data_ptr(), s), "hipk_dot_parts")
+        # recurrence <r,r> of the last completed iteration, before the partial slots are reused
         out = torch.empty(4, dtype=torch.float64, device=dev)
-        for k, prt in enumerate((part_rz, part_xx, part_bb, part_rr)):
+        _check(L.hipk_reduce_parts(part_rr.data_ptr(), G, out[3:4].data_ptr(), s), "hipk_reduce_parts")
+        # TSL:1007-1014: ||M (b - A x)||, ||x||
+        res = torch.empty_like(b)
+        residual(res, part_rz)
+        if M is not None:
+            zr = apply(M, res, "preconditioner")
+            dot_parts(zr, zr, part_rz)
+        dot_parts(x, x, part_xx)
+        for k, prt in enumerate((part_rz, part_xx, part_bb)):
             _check(L.hipk_reduce_parts(prt.data_ptr(), G, out[k:k + 1].data_ptr(), s), "hipk_reduce_parts")
         e1.record()
         res2, xx, bs, rs = (float(v) for v in out.cpu())
@@ -561,7 +601,9 @@ def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol:
     x_norm = max(xx, 0.0) ** 0.5 if xx == xx else float("nan")
     thr = max(float(torch.tensor(tol, dtype=torch.float32)) * b_norm, float(torch.tensor(atol, dtype=torch.float32)))
     info = -1 if (x_norm != x_norm or res_norm > thr) else 0
-    return SolveStats(method="cg_callable_M", iterations=iterations, matvecs=iterations + 2, info=info, breakdown=0,
+    method = ("cg_callable_M" if M is not None else "cg") if h is not None else \
+             ("cg_matrix_free_callable_M" if M is not None else "cg_matrix_free")
+    return SolveStats(method=method, iterations=iterations, matvecs=iterations + 2, info=info, breakdown=0,
                       b_norm=b_norm, residual_norm=res_norm, x_norm=x_norm, threshold=thr, recurrence_rs=rs,
                       solve_ms=e0.elapsed_time(e1), spmv_ms_avg=0.0, spmv_profiled=0)
 

@@ -167,6 +167,29 @@ def _fast_solve(method: str, A, b, x0, tol, atol, maxiter, restart=20, solve_met
     return x, int(st.info)
 
 
+def _device_vectors(b, x0) -> bool:
+    return (isinstance(b, torch.Tensor) and b.is_cuda and b.ndim == 1 and not torch.is_complex(b)
+            and b.dtype in (torch.float64, torch.float32)
+            and (x0 is None or (isinstance(x0, torch.Tensor) and x0.device == b.device and x0.ndim == 1
+                                and not torch.is_complex(x0))))
+
+
+def _fast_solve_matrix_free(A, b, x0, tol, atol, maxiter, M):
+    """cg() with a MATRIX-FREE operator (callable `A`) on device vectors: the fused vector kernels and the device-side
+    stop word run the iteration, `A` (and `M`, if any) are called between them on the same stream
+    (`_hipk.solve_cg_stepwise`).  fp64 like the reference (TSL:979-980)."""
+    from .. import _hipk
+
+    if x0 is not None and x0.shape != b.shape:
+        raise ValueError(f'arrays in x0 and b must have matching shapes: {x0.shape} vs {b.shape}')
+    bb = b.detach().to(torch.float64).contiguous()
+    x = torch.zeros_like(bb) if x0 is None else x0.detach().to(torch.float64).clone().contiguous()
+    M_fn = None if (M is None or M is _identity) else _normalize_matvec(M)
+    st = _hipk.solve_cg_stepwise(None, _normalize_matvec(A), M_fn, bb, x, tol=tol, atol=atol, maxiter=maxiter)
+    _set_stats(st)
+    return x, int(st.info)
+
+
 def _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M, restart=20, solve_method='batched'):
     """cg() / bicgstab() / gmres() with an arbitrary preconditioner `M` (callable or matrix) and a device CSR/dense `A`:
     the fused kernels run the iteration, `M` is called between them on the same stream (`_hipk.solve_cg_callable` through
@@ -394,6 +417,9 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
     if M is not None and _fast_ok(A, b, x0, None) and os.environ.get('HIPK_CG_CALLABLE_M', '1') != '0':
         return _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M)   # any other M: fused kernels around the callable
+    if (kind == 'cg' and callable(A) and not isinstance(A, torch.Tensor) and _device_vectors(b, x0)
+            and os.environ.get('HIPK_CG_MATRIX_FREE', '1') != '0'):
+        return _fast_solve_matrix_free(A, b, x0, tol, atol, maxiter, M)     # matrix-free operator between the fused kernels
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size

@@ -347,3 +347,47 @@ def test_callable_M_fp32_storage_equals_the_jacobi_paths(hipk):
             assert torch.equal(xj, xc)
         else:
             assert torch.linalg.norm(xj.double() - xc.double()) <= 1e-5 * torch.linalg.norm(xj.double())
+
+
+# ---- cg() with a matrix-free operator on device vectors (_hipk.solve_cg_stepwise without a handle) ----
+from conftest import golden_runs, load_case, run_id  # noqa: E402
+
+
+@pytest.mark.parametrize("r", golden_runs("cg"), ids=run_id)
+def test_matrix_free_cg_reproduces_the_reference_fixtures(hipk, r):
+    """A as a Python callable (here: the handle's SpMV) on CUDA vectors runs the fused vector kernels with the device
+    stop word; held to the bar of the generic path: the reference's info, operator-application count, x to 1e-8."""
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    d = load_case(r["case"])
+    n = int(d["n"])
+    A = torch.sparse_csr_tensor(torch.from_numpy(d["crow"]).long(), torch.from_numpy(d["col"]).long(),
+                                torch.from_numpy(d["val"]), size=(n, n)).to(DEV)
+    h = hipk.handle_for(A)
+    kw = dict(r["kwargs"])
+    if r["has_x0"]:
+        kw["x0"] = torch.from_numpy(d["x0"]).to(DEV)
+    x, info = cg(lambda v: hipk.spmv(h, v), torch.from_numpy(d["b"]).to(DEV), **kw)
+    st = get_last_stats()
+    assert st.method == "cg_matrix_free" and x.dtype == torch.float64
+    x_ref = d[r["tag"] + "_x"]
+    rel = np.linalg.norm(x.cpu().numpy() - x_ref) / max(np.linalg.norm(x_ref), 1e-300)
+    assert info == r["info"] and st.matvecs == r["matvecs"] and rel < 1e-8
+
+
+def test_matrix_free_cg_with_M_and_dense_operator(hipk):
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    g = torch.Generator().manual_seed(42)
+    G = torch.randn(300, 300, dtype=torch.float64, generator=g)
+    A = (G @ G.T + 300 * torch.eye(300, dtype=torch.float64)).to(DEV)
+    b = torch.randn(300, dtype=torch.float64, generator=g).to(DEV)
+    dinv = 1.0 / torch.diagonal(A)
+    x_h, info_h = cg(A, b, tol=1e-10)
+    x_f, info_f = cg(lambda v: A @ v, b, tol=1e-10)
+    assert get_last_stats().method == "cg_matrix_free"
+    x_m, info_m = cg(lambda v: A @ v, b, tol=1e-10, M=lambda v: dinv * v)
+    assert get_last_stats().method == "cg_matrix_free_callable_M"
+    assert info_h == info_f == info_m == 0
+    assert torch.linalg.norm(x_f - x_h) <= 1e-10 * torch.linalg.norm(x_h)
+    assert torch.linalg.norm(x_m - x_h) <= 1e-9 * torch.linalg.norm(x_h)
+    with pytest.raises(ValueError):
+        cg(lambda v: (A @ v)[:10], b)

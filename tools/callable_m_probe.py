@@ -23,3 +23,17 @@ for name, M, env in (("jacobi_device_resident", J, "1"), ("callable_fused", lamb
     dt = time.perf_counter() - t0
     st = get_last_stats()
     print(f"{name}: {st.iterations} iterations, {dt * 1e6 / st.iterations:.1f} us/iteration, method {st.method}", flush=True)
+
+# matrix-free operator (callable A) on device vectors: fused vector kernels + device stop word vs the generic torch-op path
+from pytorch_sparse_solver import _hipk
+h = _hipk.handle_for(A)
+for name, env in (("matrix_free_fused", "1"), ("matrix_free_generic_torch_ops", "0")):
+    os.environ["HIPK_CG_MATRIX_FREE"] = env
+    cg(lambda v: _hipk.spmv(h, v), b, tol=1e-12, maxiter=20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, info = cg(lambda v: _hipk.spmv(h, v), b, tol=1e-12, maxiter=300)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = get_last_stats()
+    print(f"{name}: {st.iterations} iterations, {dt * 1e6 / st.iterations:.1f} us/iteration, method {st.method}", flush=True)
