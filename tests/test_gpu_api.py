@@ -42,17 +42,25 @@ def test_reference_recipes_dense_inputs_on_gpu(hipk):
     assert info == 0 and x.dtype == torch.float64
 
 
-def test_generic_path_on_cuda_tensors_matches_fast_path(hipk):
+def test_generic_path_on_cuda_tensors_matches_fast_path(hipk, monkeypatch):
     from pytorch_sparse_solver.module_a import cg, get_last_stats
     A, g = _spd(80)
     b = torch.randn(80, dtype=torch.float64, generator=g).to(DEV)
     x_fast, info_fast = cg(A, b, tol=1e-10)
     it_fast = get_last_stats().iterations
-    x_gen, info_gen = cg(lambda v: A @ v, b, tol=1e-10)                  # callable operator: generic path, torch ops on GPU
+    dinv = 1.0 / torch.diagonal(A)
+    # callable operator / callable preconditioner: by default between the fused kernels (step API) ...
+    x_mf, info_mf = cg(lambda v: A @ v, b, tol=1e-10)
+    assert get_last_stats().method == "cg_matrix_free" and get_last_stats().iterations == it_fast
+    assert info_mf == 0 and torch.allclose(x_fast, x_mf, rtol=1e-10, atol=1e-12)
+    # ... and with the switches off on the generic path: the reference's algorithm in torch ops on the GPU
+    monkeypatch.setenv("HIPK_CG_MATRIX_FREE", "0")
+    monkeypatch.setenv("HIPK_CG_CALLABLE_M", "0")
+    x_gen, info_gen = cg(lambda v: A @ v, b, tol=1e-10)
     assert type(get_last_stats()).__name__ == "_GenericStats" and get_last_stats().iterations == it_fast
     assert info_fast == info_gen == 0 and torch.allclose(x_fast, x_gen, rtol=1e-10, atol=1e-12)
-    dinv = 1.0 / torch.diagonal(A)
-    x_m, info_m = cg(A, b, tol=1e-10, M=lambda v: dinv * v)             # preconditioner: generic path
+    x_m, info_m = cg(A, b, tol=1e-10, M=lambda v: dinv * v)
+    assert type(get_last_stats()).__name__ == "_GenericStats"
     assert info_m == 0 and torch.allclose(x_m, x_fast, rtol=1e-7, atol=1e-9)
 
 
