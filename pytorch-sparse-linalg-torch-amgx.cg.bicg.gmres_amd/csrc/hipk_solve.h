@@ -204,6 +204,7 @@ struct hipk_pacer {
     int64_t *sig;             // pinned host word (device-visible at the same address), or null
     const int64_t *dev_stop;  // device stop word, for the fallback
     int64_t check, window, next_post = 0;
+    int64_t timeout_us = 200000;  // HIPK_PACE_TIMEOUT_US: how long the word may stand still before the fallback (tests: 0)
     bool live;
     // pinned: the handle's 16-word block; words 0-1 belong to the poller, word 2 is the signal
     hipk_pacer(int64_t *pinned, const int64_t *dev_stop_word, int64_t check_every, int64_t win = 8)
@@ -211,6 +212,10 @@ struct hipk_pacer {
         const char *e = getenv("HIPK_HOST_SIGNAL");
         live = !(e && e[0] == '0');
         if (!live) sig = nullptr;
+        if (const char *w = getenv("HIPK_PACE_TIMEOUT_US")) {
+            const long v = atol(w);
+            if (v >= 0) timeout_us = v;
+        }
         if (const char *w = getenv("HIPK_PACE_WINDOW")) {
             const long v = atol(w);
             if (v >= 1 && v <= 4096) window = v;
@@ -236,7 +241,7 @@ struct hipk_pacer {
                         if (v != last) {
                             last = v;
                             t0 = now;
-                        } else if (now - t0 > std::chrono::milliseconds(200)) {
+                        } else if (now - t0 >= std::chrono::microseconds(timeout_us)) {
                             live = false;
                             next_post = it;
                             break;

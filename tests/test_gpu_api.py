@@ -318,6 +318,20 @@ def test_host_signal_pacing_and_stream_polling_agree(monkeypatch):
             out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.recurrence_rs, st.breakdown)
         assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (f.__name__, n, kw, out["0"][1:], out["1"][1:])
     monkeypatch.delenv("HIPK_HOST_SIGNAL", raising=False)
+    # the mid-solve fallback: the host gives up on the signal word at once (time-out 0) and carries on with
+    # stream-ordered polling while the device keeps signalling -- same bits again
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr as mk
+    A = mk(300, 300, device=dev)
+    b = torch.randn(90000, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    for f in (cg, bicgstab):
+        monkeypatch.delenv("HIPK_PACE_TIMEOUT_US", raising=False)
+        x0_, i0_ = f(A, b, tol=1e-9)
+        s0_ = get_last_stats()
+        monkeypatch.setenv("HIPK_PACE_TIMEOUT_US", "0")
+        x1_, i1_ = f(A, b, tol=1e-9)
+        s1_ = get_last_stats()
+        assert torch.equal(x0_, x1_) and (i0_, s0_.iterations, s0_.matvecs) == (i1_, s1_.iterations, s1_.matvecs)
+    monkeypatch.delenv("HIPK_PACE_TIMEOUT_US", raising=False)
 
 
 @pytest.mark.gpu
