@@ -231,7 +231,7 @@ int hipk_reduce_parts(const double *part_dev, int g, double *out_dev, hipk_strea
 /* dst[i] = src[idx[i]], i < m  (halo pack) */
 int hipk_gather(int64_t m, const int32_t *idx_dev, const void *src, void *dst, int dtype,
                 hipk_stream_t stream);
-size_t hipk_cg_scal_bytes(void); /* device scalar block: {gamma[2], atol2, bs, res2, xx, stop_it(int64), pad} */
+size_t hipk_cg_scal_bytes(void); /* device scalar block: {gamma[2], atol2, bs, res2, xx, stop_it(int64), host signal ptr (null here)} */
 int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, const double *part_rr,
                   const double *part_bb, const void *r, void *p, int dtype, double tol, double atol,
                   int64_t maxiter, hipk_stream_t stream);
