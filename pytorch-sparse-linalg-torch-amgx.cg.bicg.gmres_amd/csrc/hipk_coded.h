@@ -483,39 +483,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
 //   row pointers, for stencils with variable coefficients.
-// v of lane i + N of the same 16-lane row (DPP row_shl): the strides 8, 4, 2, 1 of the wavefront sum's tree without the
-// LDS crossbar of ds_bpermute.  Same pairing as __shfl_down for the lanes the tree reads, so the same bits.
-template <int N>
-__device__ __forceinline__ double hipk_row_shl(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// the spec's wavefront sum (strides 32 ... 1), result valid in lane 0
-// v of lane i + 32 (lanes 0..31) / lane i + 16 (lanes 0..15): gfx950's v_permlane32_swap / v_permlane16_swap with both
-// operands the same register -- the second result holds the upper half / the odd 16-lane rows moved down
-// (tools/ubench/permlane_probe.hip prints the mapping).
-__device__ __forceinline__ double hipk_lane_up32(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_permlane32_swap(hi, hi, false, false)[1],
-                            __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[1]);
-}
-__device__ __forceinline__ double hipk_lane_up16(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_permlane16_swap(hi, hi, false, false)[1],
-                            __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[1]);
-}
-__device__ __forceinline__ double hipk_wave_sum_dpp(double d) {
-    d = d + hipk_lane_up32(d);
-    d = d + hipk_lane_up16(d);
-    d = d + hipk_row_shl<8>(d);
-    d = d + hipk_row_shl<4>(d);
-    d = d + hipk_row_shl<2>(d);
-    d = d + hipk_row_shl<1>(d);
-    return d;
-}
-
 template <typename T, int UNITS, bool CHUNKED, bool VALS, bool UNI = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
@@ -717,13 +684,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         const int slot = CHUNKED ? (tc - t_first) * 4 + wave : 0;
         const size_t tpi = (size_t)tc * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
-            d0 = hipk_wave_sum_dpp(d0);
+            d0 = hipk_wave_sum(d0);
             if (lane == 0) {
                 if (CHUNKED) wsum0[slot] = d0; else a.tpart0[tpi] = d0;
             }
         }
         if (mode & HIPK_SPMV_DOT_YY) {
-            d1 = hipk_wave_sum_dpp(d1);
+            d1 = hipk_wave_sum(d1);
             if (lane == 0) {
                 if (CHUNKED) wsum1[slot] = d1; else a.tpart1[tpi] = d1;
             }

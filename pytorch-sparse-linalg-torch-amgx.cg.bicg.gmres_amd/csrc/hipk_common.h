@@ -135,6 +135,39 @@ __device__ __forceinline__ int hipk_xcd_chunk(int b, int g) {
 }
 static inline int hipk_xcd_grid(int g) { return ((g + 7) >> 3) << 3; }
 
+// v of lane i + N of the same 16-lane row (DPP row_shl): the strides 8, 4, 2, 1 of the wavefront sum's tree without the
+// LDS crossbar of ds_bpermute.  Same pairing as __shfl_down for the lanes the tree reads, so the same bits.
+template <int N>
+__device__ __forceinline__ double hipk_row_shl(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// the spec's wavefront sum (strides 32 ... 1), result valid in lane 0
+// v of lane i + 32 (lanes 0..31) / lane i + 16 (lanes 0..15): gfx950's v_permlane32_swap / v_permlane16_swap with both
+// operands the same register -- the second result holds the upper half / the odd 16-lane rows moved down
+// (tools/ubench/permlane_probe.hip prints the mapping).
+__device__ __forceinline__ double hipk_lane_up32(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_permlane32_swap(hi, hi, false, false)[1],
+                            __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[1]);
+}
+__device__ __forceinline__ double hipk_lane_up16(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_permlane16_swap(hi, hi, false, false)[1],
+                            __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[1]);
+}
+__device__ __forceinline__ double hipk_wave_sum(double d) {
+    d = d + hipk_lane_up32(d);
+    d = d + hipk_lane_up16(d);
+    d = d + hipk_row_shl<8>(d);
+    d = d + hipk_row_shl<4>(d);
+    d = d + hipk_row_shl<2>(d);
+    d = d + hipk_row_shl<1>(d);
+    return d;
+}
+
 // Sum of the 256 per-thread values with the spec's tree. Result valid in ALL threads.
 // sbuf: 256 doubles of LDS. Leaves sbuf reusable (trailing barrier).
 __device__ __forceinline__ double hipk_block_sum(double v, double *sbuf) {
@@ -144,13 +177,7 @@ __device__ __forceinline__ double hipk_block_sum(double v, double *sbuf) {
     if (t < 128) sbuf[t] = sbuf[t] + sbuf[t + 128];
     __syncthreads();
     if (t < 64) {
-        double a = sbuf[t] + sbuf[t + 64];
-        a = a + __shfl_down(a, 32);
-        a = a + __shfl_down(a, 16);
-        a = a + __shfl_down(a, 8);
-        a = a + __shfl_down(a, 4);
-        a = a + __shfl_down(a, 2);
-        a = a + __shfl_down(a, 1);
+        const double a = hipk_wave_sum(sbuf[t] + sbuf[t + 64]);  // strides 32 ... 1, register moves only
         if (t == 0) sbuf[0] = a;
     }
     __syncthreads();
@@ -173,11 +200,8 @@ __device__ __forceinline__ void hipk_block_sum2(double &v0, double &v1, double *
     if (t < 64) {
         double a = sbuf[t] + sbuf[t + 64];
         double b = sbuf[256 + t] + sbuf[256 + t + 64];
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            a = a + __shfl_down(a, s);
-            b = b + __shfl_down(b, s);
-        }
+        a = hipk_wave_sum(a);
+        b = hipk_wave_sum(b);
         if (t == 0) {
             sbuf[0] = a;
             sbuf[256] = b;
