@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 NX = 2000
-PMC_FILE = "r01i_pmc_kernels.json"   # per-kernel HBM traffic from the committed rocprofv3 --pmc passes
+PMC_FILE = "r01j_pmc_kernels.json"   # per-kernel HBM traffic from the committed rocprofv3 --pmc passes
 
 
 def parse():
