@@ -322,13 +322,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_coded_kernel(hipk_spmv
         }
         const size_t tp = (size_t)(st * R + i) * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d0 = d0 + __shfl_down(d0, o);
+d0 = hipk_wave_sum(d0);
             if (lane == 0) a.tpart0[tp] = d0;
         }
         if (mode & HIPK_SPMV_DOT_YY) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d1 = d1 + __shfl_down(d1, o);
+d1 = hipk_wave_sum(d1);
             if (lane == 0) a.tpart1[tp] = d1;
         }
     }

@@ -74,8 +74,7 @@ __device__ __forceinline__ void hipk_block_sum8(double (&v)[8], int nb, double *
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             double a = sbuf[b * HIPK_THREADS + t] + sbuf[b * HIPK_THREADS + t + 64];
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) a = a + __shfl_down(a, s);
+a = hipk_wave_sum(a);
             v[b] = a;  // valid in lane 0
         }
     }
@@ -230,8 +229,7 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_up
     __syncthreads();
     if (threadIdx.x < 64) {
         double a = chain[threadIdx.x] + chain[threadIdx.x + 64];
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) a = a + __shfl_down(a, sh);
+a = hipk_wave_sum(a);
         if (threadIdx.x == 0) {
             part_qq[c] = a;
             if (c == 0) {
@@ -302,8 +300,7 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_mu
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             double a = chain[b * HIPK_THREADS + threadIdx.x] + chain[b * HIPK_THREADS + threadIdx.x + 64];
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) a = a + __shfl_down(a, sh);
+a = hipk_wave_sum(a);
             if (threadIdx.x == 0 && j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = a;
         }
     }

@@ -283,13 +283,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
         // tile partial = ((s0 + s1) + (s2 + s3)), s_w = wavefront w's 64 values folded by v[l] += v[l+s], s = 32..1.
         // Each wavefront stores its s_w; the combine kernel forms the tile partial: no barrier here.
         if (mode & HIPK_SPMV_DOT_W) {
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) d0 = d0 + __shfl_down(d0, s);
+d0 = hipk_wave_sum(d0);
             if (lane == 0) a.tpart0[(size_t)tile * 4 + wave] = d0;
         }
         if (mode & HIPK_SPMV_DOT_YY) {
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) d1 = d1 + __shfl_down(d1, s);
+d1 = hipk_wave_sum(d1);
             if (lane == 0) a.tpart1[(size_t)tile * 4 + wave] = d1;
         }
     }
@@ -354,13 +352,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_rowdot_kernel(hipk_spmv_arg
         if (a.mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
     }
     if (a.mode & HIPK_SPMV_DOT_W) {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) d0 = d0 + __shfl_down(d0, s);
+d0 = hipk_wave_sum(d0);
         if (lane == 0) a.tpart0[(size_t)tile * 4 + wave] = d0;
     }
     if (a.mode & HIPK_SPMV_DOT_YY) {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) d1 = d1 + __shfl_down(d1, s);
+d1 = hipk_wave_sum(d1);
         if (lane == 0) a.tpart1[(size_t)tile * 4 + wave] = d1;
     }
 }
@@ -383,8 +379,7 @@ __device__ __forceinline__ double hipk_wave_fold(const double *__restrict__ tp, 
     a[0] = a[0] + a[2];  // s = 128
     a[1] = a[1] + a[3];
     double v = a[0] + a[1];  // s = 64
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_down(v, s);
+v = hipk_wave_sum(v);
     return v;  // valid in lane 0
 }
 
