@@ -168,6 +168,24 @@ __device__ __forceinline__ double hipk_wave_sum(double d) {
     return d;
 }
 
+// the same tree for an fp32 value (row sums of the row-per-wavefront SpMV with fp32 storage)
+template <int N>
+__device__ __forceinline__ float hipk_row_shl(float v) {
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x100 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float hipk_wave_sum(float d) {
+    int i = __float_as_int(d);
+    d = d + __int_as_float(__builtin_amdgcn_permlane32_swap(i, i, false, false)[1]);
+    i = __float_as_int(d);
+    d = d + __int_as_float(__builtin_amdgcn_permlane16_swap(i, i, false, false)[1]);
+    d = d + hipk_row_shl<8>(d);
+    d = d + hipk_row_shl<4>(d);
+    d = d + hipk_row_shl<2>(d);
+    d = d + hipk_row_shl<1>(d);
+    return d;
+}
+
 // Sum of the 256 per-thread values with the spec's tree. Result valid in ALL threads.
 // sbuf: 256 doubles of LDS. Leaves sbuf reusable (trailing barrier).
 __device__ __forceinline__ double hipk_block_sum(double v, double *sbuf) {

@@ -180,8 +180,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
                 if (hi - lo2 > HIPK_LONG_ROW) {
                     T s = (T)0;
                     for (int j = lo2 + lane; j < hi; j += 64) s = s + prod[j];
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
+                    s = hipk_wave_sum(s);
                     if (lane == 0) ylong[r] = s;
                 }
             }
@@ -257,8 +256,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_kernel(hipk_spmv_args 
                     if (hi2 - lo > HIPK_LONG_ROW) {
                         T s = (T)0;
                         for (int j = lo + lane; j < hi2; j += 64) s = s + prod[j];
-#pragma unroll
-                        for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
+                        s = hipk_wave_sum(s);
                         if (lane == 0) ystage[r] = s;
                     }
                 }
@@ -328,8 +326,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_rowwave_kernel(hipk_sp
             s = s + p3;
         }
         for (; j < hi; j += 64) s = s + hipk_ld_nt(val + j) * x[col[j]];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s = s + __shfl_down(s, o);
+        s = hipk_wave_sum(s);
     }
     if (lane == 0) {
         if (!listed && (a.mode & HIPK_SPMV_RESID)) s = ((const T *)a.bsub)[row] - s;  // pre-pass: raw sum, the tile kernel finishes
