@@ -11,3 +11,6 @@ x, info = cg(A, b, tol=1e-6, M=JacobiPreconditioner(A)); print(info, get_last_st
 x, info = gmres(A, b, restart=30, maxiter=3, M=JacobiPreconditioner(A)); print(info, get_last_stats().method)
 from pytorch_sparse_solver import SparseSolver
 x, res = SparseSolver().solve(A, b, method='bicgstab', backend='module_a', tol=1e-6); print(res.converged, res.residual)
+dinv = JacobiPreconditioner(A).dinv
+x, info = cg(A, b, tol=1e-6, M=lambda r: dinv * r); print(info, get_last_stats().method, get_last_stats().iterations)
+x, info = cg(lambda v: torch.sparse.mm(A, v[:, None])[:, 0], b, maxiter=20); print(info, get_last_stats().method)
