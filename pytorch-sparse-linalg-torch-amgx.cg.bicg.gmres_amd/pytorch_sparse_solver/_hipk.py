@@ -272,6 +272,16 @@ class CsrHandle:
         """Bytes one SpMV moves in the format the selected path streams."""
         return int(lib().hipk_csr_format_bytes(self._h))
 
+    def device_bytes(self) -> int:
+        """Device memory this handle keeps alive: the CSR component tensors, the library's int32 index copies and
+        tile-sum scratch, and the coded planes (format_bytes minus the two vectors an SpMV also moves)."""
+        n, nnz, sv = self.shape[0], self.nnz, self.val.element_size()
+        b = (self.crow.numel() + self.col.numel()) * self.crow.element_size() + nnz * sv
+        b += 4 * (n + 1) + 4 * nnz + 64 * ((n + 255) // 256 + 1)
+        if self.path() in ("coded", "offset_coded"):
+            b += max(0, self.format_bytes() - 2 * n * sv)
+        return int(b)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             try:
@@ -288,9 +298,27 @@ class CsrHandle:
 
 # -------------------------------------------------------------------- handle cache
 # Repeated solves with the same matrix (the LDC stepper: one matrix, thousands of RHS)
-# reuse the analysed handle.  Keyed on storage identity + version counters.
+# reuse the analysed handle.  Keyed on storage identity + version counters + the VIEW
+# (strides, storage offset, conj/neg bits): a dense `A` and its view `A.T` share storage
+# and version but are different matrices (the adjoint solve of the implicit-diff backward,
+# TSL:1245, asks for exactly that pair).
+# The cache pins the source tensors and the handles' own device arrays (int32 index copies,
+# coded planes): it is bounded by entries AND by bytes (HIPK_CACHE_BYTES, default 8 GiB; the
+# most recent handle is always kept).  `clear_cache()` drops everything.
 _CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
-_CACHE_MAX = 4
+_CACHE_MAX = 8
+_CACHE_BYTES_DEFAULT = 8 << 30
+
+
+def _cache_budget() -> int:
+    try:
+        return int(os.environ.get("HIPK_CACHE_BYTES", _CACHE_BYTES_DEFAULT))
+    except ValueError:
+        return _CACHE_BYTES_DEFAULT
+
+
+def _part_key(p: torch.Tensor):
+    return (p.data_ptr(), p._version, p.numel(), tuple(p.stride()), p.storage_offset(), p.is_conj(), p.is_neg())
 
 
 def _cache_key(A: torch.Tensor):
@@ -304,12 +332,28 @@ def _cache_key(A: torch.Tensor):
         parts = (A,)
     else:
         raise HipkError(f"unsupported tensor layout {A.layout}")
-    return (str(A.layout), tuple(A.shape), str(A.device), A.dtype) + tuple(
-        (p.data_ptr(), p._version, p.numel()) for p in parts)
+    return (str(A.layout), tuple(A.shape), str(A.device), A.dtype) + tuple(_part_key(p) for p in parts)
+
+
+def _pinned_bytes(h: "CsrHandle", src: torch.Tensor) -> int:
+    """Device bytes an entry keeps alive: the handle's arrays + (when it was converted) the source tensor."""
+    b = h.device_bytes()
+    if src.layout == torch.strided:
+        b += src.numel() * src.element_size()
+    elif src.layout == torch.sparse_coo:
+        b += src._indices().numel() * 8 + src._values().numel() * src._values().element_size()
+    return b
+
+
+def _store(key, h: "CsrHandle", src: torch.Tensor) -> None:
+    _CACHE[key] = (h, src, _pinned_bytes(h, src))  # keep the source alive so its pointers cannot be recycled
+    budget = _cache_budget()
+    while len(_CACHE) > 1 and (len(_CACHE) > _CACHE_MAX or sum(e[2] for e in _CACHE.values()) > budget):
+        _CACHE.popitem(last=False)
 
 
 def handle_for(A: torch.Tensor) -> CsrHandle:
-    """CSR handle of a CUDA tensor in any layout (dense / COO / CSR), converted once and cached."""
+    """CSR handle of a CUDA tensor in any layout (dense / COO / CSR / CSC), converted once and cached."""
     key = _cache_key(A)
     hit = _CACHE.get(key)
     if hit is not None:
@@ -321,18 +365,22 @@ def handle_for(A: torch.Tensor) -> CsrHandle:
     elif src.layout == torch.sparse_coo:
         csr = src.coalesce().to_sparse_csr()
     elif src.layout == torch.strided:
-        csr = src.to_sparse_csr()
+        csr = src.resolve_conj().resolve_neg().to_sparse_csr()
     else:
         csr = src.to_sparse_csr()
     h = CsrHandle(csr.crow_indices(), csr.col_indices(), csr.values(), csr.shape)
-    _CACHE[key] = (h, src)  # keep the source alive so its pointers cannot be recycled
-    while len(_CACHE) > _CACHE_MAX:
-        _CACHE.popitem(last=False)
+    _store(key, h, src)
     return h
 
 
 def clear_cache() -> None:
+    """Drop every cached handle (and the source matrices / index copies / coded planes they pin on the GPU)."""
     _CACHE.clear()
+
+
+def cache_info():
+    """(entries, pinned device bytes) of the handle cache."""
+    return len(_CACHE), sum(e[2] for e in _CACHE.values())
 
 
 # -------------------------------------------------------------------- primitives

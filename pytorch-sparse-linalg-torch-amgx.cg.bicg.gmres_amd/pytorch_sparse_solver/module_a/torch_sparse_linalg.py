@@ -346,10 +346,12 @@ def _gmres_flat(P: _Flat, atol_eff, ptol, restart, maxiter, incremental: bool):
     x = P.x0
     unit, rnorm = _safe_normalize(M(b - A(x)))
     cycles, mv, happy = 0, 1, 0
+    V = torch.empty(m + 1, n, dtype=dtype, device=dev)  # basis vectors are ROWS: contiguous; allocated once per solve
+    H = torch.empty(m + 1, m, dtype=dtype, device=dev)
     while cycles < maxiter and bool(rnorm > atol_eff):
-        V = torch.zeros(m + 1, n, dtype=dtype, device=dev)  # basis vectors are ROWS: contiguous
+        V.zero_()
         V[0] = unit
-        H = torch.zeros(m + 1, m, dtype=dtype, device=dev)
+        H.zero_()
         if incremental:
             R = torch.eye(m, dtype=dtype, device=dev)
             rot = []
@@ -521,9 +523,26 @@ def bicgstab(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[
     return x, info
 
 
+_warned_restart = False
+
+
+def _warn_restart_route(A, b, x0, restart) -> None:
+    """gmres(restart > 31) on a device matrix leaves the HIP path (routing rule below): say so once, loudly --
+    at N = 4 M the generic torch-op path is orders of magnitude slower."""
+    global _warned_restart
+    if not _warned_restart and restart > 31 and _fast_ok(A, b, x0, None):
+        import warnings
+        _warned_restart = True
+        warnings.warn(f"gmres(restart={restart}): the device-resident HIP GMRES keeps at most 31 basis vectors; "
+                      f"restart > 31 runs on the generic torch-op path (one host synchronisation per Arnoldi step, "
+                      f"much slower on large systems). Use restart <= 31 to stay on the MI355X kernels.",
+                      RuntimeWarning, stacklevel=4)
+
+
 def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
     # the device-resident GMRES keeps at most 31 basis vectors (H in a fixed device block); larger Krylov
-    # spaces take the generic path (documented routing rule, not a fallback on failure)
+    # spaces take the generic path (documented routing rule, not a fallback on failure; warned about once)
+    _warn_restart_route(A, b, x0, restart)
     if _fast_ok(A, b, x0, M) and 1 <= restart <= 31:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method)
     if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31:

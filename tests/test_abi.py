@@ -54,3 +54,36 @@ def test_cuda_tensor_path_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(_hipk, "LIB_PATH", "/nonexistent/libhipk.so")
     with pytest.raises(_hipk.HipkError, match="no CPU fallback"):
         _hipk.lib()
+
+
+def test_cache_key_distinguishes_views():
+    """a dense matrix and its transposed VIEW share storage, version and numel -- the handle cache key
+    must still differ (the adjoint solve of the implicit-diff backward asks for the handle of A.T right after A's)."""
+    import torch
+    from pytorch_sparse_solver import _hipk
+    A = torch.arange(16, dtype=torch.float64).reshape(4, 4)
+    assert _hipk._cache_key(A) != _hipk._cache_key(A.T)
+    assert _hipk._cache_key(A) == _hipk._cache_key(A.detach())
+    assert _hipk._cache_key(A) != _hipk._cache_key(A[::1, :].clone())
+    B = torch.arange(32, dtype=torch.float64).reshape(8, 4)
+    assert _hipk._cache_key(B[:4]) != _hipk._cache_key(B[4:])            # same storage, different offset
+    C = torch.randn(4, 4, dtype=torch.complex128)
+    assert _hipk._cache_key(C) != _hipk._cache_key(C.conj())             # lazy conj bit
+    S = A.to_sparse_csr()
+    assert _hipk._cache_key(S) == _hipk._cache_key(S.detach())
+    assert _hipk._cache_key(S) != _hipk._cache_key(S.t())                # CSC view of the same arrays
+
+
+def test_gmres_large_restart_warns_once_about_the_route(monkeypatch):
+    """gmres(restart > 31) on a device matrix leaves the HIP path: that must not be silent."""
+    import warnings
+    import torch
+    from pytorch_sparse_solver.module_a import torch_sparse_linalg as T
+    monkeypatch.setattr(T, "_fast_ok", lambda A, b, x0, M: True)         # pretend A, b live on the GPU
+    monkeypatch.setattr(T, "_warned_restart", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        T._warn_restart_route(None, None, None, 40)
+        T._warn_restart_route(None, None, None, 40)
+        T._warn_restart_route(None, None, None, 20)
+    assert len(w) == 1 and "restart > 31" in str(w[0].message)

@@ -30,6 +30,9 @@ def main():
     ms = timeit(lambda: _hipk.spmv(h, x, out=y), 200, 20)
     B = h.spmv_bytes()
     print(f"spmv  n={n} nnz={h.nnz}: {ms*1e3:.1f} us  {B/ms/1e6:.1f} GB/s ({B/ms/1e6/8000*100:.1f}% of 8 TB/s)")
+    ref = torch.matmul(A, x)
+    if not torch.allclose(y, ref, rtol=1e-12, atol=1e-12):
+        raise SystemExit("gpu_probe: hipk SpMV differs from torch CSR matmul")
     ms_t = timeit(lambda: torch.matmul(A, x), 50, 5)
     print(f"torch CSR matmul: {ms_t*1e3:.1f} us  ({B/ms_t/1e6:.1f} GB/s on algorithmic bytes)")
     ms = timeit(lambda: _hipk.dot(x, y), 200, 20)
@@ -46,6 +49,8 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         st = get_last_stats()
+        if info != 0:
+            raise SystemExit(f"gpu_probe: cg did not converge (info={info})")
         print(f"cg tol=1e-6: info={info} iters={st.iterations} wall={t1-t0:.3f}s dev={st.solve_ms:.1f}ms "
               f"-> {st.iterations/(st.solve_ms/1e3):.0f} it/s  relres={st.residual_norm/st.b_norm:.3e}")
     # profiled pass: SpMV kernel time inside CG
@@ -55,4 +60,13 @@ def main():
           f"iteration {st.solve_ms/300*1e3:.1f} us")
 
 if __name__ == "__main__":
-    main()
+    # a probe must never report success after a failed solve / SpMV: any exception (HipkError, a HIP error surfacing at the
+    # next synchronize) or a non-converged CG ends with a non-zero exit code; a GPU memory fault aborts the process (SIGABRT)
+    try:
+        main()
+        torch.cuda.synchronize()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        print(f"gpu_probe FAILED: {type(e).__name__}: {e}", file=sys.stderr)
+        sys.exit(1)
