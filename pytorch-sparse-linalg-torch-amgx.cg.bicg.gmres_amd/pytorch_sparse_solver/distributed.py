@@ -309,11 +309,13 @@ class DistProblem:
         self.slab_all = ops.zeros(self.plan.slab * part.world)
         # per-iteration collectives: direct RCCL when the ranks are GPUs of an 'nccl' group, else torch.distributed
         self.comm = None
+        self.comm_kind = "torch.distributed"
         import os
         want = os.environ.get("HIPK_DIST_COMM", "rccl")
         if want == "rccl" and isinstance(ops, HipOps) and dist.is_initialized() and dist.get_backend(group) == "nccl":
             try:
                 self.comm = RcclComm(part.rank, part.world, ops.device, group)
+                self.comm_kind = "rccl-direct"
             except Exception as e:  # stay functional on the well-trodden torch.distributed path
                 import warnings
                 warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed collectives")
@@ -450,14 +452,17 @@ def _agree_stop(prob, scal) -> int:
 
 
 class DistPoissonProblem(DistProblem):
-    """bench.py workload: 5-point Poisson on a (nx_per_rank * world) x ny grid, b = ones, rank r owning
-    grid lines [r nx_per_rank, (r+1) nx_per_rank) -- requires ny * nx_per_rank to be chunk aligned, else
-    the chunk-aligned partition of RowPartition is used as is."""
+    """bench.py workloads: 5-point Poisson on an nx x ny grid (row k = i*ny + j), b = ones, rows split by RowPartition
+    (contiguous blocks on reduction-chunk boundaries of the GLOBAL problem -- a rank's block need not end on a grid line).
+      weak scaling   nx = nx_per_rank * world  (every rank about nx_per_rank grid lines: per-GPU work fixed)
+      strong scaling nx = nx_global            (BASELINE config 5: 8000 x 8000, N = 64 M, over 1/2/4/8 ranks)"""
 
-    def __init__(self, nx_per_rank: int, ny: int, rank: int, world: int, device, group=None, force_ch: int = 0):
+    def __init__(self, nx_per_rank: int = 0, ny: int = 0, rank: int = 0, world: int = 1, device=None, group=None,
+                 force_ch: int = 0, nx_global: int = 0):
         from .utils.matrix_utils import stencil5_csr_components
+        assert (nx_per_rank > 0) != (nx_global > 0), "give nx_per_rank (weak) or nx_global (strong)"
         ops = HipOps(device)
-        nx = nx_per_rank * world
+        nx = nx_global if nx_global > 0 else nx_per_rank * world
         part = RowPartition(nx * ny, world, rank, force_ch)
         crow, col, val = stencil5_csr_components(nx, ny, 4.0, -1.0, -1.0, -1.0, -1.0, row_begin=part.row0,
                                                  row_end=part.row1, device=device)

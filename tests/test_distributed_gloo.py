@@ -49,6 +49,8 @@ def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu"):
     (4, "poisson", 96, 64),       # rank 3 owns NO rows
     (2, "random_spd", 80, 77),    # 6160 rows (ragged last chunk), ghosts from arbitrary owners
     (3, "random_spd", 80, 77),
+    (2, "poisson", 4, 8000),      # BASELINE config 5's slab shape: 8000-wide grid lines, the halo is a whole grid line
+    (3, "poisson", 5, 8000),      #   and the block boundaries (chunk aligned) fall INSIDE grid lines
 ])
 def test_dist_cg_bitwise_equals_single_rank(world, kind, nx, ny, tmp_path):
     r = _run(world, kind, nx, ny, 1e-8, -1, tmp_path)
@@ -57,6 +59,8 @@ def test_dist_cg_bitwise_equals_single_rank(world, kind, nx, ny, tmp_path):
     assert set(r["iterations"]) == {r["ref_iterations"]}
     assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
     assert sum(r["n_local"]) == nx * ny and r["chunk"] == 2048
+    if ny == 8000:
+        assert r["n_ghost"] == 8000     # rank 0 needs exactly one grid line of its neighbour
 
 
 def test_dist_cg_maxiter_cutoff(tmp_path):
@@ -65,7 +69,8 @@ def test_dist_cg_maxiter_cutoff(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,nx,ny", [(2, "poisson", 96, 64), (3, "random_spd", 80, 77), (4, "poisson", 96, 64)])
+@pytest.mark.parametrize("world,kind,nx,ny", [(2, "poisson", 96, 64), (3, "random_spd", 80, 77), (4, "poisson", 96, 64),
+                                              (2, "poisson", 4, 8000)])
 def test_dist_cg_hip_kernels_multi_rank_on_one_gpu(world, kind, nx, ny, tmp_path):
     """The REAL step API (libhipk.so) under a multi-rank partition: ranks share cuda:0, collectives are staged
     through the host over gloo.  Must equal the single-rank oracle solve bit for bit."""
