@@ -30,6 +30,17 @@ def golden_runs(solver=None):
     return [r for r in runs if solver is None or r["solver"] == solver]
 
 
+def ldc100_runs():
+    """BASELINE config 4 at the reference's default size (nx = 100, Re = 400), oracle/gen_golden_r2.py."""
+    with open(os.path.join(GOLDEN, "ldc100_index.json")) as f:
+        return json.load(f)["runs"]
+
+
+def gmres_tol_runs():
+    with open(os.path.join(GOLDEN, "gmres_tol.json")) as f:
+        return json.load(f)["runs"]
+
+
 def load_case(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

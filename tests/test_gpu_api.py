@@ -108,7 +108,7 @@ def test_autograd_nonsymmetric_adjoint_uses_the_transpose(hipk, layout):
     assert (expect - wrong).norm() / expect.norm() > 1e-2
     for fn, kw in ((bicgstab, {}), (gmres, {"restart": 30})):
         b = torch.randn(n, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
-        x, info = fn(A, b, tol=1e-11, **kw)
+        x, info = fn(A, b, tol=1e-9, **kw)
         assert type(get_last_stats()).__name__ == "SolveStats"            # forward on the HIP path
         (x * gvec).sum().backward()
         assert type(get_last_stats()).__name__ == "SolveStats"            # adjoint solve on the HIP path as well
@@ -116,7 +116,7 @@ def test_autograd_nonsymmetric_adjoint_uses_the_transpose(hipk, layout):
         assert torch.allclose(b.grad, expect, rtol=1e-6, atol=1e-9), (fn.__name__, (b.grad - expect).norm() / expect.norm())
     for fn, kw in ((bicgstab_differentiable, {}), (gmres_differentiable, {"restart": 30})):
         b = torch.randn(n, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
-        (fn(A, b, tol=1e-11, **kw) * gvec).sum().backward()
+        (fn(A, b, tol=1e-9, **kw) * gvec).sum().backward()
         assert torch.allclose(b.grad, expect, rtol=1e-6, atol=1e-9), (fn.__name__, (b.grad - expect).norm() / expect.norm())
 
 
@@ -129,11 +129,11 @@ def test_forward_solve_with_a_transposed_view(hipk):
     g = torch.Generator().manual_seed(5)
     b = torch.randn(A.shape[0], dtype=torch.float64, generator=g).to(DEV)
     for M, Mt in ((A, A.T), (A_csr, A_csr.t())):
-        x1, i1 = bicgstab(M, b, tol=1e-11)
-        x2, i2 = bicgstab(Mt, b, tol=1e-11)
+        x1, i1 = bicgstab(M, b, tol=1e-9)
+        x2, i2 = bicgstab(Mt, b, tol=1e-9)
         assert i1 == 0 and i2 == 0
-        assert torch.allclose(x1, torch.linalg.solve(A, b), rtol=1e-7, atol=1e-10)
-        assert torch.allclose(x2, torch.linalg.solve(A.T, b), rtol=1e-7, atol=1e-10)
+        assert torch.allclose(x1, torch.linalg.solve(A, b), rtol=1e-6, atol=1e-9)
+        assert torch.allclose(x2, torch.linalg.solve(A.T, b), rtol=1e-6, atol=1e-9)
         assert (x1 - x2).norm() / x1.norm() > 1e-3
 
 

@@ -292,6 +292,57 @@ def test_fp32_solves_bit_exact_vs_fp32_oracle(hipk, oracle, case, solver, kw):
     assert st.residual_norm <= (20 if case.startswith("ldc") else 2) * tol * st.b_norm
 
 
+@pytest.mark.parametrize("step", [0, 1, 2])
+def test_config4_as_quoted_fp32_gmres30_ldc_nx100(hipk, oracle, step):
+    """BASELINE config 4 exactly as quoted: gmres(restart=30) on the LDC pressure system at the example's default
+    nx = 100 (Re = 400, FVM step `step`, recorded from the reference's BaseLDCSolver), fp32 storage, tol 1e-5 (the
+    documented fp32 tolerance: the true residual of an fp32 solve stalls near 5e-6 ||b|| here).
+    GPU == oracle32 bit for bit; x within 2e-3 of the reference's fp64 solution (modulo the null-space constant)."""
+    from pytorch_sparse_solver.module_a import get_last_stats, gmres
+    d = load_case(f"ldc_nx100_step{step}")
+    x, info = gmres(_dev_csr32(d), torch.from_numpy(d["b"]).to(DEV), tol=1e-5, restart=30, maxiter=1000)
+    st = get_last_stats()
+    ref = oracle.gmres32(d["crow"], d["col"], d["val"], d["b"].astype(np.float32), tol=1e-5, restart=30, maxiter=1000,
+                         gpu_tolerances=True)
+    assert x.dtype == torch.float32 and info == ref.info == 0
+    assert (st.iterations, st.matvecs, st.residual_norm) == (ref.iterations, ref.matvecs, ref.residual_norm)
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    xs, xr = x.double().cpu().numpy(), d["gmres_batched_x"]
+    assert np.linalg.norm((xs - xs.mean()) - (xr - xr.mean())) <= 2e-3 * np.linalg.norm(xr - xr.mean())
+    assert st.residual_norm <= 1e-5 * st.b_norm
+
+
+def _ldc100():
+    from conftest import ldc100_runs
+    return ldc100_runs()
+
+
+@pytest.mark.parametrize("r", _ldc100(), ids=lambda r: f"{r['case']}-{r['tag']}")
+def test_config4_fp64_against_reference_fixture_at_nx100(hipk, oracle, r):
+    """The reference's own nx = 100 runs (ldc_solver_module_a.py:19-21 call) in fp64: GPU == oracle bit for bit, same info,
+    x to 1e-8 of the reference's; GMRES needs at most the reference's operator applications (GPU tolerance branch,
+    TSL:737-740), BiCGStab within the chaotic band."""
+    from pytorch_sparse_solver.module_a import bicgstab, get_last_stats, gmres
+    d = load_case(r["case"])
+    A = torch.sparse_csr_tensor(torch.from_numpy(d["crow"]).long(), torch.from_numpy(d["col"]).long(),
+                                torch.from_numpy(d["val"]), size=(int(d["n"]),) * 2).to(DEV)
+    b = torch.from_numpy(d["b"]).to(DEV)
+    kw = dict(r["kwargs"])
+    x, info = {"gmres": gmres, "bicgstab": bicgstab}[r["solver"]](A, b, **kw)
+    st = get_last_stats()
+    okw = dict(kw, gpu_tolerances=True) if r["solver"] == "gmres" else kw
+    ref = getattr(oracle, r["solver"])(d["crow"], d["col"], d["val"], d["b"], **okw)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs) and info == r["info"]
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    xs, xr = x.cpu().numpy(), d[r["tag"] + "_x"]
+    if r["solver"] == "gmres":
+        assert st.matvecs <= r["matvecs"]
+        assert np.linalg.norm((xs - xs.mean()) - (xr - xr.mean())) <= 1e-7 * np.linalg.norm(xr)
+    else:
+        assert abs(st.matvecs - r["matvecs"]) <= 0.15 * r["matvecs"]
+    assert st.residual_norm <= 1e-10 * st.b_norm * 10
+
+
 # ---------------------------------------------------------------- BASELINE's full sizes against the reference itself
 def _big_runs():
     import json
