@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HIPK_VERSION 100
+#define HIPK_VERSION 200
 
 typedef struct hipk_csr_s *hipk_csr_t;
 typedef void *hipk_stream_t; /* hipStream_t */
@@ -126,6 +126,16 @@ int hipk_csr_spmv_path(hipk_csr_t h);
 int hipk_csr_set_path(hipk_csr_t h, int mode);
 /* Bytes one SpMV has to move in the format the selected path streams (= hipk_csr_spmv_bytes unless CODED). */
 int64_t hipk_csr_format_bytes(hipk_csr_t h);
+
+/* ---- transpose (adjoint solves) ------------------------------------------------
+ * The implicit-diff backward of the reference solves with A^T (`ImplicitAdjointFunction.backward`, TSL:1237-1248; `A.T`,
+ * TSL:1245).  hipk_csr_transpose writes the CSR arrays of A^T -- int32 row pointers [n_cols + 1], int32 columns [nnz]
+ * sorted within each row, values [nnz] of the handle's dtype -- into caller-owned device buffers, from which a handle
+ * for A^T is created with hipk_csr_create (idx_bytes 4).  Device-side stable sort by column; `work` >=
+ * hipk_csr_transpose_work_bytes(h), 256-byte aligned.  Setup step, not on the per-iteration path. */
+size_t hipk_csr_transpose_work_bytes(hipk_csr_t h);
+int hipk_csr_transpose(hipk_csr_t h, int32_t *crow_t_dev, int32_t *col_t_dev, void *val_t_dev, void *work,
+                       size_t work_bytes, hipk_stream_t stream);
 
 /* ---- reduction geometry ------------------------------------------------------
  * Every dot/norm is a two-level fixed tree: the vector is cut in `count` chunks

@@ -27,6 +27,7 @@ SYMBOLS = [
     "hipk_version", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
+    "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
     "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve", "hipk_pbicgstab_solve_cb", "hipk_pgmres_solve_cb",
@@ -131,6 +132,9 @@ def lib():
     for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes, L.hipk_csr_format_bytes):
         f.argtypes = [vp]
         f.restype = i64
+    L.hipk_csr_transpose_work_bytes.argtypes = [vp]
+    L.hipk_csr_transpose_work_bytes.restype = ctypes.c_size_t
+    L.hipk_csr_transpose.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.hipk_csr_spmv_path.argtypes = [vp]
     L.hipk_csr_set_path.argtypes = [vp, i32]
     L.hipk_chunk_size.argtypes = [i64]
@@ -282,6 +286,28 @@ class CsrHandle:
             b += max(0, self.format_bytes() - 2 * n * sv)
         return int(b)
 
+    def transposed(self) -> "CsrHandle":
+        """Handle of A^T, built on the device from this handle's int32 arrays (hipk_csr_transpose: stable sort of the entries
+        by column, so the rows of A^T come out column-sorted) and cached here: the adjoint solve of every backward pass
+        reuses it (`ImplicitAdjointFunction.backward`, TSL:1237-1248)."""
+        ht = getattr(self, "_transposed", None)
+        if ht is not None:
+            return ht
+        L = lib()
+        n_rows, n_cols = self.shape
+        with torch.cuda.device(self.device):
+            crow_t = torch.empty(n_cols + 1, dtype=torch.int32, device=self.device)
+            col_t = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)[:self.nnz]
+            val_t = torch.empty(max(self.nnz, 1), dtype=self.dtype, device=self.device)[:self.nnz]
+            wb = int(L.hipk_csr_transpose_work_bytes(self._h))
+            work = torch.empty(wb, dtype=torch.uint8, device=self.device)
+            _check(L.hipk_csr_transpose(self._h, crow_t.data_ptr(), col_t.data_ptr(), val_t.data_ptr(), work.data_ptr(), wb,
+                                        _stream(self.device)), "hipk_csr_transpose")
+            ht = CsrHandle(crow_t, col_t, val_t, (n_cols, n_rows))
+        del work
+        self._transposed = ht
+        return ht
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             try:
@@ -360,6 +386,19 @@ def handle_for(A: torch.Tensor) -> CsrHandle:
         _CACHE.move_to_end(key)
         return hit[0]
     src = A.detach()
+    # transposed views (what the adjoint solve of the implicit-diff backward passes, TSL:1245): the handle of the base
+    # matrix, transposed on the device -- no torch CSC -> CSR re-conversion, no second dense -> CSR pass
+    if src.layout == torch.sparse_csc and src.dim() == 2:
+        base = torch.sparse_csr_tensor(src.ccol_indices(), src.row_indices(), src.values(),
+                                       size=(src.shape[1], src.shape[0]), check_invariants=False)
+        h = handle_for(base).transposed()
+        _store(key, h, src)
+        return h
+    if (src.layout == torch.strided and src.dim() == 2 and not src.is_contiguous() and src.t().is_contiguous()
+            and not src.is_conj() and not src.is_neg()):
+        h = handle_for(src.t()).transposed()
+        _store(key, h, src)
+        return h
     if src.layout == torch.sparse_csr:
         csr = src
     elif src.layout == torch.sparse_coo:

@@ -137,6 +137,45 @@ def test_forward_solve_with_a_transposed_view(hipk):
         assert (x1 - x2).norm() / x1.norm() > 1e-3
 
 
+@pytest.mark.parametrize("kind", ["convdiff", "random", "dense", "empty_rows", "fp32"])
+def test_native_transpose_handle_bit_exact(hipk, oracle, kind):
+    """A^T built on the device from the handle's own arrays (hipk_csr_transpose).  Its SpMV must equal
+    the oracle SpMV of the explicit, column-sorted transpose BIT FOR BIT (so the rows of A^T are sorted like torch's CSR)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    if kind == "convdiff":
+        A = _convdiff(40).cpu()
+        M = sp.csr_matrix((A.values().numpy(), A.col_indices().numpy(), A.crow_indices().numpy()), shape=tuple(A.shape))
+    elif kind == "dense":
+        M = sp.csr_matrix(rng.standard_normal((300, 300)))
+    elif kind == "empty_rows":
+        M = sp.random(700, 700, density=0.004, random_state=3, format="csr")     # many empty rows and columns
+    else:
+        M = sp.random(3000, 3000, density=0.003, random_state=5, format="csr") + sp.eye(3000, format="csr") * 3.0
+    M = M.tocsr()
+    M.sort_indices()
+    dt = np.float32 if kind == "fp32" else np.float64
+    M = M.astype(dt)
+    A = torch.sparse_csr_tensor(torch.from_numpy(M.indptr.astype(np.int64)), torch.from_numpy(M.indices.astype(np.int64)),
+                                torch.from_numpy(M.data), size=M.shape).to(DEV)
+    hipk.clear_cache()
+    h = hipk.handle_for(A)
+    ht = h.transposed()
+    assert ht is h.transposed() and ht.shape == (M.shape[1], M.shape[0]) and ht.nnz == M.nnz
+    Mt = M.T.tocsr()
+    Mt.sort_indices()
+    assert np.array_equal(ht.crow.cpu().numpy(), Mt.indptr) and np.array_equal(ht.col.cpu().numpy(), Mt.indices)
+    assert np.array_equal(ht.val.cpu().numpy(), Mt.data)
+    x = rng.standard_normal(M.shape[0]).astype(dt)
+    y = hipk.spmv(ht, torch.from_numpy(x).to(DEV)).cpu().numpy()
+    spmv = oracle.spmv32 if kind == "fp32" else oracle.spmv
+    assert np.array_equal(y, spmv(Mt.indptr.astype(np.int32), Mt.indices.astype(np.int32), Mt.data, x))
+    # the views torch hands to the adjoint solve resolve to the same cached transposed handle (no re-conversion)
+    assert hipk.handle_for(A.t()) is ht
+    Ad = A.to_dense()
+    assert hipk.handle_for(Ad.T) is hipk.handle_for(Ad).transposed()
+
+
 def test_dispatcher_on_gpu(hipk):
     from pytorch_sparse_solver import SparseSolver, solve
     A, g = _spd(100)
