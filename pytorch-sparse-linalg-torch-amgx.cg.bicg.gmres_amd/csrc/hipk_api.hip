@@ -556,6 +556,16 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (chunked) {
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
                 lgrid = hipk_xcd_grid(a.g);
+                // pair codes with an exact tile size: two tiles per loop trip (hipk_spmv_sell_pair_kernel)
+                static const bool no_pair = getenv("HIPK_SPMV_SELL_NO_PAIR") != nullptr;
+                if (!no_pair && h->coded_layout == 2 && (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8)) {
+#define HIPK_PICK_PAIR_U(T, U) \
+    (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
+#define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
+                    kern = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+#undef HIPK_PICK_PAIR
+#undef HIPK_PICK_PAIR_U
+                }
             } else {
                 lgrid = slots * h->sell_loop;
                 if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;

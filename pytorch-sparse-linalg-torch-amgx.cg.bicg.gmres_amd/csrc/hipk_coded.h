@@ -715,4 +715,159 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         }
     }
 }
+// ------------------------------------------------------------------ chunk per workgroup, TWO tiles per loop trip
+// The persistent kernel above spends one x-gather round trip (~2.5 us at full occupancy) PER TILE per workgroup and about
+// 250 executed instructions per tile and wavefront, a fifth of them register copies of the software pipeline
+// (`rc = rn`) and hazard no-ops between the dependent DPP steps of the fused dot's wavefront sum: with one wave of
+// workgroups (one reduction chunk = 8 tiles each at N = 4 M) the kernel lasts 8 round trips.  Here the workgroup takes its
+// tiles in PAIRS: both tiles' gathers (2 x NE loads per thread) are in flight together, their row sums and wavefront
+// sums are independent instruction streams the scheduler interleaves (no idle hazard slots), and the loop is unrolled over
+// two pairs so that the prefetched requests change roles instead of being copied.  Same arithmetic per row, same tile /
+// chunk folds: same bits.  Pair codes only (VALS = false), exact tile sizes (UNITS = 4, 5, 8), chunks of <= 64 tiles.
+template <typename T, int UNITS, bool UNI>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_spmv_args a) {
+    constexpr int G0 = (UNITS + 3) / 4;
+    constexpr int NE = UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8);
+    static_assert(UNITS == 4 || UNITS == 5 || UNITS == 8, "exact tile sizes only");
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tpc = a.ch / HIPK_TILE;
+    const int chunk = hipk_xcd_chunk(blockIdx.x, a.g);
+    if (chunk < 0) return;
+    const int t_first = chunk * tpc;
+    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;
+    __shared__ double wsum0[HIPK_SELL_MAX_TPC * 4];
+    __shared__ double wsum1[HIPK_SELL_MAX_TPC * 4];
+    __shared__ T dval[HIPK_CODED_MAX];
+    __shared__ int doff[HIPK_CODED_MAX];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned char *__restrict__ code = a.code;
+    const char *__restrict__ xb = (const char *)a.x;
+    T *__restrict__ y = (T *)a.y;
+    const int mode = a.mode;
+    const int n32 = (int)a.n;
+    const unsigned long long *__restrict__ ucode = a.tile_ucode;
+
+    T dv = (T)0;
+    int dofs = 0;
+    if (t < a.n_codes) {
+        dv = ((const T *)a.dict_val)[t];
+        dofs = a.dict_off[t];
+    }
+    struct req_t {
+        unsigned c[G0];
+        T w, b, d;
+    };
+    auto request = [&](int tl, req_t &q) {  // tile tl's code groups and epilogue operands
+        unsigned long long uc = 0ull;
+        if (UNI) {
+            const unsigned long long u = ucode[tl];  // wave-uniform: scalar load
+            uc = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)u) |
+                 ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32);
+        }
+        if (UNI && uc != 0ull) {
+            q.c[0] = (unsigned)uc;
+            if (G0 > 1) q.c[G0 - 1] = (unsigned)(uc >> 32);
+        } else {
+            const unsigned char *tp = code + (size_t)tl * (UNITS * HIPK_TILE);
+            constexpr int D = UNITS >> 2, Bp = UNITS & 3;
+#pragma unroll
+            for (int g = 0; g < G0; ++g) {
+                unsigned wv = 0xFFFFFFFFu;
+                if (g < D) {
+                    wv = ((const unsigned *)tp)[g * HIPK_TILE + t];
+                } else {
+                    const unsigned char *bp = tp + (size_t)D * 1024 + t;
+                    if (Bp >= 1) wv = (wv & 0xFFFFFF00u) | bp[0];
+                    if (Bp >= 2) wv = (wv & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
+                }
+                q.c[g] = wv;
+            }
+        }
+        const int row = tl * HIPK_TILE + t;
+        q.w = (T)0;
+        q.b = (T)0;
+        q.d = (T)0;
+        if (row < n32) {
+            if (mode & HIPK_SPMV_DOT_W) q.w = ((const T *)a.w)[row];
+            if (mode & HIPK_SPMV_RESID) q.b = ((const T *)a.bsub)[row];
+            if (mode & HIPK_SPMV_SCALE) q.d = ((const T *)a.dscale)[row];
+        }
+    };
+    auto gather = [&](const req_t &q, int tl, T(&xv)[NE]) {
+        const int row = tl * HIPK_TILE + t;
+        const int rowx = row < n32 ? row : n32 - 1;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (q.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
+            xv[k] = *(const T *)(xb + bo);
+        }
+    };
+    auto finish = [&](const req_t &q, int tl, const T(&xv)[NE]) {
+        const int row = tl * HIPK_TILE + t;
+        T s = (T)0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (q.c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const T p = dval[ck] * xv[k];
+            const T s1 = s + p;
+            s = (ck != HIPK_SELL_PAD) ? s1 : s;
+        }
+        double d0 = 0.0, d1 = 0.0;
+        if (row < n32) {
+            T out = s;
+            if (mode & HIPK_SPMV_RESID) out = q.b - out;
+            if (mode & HIPK_SPMV_SCALE) out = q.d * out;
+            y[row] = out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)q.w * (double)out;
+            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+        }
+        const int slot = (tl - t_first) * 4 + wave;
+        if (mode & HIPK_SPMV_DOT_W) {
+            d0 = hipk_wave_sum(d0);
+            if (lane == 0) wsum0[slot] = d0;
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+            d1 = hipk_wave_sum(d1);
+            if (lane == 0) wsum1[slot] = d1;
+        }
+    };
+    // one trip: gathers of the pair (ca, cb) = tiles tp, tp + 1 | requests of the next pair into (na, nb) | finish the pair
+    auto trip = [&](req_t &ca, req_t &cb, req_t &na, req_t &nb, int tp) {
+        const bool hb = tp + 1 < t_end;
+        T xa[NE], xbv[NE];
+        gather(ca, tp, xa);
+        if (hb) gather(cb, tp + 1, xbv);
+        if (tp + 2 < t_end) request(tp + 2, na);
+        if (tp + 3 < t_end) request(tp + 3, nb);
+        finish(ca, tp, xa);
+        if (hb) finish(cb, tp + 1, xbv);
+    };
+
+    req_t r0, r1, r2, r3;
+    if (t_first < t_end) request(t_first, r0);
+    if (t_first + 1 < t_end) request(t_first + 1, r1);
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
+    doff[t] = dofs;
+    __syncthreads();
+    for (int tp = t_first; tp < t_end; tp += 4) {
+        trip(r0, r1, r2, r3, tp);
+        if (tp + 2 < t_end) trip(r2, r3, r0, r1, tp + 2);
+    }
+    if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+        __syncthreads();
+        if (wave == 0) {
+            const int cnt = t_end - t_first;
+            if (mode & HIPK_SPMV_DOT_W) {
+                const double r = hipk_wave_fold(wsum0, cnt, lane);
+                if (lane == 0) a.part0[chunk] = r;
+            }
+            if (mode & HIPK_SPMV_DOT_YY) {
+                const double r = hipk_wave_fold(wsum1, cnt, lane);
+                if (lane == 0) a.part1[chunk] = r;
+            }
+        }
+    }
+}
 #endif

@@ -49,6 +49,9 @@ struct hipk_gm_scal {
     double beta_vec[HIPK_GM_LDH + 1];
     double hvec[HIPK_GM_LDH];
     double rvec[HIPK_GM_LDH];
+    int32_t bar;        // counter barrier of hipk_gm_cycle_small_kernel (zeroed by hipk_gm_cycle_init_kernel)
+    int32_t redo;       // speculation miss: a second CGS pass was wanted at a step whose pass-2 launches were not enqueued
+    int64_t redo_step;
 };
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
@@ -388,6 +391,121 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_sc
     }
 }
 
+
+// =====================================================================================================================
+// Large systems: the Krylov basis (31 x 32 MB at N = 4 M) is far larger than the 256 MiB Infinity Cache and every Arnoldi
+// step reads its live columns twice (h = V^H w, then q = w - V h, with a global reduction in between).  Measured on
+// MI355X (profiles/r02_gmres_history.md):
+//  * STREAMING POLICY.  Basis columns >= `nres` are loaded NON-TEMPORAL: they pass through without displacing what is
+//    re-read soon (w, the first `nres` columns, the SpMV's operands).  8.15 -> 6.80 ms per GMRES(30) cycle at N = 4 M.
+//  * tried and rejected: chunk-major sweeps with alternating direction (the turn-around hits of the Infinity Cache bought
+//    nothing measurable: MALL-served reads are only ~1.4x faster than HBM reads) and last-arriver folds of the partial sums
+//    inside the kernels (ticket atomics + write-through stores per workgroup: +1.3 ms per cycle).
+// The order of operations per element (columns ascending) is the spec's: same bits as the kernels above.
+__device__ __forceinline__ void hipk_publish(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double hipk_peek(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// part[j*MAXP + c] = chunk partial of <V_j, w>.  grid = g * (k/8 + 1): workgroup b takes chunk b % g of column group b / g.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_stream_kernel(
+    int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    const T *__restrict__ w, double *__restrict__ part, int g, int nres) {
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    const int grp = blockIdx.x / g, c = blockIdx.x % g;
+    __shared__ double sbuf[8 * HIPK_THREADS];
+    const int j0 = 8 * grp;
+    double acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+    hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+        hipk_ld<T>(w, i, nv, wv);
+        T vv[8][VEC];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) {
+                if (j0 + b < nres) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+                else hipk_ld_nt_vec<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+            }
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (e < nv) acc[b] = fma((double)vv[b][e], (double)wv[e], acc[b]);
+            }
+    });
+    hipk_block_sum8(acc, 8, sbuf);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = acc[b];
+    }
+}
+
+// q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305).  grid = g.
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_stream_kernel(
+    int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
+    T *__restrict__ w, double *__restrict__ part_qq, int nres) {
+    if (k >= scal->stop_step) return;
+    if (pass == 1 && !scal->pass2) return;
+    const int c = blockIdx.x;
+    __shared__ double sbuf[HIPK_THREADS];
+    __shared__ double hs[HIPK_GM_LDH];
+    if (threadIdx.x < HIPK_GM_LDH) hs[threadIdx.x] = (threadIdx.x <= k) ? scal->hvec[threadIdx.x] : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+        hipk_ld<T>((const T *)w, i, nv, wv);
+        double s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < HIPK_GM_LDH; j0 += 8) {  // batches of eight column loads, then their FMAs in column order
+            if (j0 <= k) {
+                T vv[8][VEC];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) {
+                        if (j0 + b < nres) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+                        else hipk_ld_nt_vec<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+                    }
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b <= k) {
+                        const double hj = hs[j0 + b];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[b][e], hj, s[e]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            wv[e] = (T)((double)wv[e] - s[e]);
+            if (e < nv) acc = fma((double)wv[e], (double)wv[e], acc);
+        }
+        hipk_st<T>(w, i, nv, wv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) {
+        part_qq[c] = acc;
+        if (c == 0) {
+            for (int j = 0; j <= k; ++j) scal->rvec[j] = ((pass == 0) ? 0.0 : scal->rvec[j]) + hs[j];
+        }
+    }
+}
+
 __device__ __forceinline__ void hipk_givens(double a, double b, double &cs, double &sn) {  // TSL:508-518
     if (fabs(b) == 0.0) {
         cs = 1.0;
@@ -412,7 +530,7 @@ __device__ __forceinline__ void hipk_givens(double a, double b, double &cs, doub
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     int64_t n, int ch, int g, hipk_gm_scal *__restrict__ scal, int k, T *__restrict__ w,
-    const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps, int small_ntiles) {
+    const double *__restrict__ part_qq, const double *__restrict__ part_ww, double eps, int small_ntiles, int guard = 0) {
     hipk_pre<T, 1> pre;  // w travels while the stop word is read and the partials are folded
     pre.issue(n, ch, blockIdx.x, {(const T *)w});
     if (k >= scal->stop_step) return;
@@ -423,6 +541,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
         qq = hipk_reduce_parts(part_qq, g, sbuf);
     } else {
         hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
+    }
+    if (guard) {
+        // SPECULATION: the host did not enqueue this step's second-pass launches (it happens about once per cycle, at the
+        // steps the host predicts).  Every workgroup takes the CGS2 decision (TSL:313-326) from the same partials; if the
+        // pass was wanted after all, nothing is stored: the step is stopped and reported, the host re-enqueues the cycle
+        // from this step with the second pass in place.
+        double qnorm;
+        if (hipk_gm_want_pass2(scal, k, qq, eps, &qnorm)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                scal->redo = 1;
+                scal->redo_step = k;
+                scal->stop_step = k;   // this launch's other workgroups compare k >= stop_step too: they return either way
+            }
+            return;
+        }
     }
     double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
     double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
@@ -483,6 +616,392 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     }
 }
 
+// =====================================================================================================================
+// Small systems (<= 8 reduction chunks of 2048 rows, n <= 16384; rows of <= 32 entries): ONE LAUNCH PER RESTART CYCLE.
+// The LDC pressure solve of the reference's example (ldc_solver_module_a.py:17-22: n = 10^4, gmres(restart=30)) is launch
+// bound: 6 launches of >= 4.9 us per Arnoldi step for a few hundred KB of traffic.  Here one workgroup PER CHUNK (1024
+// threads fp64 / 512 fp32: one 256-thread group per chunk-loop step, the wide form above) stays resident for the whole
+// cycle and the workgroups meet at a counter barrier between the phases of a step:
+//     A  w = (M) A v_k on the own rows (CSR, thread per row; per-wavefront sums of <w,w>) | multi-dot partials | barrier
+//     B  h = fold of the partials | q = w - V h on the own chunk, <q,q> partial                                 | barrier
+//     C  CGS2 decision (every workgroup, same bits) [| pass 2: A', B' with two more barriers]
+//        | v_{k+1} = q / ||q|| on the own chunk | workgroup 0: H column, Givens, breakdown / early exit           | barrier
+// Cross-workgroup data (partials, the new basis vector that the next SpMV gathers, the stop word) is stored write-through
+// (sc1) and drained before the arrival, and read with sc1 loads (cdna guide, G16: no fence needed for this hand-off form);
+// a workgroup's own chunk of w / V is only ever touched by itself.  All workgroups are placed on ONE XCD (only blocks with
+// blockIdx.x % 8 == 0 work: round-robin dispatch; speed only).  Arithmetic = the multi-launch small-system path, bit for bit.
+template <typename T>
+struct hipk_gm_cyc_args {
+    int64_t n;
+    int g, m;
+    hipk_gm_scal *scal;
+    T *V;
+    int64_t ldv;
+    const int *crow;
+    const int *col;
+    const T *val;
+    const T *dscale;   // left Jacobi preconditioning (HIPK_SPMV_SCALE), or null
+    double *part_md;   // [m + 1][HIPK_MAX_PARTS]
+    double *part_qq;   // [HIPK_MAX_PARTS]
+    double *tile_ww;   // [ntiles * 4] per-wavefront sums of <w,w>
+    int32_t *bar;      // barrier counter, zeroed by hipk_gm_cycle_init_kernel
+    double eps;
+    unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
+};
+
+template <typename T>
+__device__ __forceinline__ T hipk_peek_t(const T *p);
+template <>
+__device__ __forceinline__ double hipk_peek_t<double>(const double *p) { return hipk_peek(p); }
+template <>
+__device__ __forceinline__ float hipk_peek_t<float>(const float *p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void hipk_publish_t(double *p, double v) { hipk_publish(p, v); }
+__device__ __forceinline__ void hipk_publish_t(float *p, float v) {
+    __hip_atomic_store((unsigned *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// hipk_fold8 on partials another workgroup of THIS launch wrote
+__device__ __forceinline__ double hipk_fold8_sc1(const double *part, int g) {
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.0 + ((i < g) ? hipk_peek(part + i) : 0.0);
+    return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+// hipk_wave_fold / hipk_fold_tiles8 with sc1 loads; any number of wavefronts may call (all threads must)
+__device__ __forceinline__ double hipk_wave_fold_sc1(const double *tp, int cnt, int lane) {
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = lane + 64 * j;
+        double acc = 0.0;
+        for (int i = t; i < cnt; i += HIPK_THREADS) {
+            const double *w4 = tp + (size_t)i * 4;
+            const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+            acc = acc + ((w0 + w1) + (w2 + w3));
+        }
+        a[j] = acc;
+    }
+    a[0] = a[0] + a[2];
+    a[1] = a[1] + a[3];
+    double v = a[0] + a[1];
+    v = hipk_wave_sum(v);
+    return v;
+}
+__device__ __forceinline__ double hipk_fold_tiles8_sc1(const double *tp, int ntiles, int tpc, int g, double *cp, int nwaves) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < 8; c += nwaves) {
+        double r = 0.0;
+        if (c < g) {
+            const int first = c * tpc;
+            const int cnt = (ntiles - first < tpc) ? ntiles - first : tpc;
+            r = hipk_wave_fold_sc1(tp + (size_t)first * 4, cnt, lane);
+        }
+        if (lane == 0) cp[c] = r;
+    }
+    __syncthreads();
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.0 + ((i < g) ? cp[i] : 0.0);
+    const double v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+    __syncthreads();
+    return v;
+}
+// counter barrier of the `nwg` resident workgroups; false when the spin bound was hit (another workgroup never arrived)
+__device__ __forceinline__ bool hipk_gbar(int32_t *ctr, int nwg, int &epoch, int *fail_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront: its (sc1) stores have left
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = epoch * nwg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 25)) {  // seconds: a workgroup of this launch is not running
+                *fail_lds = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return *fail_lds == 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cycle_small_kernel(hipk_gm_cyc_args<T> a) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr int NTH = HIPK_BASE_CHUNK / VEC;       // threads per workgroup
+    constexpr int NIT = NTH / HIPK_THREADS;          // 256-thread groups = chunk-loop steps
+    constexpr int NW = NTH / 64;
+    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
+    const int c = blockIdx.x >> 3;
+    const int g = a.g;
+    if (c >= g) return;
+    hipk_gm_scal *scal = a.scal;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = tid & (HIPK_THREADS - 1), q = tid / HIPK_THREADS;
+    const int64_t n = a.n;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t end = (base + HIPK_BASE_CHUNK < n) ? base + HIPK_BASE_CHUNK : n;
+    const int64_t ei = base + (int64_t)VEC * t + (int64_t)q * VEC * HIPK_THREADS;   // this thread's element group
+    const int nv = (ei < end) ? ((end - ei < VEC) ? (int)(end - ei) : VEC) : 0;
+    const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    const int *__restrict__ crow = a.crow;
+    const int *__restrict__ col = a.col;
+    const T *__restrict__ val = a.val;
+
+    __shared__ double chain[8 * HIPK_THREADS];
+    __shared__ double hs[HIPK_GM_LDH];
+    __shared__ double rv[HIPK_GM_LDH];
+    __shared__ double cp[8];
+    __shared__ double bc[2];
+    __shared__ int fail;
+    __shared__ long long stop_lds;
+    if (tid == 0) fail = 0;
+    if (tid < HIPK_GM_LDH) rv[tid] = 0.0;
+    __syncthreads();
+    int epoch = 0;
+    long long stop = a.m;
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamping = a.stamps != nullptr && c == 0 && tid == 0;
+#define HIPK_STAMP(slot)                                              \
+    if (stamping) {                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        t_acc[slot] += now_ - t_prev;                                 \
+        t_prev = now_;                                                \
+    }
+    if (stamping) t_prev = __builtin_amdgcn_s_memtime();
+
+    for (int k = 0; k < a.m && k < stop; ++k) {
+        const T *vk = a.V + (int64_t)k * a.ldv;
+        T *w = a.V + (int64_t)(k + 1) * a.ldv;
+        // ---------------- A: w = (M) A v_k on the own rows, per-wavefront sums of <w,w>
+#pragma unroll
+        for (int i = 0; i < HIPK_BASE_CHUNK / NTH; ++i) {
+            const int64_t r = base + (int64_t)i * NTH + tid;
+            T out = (T)0;
+            if (r < n) {
+                const int lo = crow[r], hi = crow[r + 1];
+                T s = (T)0;
+                for (int j = lo; j < hi; ++j) {
+                    const T p = val[j] * hipk_peek_t<T>(vk + col[j]);
+                    s = s + p;
+                }
+                out = s;
+                if (a.dscale) out = a.dscale[r] * out;
+                w[r] = out;
+            }
+            double d1 = (r < n) ? (double)out * (double)out : 0.0;
+            d1 = hipk_wave_sum(d1);
+            const int64_t rf = r - lane;   // first row of this wavefront's 64
+            if (lane == 0 && rf / HIPK_TILE < ntiles) hipk_publish(&a.tile_ww[(size_t)(rf / HIPK_TILE) * 4 + (rf % HIPK_TILE) / 64], d1);
+        }
+        __syncthreads();   // w is read below by other threads of this workgroup
+        HIPK_STAMP(0)
+        for (int pass = 0; pass < 2; ++pass) {
+            // ---------------- multi-dot partials of the own chunk (wide form: group qq owns chunk-loop step qq)
+            T wv[VEC];
+            if (nv > 0) hipk_ld<T>((const T *)w, ei, nv, wv);
+            for (int j0 = 0; j0 <= k; j0 += 8) {
+                T vv[8][VEC];
+                if (nv > 0) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j0 + b <= k) hipk_ld<T>(a.V + (int64_t)(j0 + b) * a.ldv, ei, nv, vv[b]);
+                }
+#pragma unroll
+                for (int qq = 0; qq < NIT; ++qq) {
+                    if (q == qq) {
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            double acc = (qq == 0) ? 0.0 : chain[b * HIPK_THREADS + t];
+                            if (j0 + b <= k) {
+#pragma unroll
+                                for (int e = 0; e < VEC; ++e)
+                                    if (e < nv) acc = fma((double)vv[b][e], (double)wv[e], acc);
+                            }
+                            chain[b * HIPK_THREADS + t] = acc;
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (tid < 128) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) chain[b * HIPK_THREADS + tid] = chain[b * HIPK_THREADS + tid] + chain[b * HIPK_THREADS + tid + 128];
+                }
+                __syncthreads();
+                if (tid < 64) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        double v = chain[b * HIPK_THREADS + tid] + chain[b * HIPK_THREADS + tid + 64];
+                        v = hipk_wave_sum(v);
+                        if (tid == 0 && j0 + b <= k) hipk_publish(&a.part_md[(size_t)(j0 + b) * HIPK_MAX_PARTS + c], v);
+                    }
+                }
+                __syncthreads();
+            }
+            HIPK_STAMP(1)
+            if (!hipk_gbar(a.bar, g, epoch, &fail)) {
+                if (tid == 0) scal->redo = -1;
+                return;
+            }
+            HIPK_STAMP(2)
+            // ---------------- B: h = fold of the partials; q = w - V h on the own chunk; <q,q> partial
+            if (tid < HIPK_GM_LDH) {
+                const double hj = (tid <= k) ? hipk_fold8_sc1(a.part_md + (size_t)tid * HIPK_MAX_PARTS, g) : 0.0;
+                hs[tid] = hj;
+                rv[tid] = ((pass == 0) ? 0.0 : rv[tid]) + hj;   // rvec += h (TSL:305), kept by every workgroup
+            }
+            __syncthreads();
+            if (nv > 0) {
+                double sacc[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sacc[e] = 0.0;
+                for (int j0 = 0; j0 <= k; j0 += 8) {
+                    T vv[8][VEC];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j0 + b <= k) hipk_ld<T>(a.V + (int64_t)(j0 + b) * a.ldv, ei, nv, vv[b]);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j0 + b <= k) {
+                            const double hj = hs[j0 + b];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) sacc[e] = fma((double)vv[b][e], hj, sacc[e]);
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wv[e] = (T)((double)wv[e] - sacc[e]);
+                hipk_st<T>(w, ei, nv, wv);
+            }
+#pragma unroll
+            for (int qq = 0; qq < NIT; ++qq) {   // the spec's per-thread <q,q> chain, one chunk-loop step per group
+                if (q == qq) {
+                    double acc = (qq == 0) ? 0.0 : chain[t];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (e < nv) acc = fma((double)wv[e], (double)wv[e], acc);
+                    chain[t] = acc;
+                }
+                __syncthreads();
+            }
+            if (tid < 128) chain[tid] = chain[tid] + chain[tid + 128];
+            __syncthreads();
+            if (tid < 64) {
+                double v = chain[tid] + chain[tid + 64];
+                v = hipk_wave_sum(v);
+                if (tid == 0) hipk_publish(&a.part_qq[c], v);
+            }
+            HIPK_STAMP(3)
+            if (!hipk_gbar(a.bar, g, epoch, &fail)) {
+                if (tid == 0) scal->redo = -1;
+                return;
+            }
+            HIPK_STAMP(4)
+            // ---------------- C: CGS2 decision (TSL:313-326), every workgroup from the same partials
+            if (pass == 1) break;
+            if (tid == 0) {
+                const double qq = hipk_fold8_sc1(a.part_qq, g);
+                double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+                if (!(qnorm > a.eps)) qnorm = 0.0;
+                double rr = 0.0;
+                for (int j = 0; j <= k; ++j) rr = fma(rv[j], rv[j], rr);
+                double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                if (!(rnorm > a.eps)) rnorm = 0.0;
+                bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            const bool want2 = bc[0] != 0.0;
+            __syncthreads();
+            if (!want2) break;
+        }
+        // ---------------- normalise: v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), TSL:358-387
+        const double ww = hipk_fold_tiles8_sc1(a.tile_ww, ntiles, HIPK_BASE_CHUNK / HIPK_TILE, g, cp, NW);
+        if (tid == 0) bc[1] = hipk_fold8_sc1(a.part_qq, g);
+        __syncthreads();
+        const double qq = bc[1];
+        double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
+        double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
+        if (!(norm0 > a.eps)) norm0 = 0.0;
+        const double thr = a.eps * norm0;
+        const bool use = norm1 > thr;
+        const T nrm = (T)norm1;
+        if (nv > 0) {
+            T qv[VEC];
+            hipk_ld<T>((const T *)w, ei, nv, qv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (e < nv) hipk_publish_t(w + ei + e, use ? qv[e] / nrm : (T)0);   // gathered by the other workgroups' next SpMV
+        }
+        if (c == 0 && tid == 0) {
+            if (!use) norm1 = 0.0;
+            double *H = scal->H;
+            for (int j = 0; j <= k; ++j) H[j * HIPK_GM_LDH + k] = rv[j];
+            H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+            scal->steps_done = k + 1;
+            bool stp = false;
+            if (norm1 == 0.0) {  // TSL:387
+                scal->breakdown = 1;
+                stp = true;
+            }
+            if (scal->incremental) {
+                double hc[HIPK_GM_LDH + 1];
+                for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * HIPK_GM_LDH + k];
+                for (int i = 0; i < k; ++i) {
+                    const double cs = scal->gv[2 * i], sn = scal->gv[2 * i + 1];
+                    const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+                    const double t0 = p0 - p1;
+                    const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
+                    hc[i + 1] = p2 + p3;
+                    hc[i] = t0;
+                }
+                double cs, sn;
+                hipk_givens(hc[k], hc[k + 1], cs, sn);
+                scal->gv[2 * k] = cs;
+                scal->gv[2 * k + 1] = sn;
+                {
+                    const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
+                    hc[k] = p0 - p1;
+                }
+                hc[k + 1] = 0.0;
+                for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
+                double *bv = scal->beta_vec;
+                const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
+                const double t0 = p0 - p1;
+                const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
+                bv[k + 1] = p2 + p3;
+                bv[k] = t0;
+                const double err = fabs(bv[k + 1]);
+                scal->err = err;
+                if (!(err > scal->ptol)) stp = true;  // TSL:591
+            }
+            if (stp) __hip_atomic_store((long long *)&scal->stop_step, (long long)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        HIPK_STAMP(5)
+        if (!hipk_gbar(a.bar, g, epoch, &fail)) {
+            if (tid == 0) scal->redo = -1;
+            return;
+        }
+        HIPK_STAMP(6)
+        if (tid == 0) stop_lds = __hip_atomic_load((const long long *)&scal->stop_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        stop = stop_lds;
+        __syncthreads();
+    }
+    if (stamping)
+        for (int i = 0; i < 8; ++i) a.stamps[i] += t_acc[i];
+#undef HIPK_STAMP
+}
+
+// after a speculation miss at step k (hipk_gm_normalize_kernel, guard): steps >= k of the cycle are enqueued again
+__global__ void hipk_gm_resume_kernel(hipk_gm_scal *__restrict__ scal) {
+    scal->stop_step = INT64_MAX;
+    scal->redo = 0;
+    scal->redo_step = -1;
+    scal->pass2 = 0;
+}
+
 __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int incremental, double ptol) {
     const int t = threadIdx.x;
     for (int i = t; i < (HIPK_GM_MAXM + 2) * HIPK_GM_LDH; i += blockDim.x) scal->H[i] = 0.0;
@@ -491,6 +1010,9 @@ __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int i
     for (int i = t; i < HIPK_GM_LDH * 2; i += blockDim.x) scal->gv[i] = 0.0;
     for (int i = t; i <= HIPK_GM_LDH; i += blockDim.x) scal->beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
     if (t == 0) {
+        scal->bar = 0;
+        scal->redo = 0;
+        scal->redo_step = -1;
         scal->stop_step = INT64_MAX;
         scal->steps_done = 0;
         scal->pass2 = 0;
@@ -517,7 +1039,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_xupdate_kernel(int64_t n
         for (int j = 0; j < HIPK_GM_LDH; ++j) {
             if (j < k) {
                 T vv[VEC];
-                hipk_ld<T>(V + (int64_t)j * ldv, i, nv, vv);
+                hipk_ld_nt_vec<T>(V + (int64_t)j * ldv, i, nv, vv);   // every column is read once: stream it
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], yy.y[j], s[e]);
             }
@@ -780,12 +1302,46 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     int64_t cycles = 0;
     const bool small = gm.g <= 8 && !getenv("HIPK_GMRES_NO_SMALL");  // launch-bound systems: fewer launches per step
     const bool wide = small && gm.ch == HIPK_BASE_CHUNK && !getenv("HIPK_GMRES_NO_WIDE");  // hipk_gm_update_wide_kernel
+    // small systems with short rows: the whole restart cycle in ONE launch (hipk_gm_cycle_small_kernel)
+    const bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    const bool stream_k = !small && !getenv("HIPK_GMRES_NO_STREAM");  // large systems: hipk_gm_*_stream_kernel
+    const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
+    // large systems: second-pass launches only at the steps where a second CGS pass is expected (step 0, then every step
+    // that ever asked for one in this solve); a miss is caught on the device and the cycle re-enqueued from that step
+    const bool spec = !small && env_int("HIPK_GM_SPEC", 1) != 0;
+    bool predict[HIPK_GM_LDH];
+    for (int j = 0; j < HIPK_GM_LDH; ++j) predict[j] = (j == 0) && env_int("HIPK_GM_SPEC", 1) != 2;  // 2: learn everything (tests)
     int happy = 0;
     int64_t prof_valid = 0;
     rc = HIPK_OK;
+    const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     while (cycles < maxiter && res_norm > atol_eff) {
         hipk_gm_cycle_init_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, incremental, ptol);
-        for (int k = 0; k < m; ++k) {
+        int k_start = 0;
+      enqueue:
+        if (cyc) {
+            hipk_gm_cyc_args<T> ca;
+            ca.n = n;
+            ca.g = gm.g;
+            ca.m = m;
+            ca.scal = scal;
+            ca.V = V;
+            ca.ldv = ldv;
+            ca.crow = A->crow;
+            ca.col = A->col;
+            ca.val = (const T *)A->val;
+            ca.dscale = dinv;
+            ca.part_md = part_md;
+            ca.part_qq = part_qq;
+            ca.tile_ww = A->tile_part + 4 * (size_t)nt;
+            ca.bar = &scal->bar;
+            ca.eps = eps_t;
+            ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
+            if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 64, stream);
+            hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
+        }
+        for (int k = cyc ? m : k_start; k < m; ++k) {
             T *w = V + (int64_t)(k + 1) * ldv;
             hipk_spmv_args sw = sa;
             sw.x = V + (int64_t)k * ldv;
@@ -798,7 +1354,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             sw.it = k;
             if ((rc = hipk_launch_spmv(A, sw, stream, &prof)) != HIPK_OK) break;
             if (ext && (rc = precondition(w, part_ww)) != HIPK_OK) break;  // w = M(A v_k), ||w||^2 (TSL:351-352)
-            for (int pass = 0; pass < 2; ++pass) {
+            const int npass = (spec && !predict[k]) ? 1 : 2;
+            for (int pass = 0; pass < npass; ++pass) {
                 const dim3 mgrid(gm.g, k / 8 + 1);
                 if (small) {  // 7 instead of 10 launches per Arnoldi step (decide and the two hreduce folded away)
                     if (wide)
@@ -815,17 +1372,24 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                                                                                           part_qq, part_md, gm.g);
                 } else {
                     if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
-                    hipk_gm_multidot_kernel<T, false><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                          part_md, part_qq, gm.g, eps_t);
+                    if (stream_k)
+                        hipk_gm_multidot_stream_kernel<T><<<gm.g * (k / 8 + 1), HIPK_THREADS, 0, stream>>>(
+                            n, gm.ch, scal, k, pass, V, ldv, w, part_md, gm.g, gm_nres);
+                    else
+                        hipk_gm_multidot_kernel<T, false><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                              part_md, part_qq, gm.g, eps_t);
                     hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
-                    hipk_gm_update_kernel<T, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                       part_qq, part_md, gm.g);
+                    if (stream_k)
+                        hipk_gm_update_stream_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                            part_qq, gm_nres);
+                    else
+                        hipk_gm_update_kernel<T, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                           part_qq, part_md, gm.g);
                 }
             }
-            const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
             hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(
                 n, gm.ch, gm.g, scal, k, w, part_qq, (small && !ext) ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t,
-                (small && !ext) ? nt : 0);
+                (small && !ext) ? nt : 0, npass == 1 ? 1 : 0);
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -833,6 +1397,17 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             hipk_set_error("hipk_gmres_solve: HIP failure inside a restart cycle");
             rc = HIPK_ERR_HIP;
             break;
+        }
+        if (hs->redo < 0) {
+            hipk_set_error("hipk_gmres_solve: the resident workgroups of the small-system cycle kernel did not all arrive");
+            rc = HIPK_ERR_HIP;
+            break;
+        }
+        if (hs->redo > 0) {  // speculation miss: second pass wanted at redo_step; enqueue the cycle again from there
+            k_start = (int)hs->redo_step;
+            predict[k_start] = true;
+            hipk_gm_resume_kernel<<<1, 1, 0, stream>>>(scal);
+            goto enqueue;
         }
         const int k = (int)hs->steps_done;
         matvecs += k;
@@ -867,6 +1442,14 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     }
     free(hs);
     if (rc != HIPK_OK) return rc;
+    if (cyc && getenv("HIPK_GM_STAMPS")) {  // diagnostic build-in: where workgroup 0 of the cycle kernel spent its shader clocks
+        unsigned long long st8[8];
+        HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1024, sizeof(st8), hipMemcpyDeviceToHost, stream));
+        HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+        fprintf(stderr, "hipk_gm_cycle_small_kernel stamps (shader clocks, %lld cycles of %d steps): A spmv %llu | multidot %llu | bar1 %llu | "
+                        "B fold+update %llu | bar2 %llu | C decide+normalize %llu | bar3 %llu\n",
+                (long long)cycles, m, st8[0], st8[1], st8[2], st8[3], st8[4], st8[5], st8[6]);
+    }
 
     // TSL:766-773
     hipk_spmv_args sf = sr;

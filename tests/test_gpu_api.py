@@ -113,11 +113,11 @@ def test_autograd_nonsymmetric_adjoint_uses_the_transpose(hipk, layout):
         (x * gvec).sum().backward()
         assert type(get_last_stats()).__name__ == "SolveStats"            # adjoint solve on the HIP path as well
         assert info == 0
-        assert torch.allclose(b.grad, expect, rtol=1e-6, atol=1e-9), (fn.__name__, (b.grad - expect).norm() / expect.norm())
+        assert (b.grad - expect).norm() / expect.norm() < 1e-6, (fn.__name__, (b.grad - expect).norm() / expect.norm())
     for fn, kw in ((bicgstab_differentiable, {}), (gmres_differentiable, {"restart": 30})):
         b = torch.randn(n, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
         (fn(A, b, tol=1e-9, **kw) * gvec).sum().backward()
-        assert torch.allclose(b.grad, expect, rtol=1e-6, atol=1e-9), (fn.__name__, (b.grad - expect).norm() / expect.norm())
+        assert (b.grad - expect).norm() / expect.norm() < 1e-6, (fn.__name__, (b.grad - expect).norm() / expect.norm())
 
 
 def test_forward_solve_with_a_transposed_view(hipk):
@@ -132,8 +132,10 @@ def test_forward_solve_with_a_transposed_view(hipk):
         x1, i1 = bicgstab(M, b, tol=1e-9)
         x2, i2 = bicgstab(Mt, b, tol=1e-9)
         assert i1 == 0 and i2 == 0
-        assert torch.allclose(x1, torch.linalg.solve(A, b), rtol=1e-6, atol=1e-9)
-        assert torch.allclose(x2, torch.linalg.solve(A.T, b), rtol=1e-6, atol=1e-9)
+        r1 = torch.linalg.solve(A, b)
+        assert (x1 - r1).norm() / r1.norm() < 1e-6
+        r2 = torch.linalg.solve(A.T, b)
+        assert (x2 - r2).norm() / r2.norm() < 1e-6
         assert (x1 - x2).norm() / x1.norm() > 1e-3
 
 
@@ -459,6 +461,78 @@ def test_gmres_wide_small_system_kernels_are_bit_identical(monkeypatch):
                     out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
                 assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (n, dt, method)
     monkeypatch.delenv("HIPK_GMRES_NO_WIDE", raising=False)
+
+
+@pytest.mark.gpu
+def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
+    """small systems with short rows run a whole restart cycle in ONE launch
+    (hipk_gm_cycle_small_kernel: a resident workgroup per chunk, counter barriers between the phases);
+    HIPK_GMRES_NO_CYCLE=1 selects the multi-launch small-system path: same bits -- ragged tails, one to eight chunks,
+    second CGS passes, breakdown / early exit, Jacobi scaling and fp32 storage included."""
+    import torch
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_ldc_pressure_csr,
+                                                          create_variable_diffusion_2d_csr)
+    dev = "cuda:0"
+    mats = [create_convdiff_2d_csr(100, 100, device=dev), create_ldc_pressure_csr(100, device=dev),
+            create_convdiff_2d_csr(7, 5, device=dev), create_convdiff_2d_csr(128, 128, device=dev),
+            create_ldc_pressure_csr(47, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev)]
+    for mi, A in enumerate(mats):
+        n = A.shape[0]
+        for dt in (torch.float64, torch.float32):
+            Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(),
+                                                                        A.values().float(), size=A.shape)
+            b = torch.randn(n, dtype=dt, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+            for method, M in (("batched", None), ("incremental", None), ("batched", "jacobi")):
+                if M == "jacobi" and mi not in (0, 5):
+                    continue
+                kw = dict(tol=1e-9 if dt == torch.float64 else 1e-4, restart=30 if mi != 3 else 7, maxiter=6, solve_method=method)
+                if M == "jacobi":
+                    kw["M"] = JacobiPreconditioner(Ad)
+                out = {}
+                for flag in ("0", "1"):
+                    if flag == "1":
+                        monkeypatch.setenv("HIPK_GMRES_NO_CYCLE", "1")
+                    else:
+                        monkeypatch.delenv("HIPK_GMRES_NO_CYCLE", raising=False)
+                    x, info = gmres(Ad, b, **kw)
+                    st = get_last_stats()
+                    out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
+                assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (n, dt, method, M)
+    monkeypatch.delenv("HIPK_GMRES_NO_CYCLE", raising=False)
+    # a tiny exactly solvable system: happy breakdown inside the cycle kernel
+    A = torch.eye(5, dtype=torch.float64, device=dev).to_sparse_csr()
+    x, info = gmres(A, torch.arange(1.0, 6.0, dtype=torch.float64, device=dev), tol=1e-12, restart=5)
+    assert info == 0 and torch.allclose(x, torch.arange(1.0, 6.0, dtype=torch.float64, device=dev))
+
+
+@pytest.mark.gpu
+def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypatch):
+    """Large systems (more than 8 reduction chunks): the streaming-policy kernels (non-temporal loads of the basis columns
+    beyond the resident ones) and the speculative second CGS pass (launched only where predicted; a miss is caught on the
+    device and the cycle re-enqueued from that step) must return the bits of the plain launch sequence."""
+    import torch
+    from pytorch_sparse_solver.module_a import get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr
+    dev = "cuda:0"
+    for A, kw in ((create_convdiff_2d_csr(300, 300, device=dev), dict(tol=1e-8, restart=30, maxiter=5)),
+                  (create_poisson_2d_csr(200, 170, device=dev), dict(tol=1e-8, restart=12, maxiter=7, solve_method="incremental"))):
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+        out = []
+        for env in ({"HIPK_GMRES_NO_STREAM": "1", "HIPK_GM_SPEC": "0"}, {"HIPK_GM_SPEC": "0"}, {}, {"HIPK_GM_NRES": "0"},
+                    {"HIPK_GM_NRES": "31"}, {"HIPK_GM_SPEC": "2"}):   # 2: nothing predicted -> every first need is a miss
+            for k in ("HIPK_GMRES_NO_STREAM", "HIPK_GM_SPEC", "HIPK_GM_NRES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            x, info = gmres(A, b, **kw)
+            st = get_last_stats()
+            out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
+        for o in out[1:]:
+            assert torch.equal(o[0], out[0][0]) and o[1:] == out[0][1:]
+    for k in ("HIPK_GMRES_NO_STREAM", "HIPK_GM_SPEC", "HIPK_GM_NRES"):
+        monkeypatch.delenv(k, raising=False)
 
 
 @pytest.mark.gpu
