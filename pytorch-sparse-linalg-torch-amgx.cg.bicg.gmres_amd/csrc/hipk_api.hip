@@ -562,7 +562,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
 #define HIPK_PICK_PAIR_U(T, U) \
     (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
 #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
-                    kern = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+                    void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+                    int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
+                        (pocc * h->n_cu >= a.g || pocc >= occ))
+                        kern = pk;
 #undef HIPK_PICK_PAIR
 #undef HIPK_PICK_PAIR_U
                 }

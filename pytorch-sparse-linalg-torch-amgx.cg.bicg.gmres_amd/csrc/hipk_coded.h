@@ -753,11 +753,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
         dv = ((const T *)a.dict_val)[t];
         dofs = a.dict_off[t];
     }
-    struct req_t {
-        unsigned c[G0];
+    struct req_t {  // the code groups of a tile: all that is fetched one trip ahead (8 VGPRs for the four requests in flight;
+        unsigned c[G0];  // the epilogue operands travel with the x gathers, which keeps the kernel at 8 workgroups per CU)
+    };
+    struct ops_t {
         T w, b, d;
     };
-    auto request = [&](int tl, req_t &q) {  // tile tl's code groups and epilogue operands
+    auto request = [&](int tl, req_t &q) {
         unsigned long long uc = 0ull;
         if (UNI) {
             const unsigned long long u = ucode[tl];  // wave-uniform: scalar load
@@ -783,17 +785,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
                 q.c[g] = wv;
             }
         }
-        const int row = tl * HIPK_TILE + t;
-        q.w = (T)0;
-        q.b = (T)0;
-        q.d = (T)0;
-        if (row < n32) {
-            if (mode & HIPK_SPMV_DOT_W) q.w = ((const T *)a.w)[row];
-            if (mode & HIPK_SPMV_RESID) q.b = ((const T *)a.bsub)[row];
-            if (mode & HIPK_SPMV_SCALE) q.d = ((const T *)a.dscale)[row];
-        }
     };
-    auto gather = [&](const req_t &q, int tl, T(&xv)[NE]) {
+    auto gather = [&](const req_t &q, int tl, T(&xv)[NE], ops_t &o) {
         const int row = tl * HIPK_TILE + t;
         const int rowx = row < n32 ? row : n32 - 1;
 #pragma unroll
@@ -802,8 +795,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
             const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
             xv[k] = *(const T *)(xb + bo);
         }
+        o.w = (T)0;
+        o.b = (T)0;
+        o.d = (T)0;
+        if (row < n32) {
+            if (mode & HIPK_SPMV_DOT_W) o.w = ((const T *)a.w)[row];
+            if (mode & HIPK_SPMV_RESID) o.b = ((const T *)a.bsub)[row];
+            if (mode & HIPK_SPMV_SCALE) o.d = ((const T *)a.dscale)[row];
+        }
     };
-    auto finish = [&](const req_t &q, int tl, const T(&xv)[NE]) {
+    auto finish = [&](const req_t &q, int tl, const T(&xv)[NE], const ops_t &o) {
         const int row = tl * HIPK_TILE + t;
         T s = (T)0;
 #pragma unroll
@@ -816,10 +817,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
         double d0 = 0.0, d1 = 0.0;
         if (row < n32) {
             T out = s;
-            if (mode & HIPK_SPMV_RESID) out = q.b - out;
-            if (mode & HIPK_SPMV_SCALE) out = q.d * out;
+            if (mode & HIPK_SPMV_RESID) out = o.b - out;
+            if (mode & HIPK_SPMV_SCALE) out = o.d * out;
             y[row] = out;
-            if (mode & HIPK_SPMV_DOT_W) d0 = (double)q.w * (double)out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)o.w * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
         const int slot = (tl - t_first) * 4 + wave;
@@ -832,16 +833,17 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
             if (lane == 0) wsum1[slot] = d1;
         }
     };
-    // one trip: gathers of the pair (ca, cb) = tiles tp, tp + 1 | requests of the next pair into (na, nb) | finish the pair
+    // one trip: gathers of the pair (ca, cb) = tiles tp, tp + 1 | code requests of the next pair into (na, nb) | finish the pair
     auto trip = [&](req_t &ca, req_t &cb, req_t &na, req_t &nb, int tp) {
         const bool hb = tp + 1 < t_end;
         T xa[NE], xbv[NE];
-        gather(ca, tp, xa);
-        if (hb) gather(cb, tp + 1, xbv);
+        ops_t oa, ob;
+        gather(ca, tp, xa, oa);
+        if (hb) gather(cb, tp + 1, xbv, ob);
         if (tp + 2 < t_end) request(tp + 2, na);
         if (tp + 3 < t_end) request(tp + 3, nb);
-        finish(ca, tp, xa);
-        if (hb) finish(cb, tp + 1, xbv);
+        finish(ca, tp, xa, oa);
+        if (hb) finish(cb, tp + 1, xbv, ob);
     };
 
     req_t r0, r1, r2, r3;

@@ -41,6 +41,69 @@ def test_spmv_bit_exact_on_fixture_matrices(hipk, oracle, case):
     assert np.array_equal(y, oracle.spmv(d["crow"], d["col"], d["val"], x))
 
 
+def _at_allocation_end(arr, dtype=None):
+    """Device copy of `arr` whose LAST byte is the last byte of a fresh 32 MiB allocation (the caching allocator hands
+    requests above 10 MiB to hipMalloc at their 2 MiB-rounded size): one element read past the end leaves the mapping."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dtype is not None:
+        t = t.to(dtype)
+    nbytes = t.numel() * t.element_size()
+    pad = (-nbytes) % 16                                    # keep the view 16-byte aligned
+    buf = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    view = buf[buf.numel() - nbytes - pad: buf.numel() - pad].view(t.dtype)
+    view.copy_(t)
+    return view, buf
+
+
+@pytest.mark.parametrize("name", ["stencil_partial_last_tile", "short_rows_cnt_lt_256", "trailing_empty_tile", "long_rows"])
+def test_spmv_operands_at_allocation_ends(hipk, oracle, name):
+    """Regression for the round-1 GPU memory fault (profiles/r01_spmv_history.md, 'The 06:21 fault'): an SpMV variant
+    gathered x through index registers that the lanes past the tile's last entry had never loaded.  Shapes that put those
+    lanes to work -- a last tile with fewer than 256 entries / rows, a tile with NO entries, a ragged tail -- with every
+    operand (val, x, w, b, y) ENDING exactly at the end of its allocation, so any read past an array's end is not absorbed
+    by allocator slack.  All SpMV kernel families, plain and fused forms; results bit-exact vs the oracle."""
+    rng = np.random.default_rng(21)
+    if name == "stencil_partial_last_tile":               # coded path; 4690 rows: last tile has 82 rows
+        from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+        A = create_poisson_2d_csr(70, 67)
+        crow, col, val = A.crow_indices().numpy(), A.col_indices().numpy(), A.values().numpy()
+        n = 4690
+    elif name == "short_rows_cnt_lt_256":                 # tile kernel: last tile 44 rows with 0-3 entries each
+        n = 300
+        lens = rng.integers(0, 4, n)
+        lens[0] += lens.sum() % 2
+        crow, col, val = random_csr(n, lens, seed=4)
+    elif name == "trailing_empty_tile":                   # the last 300 rows are empty: a tile with cnt == 0, j0 == nnz
+        n = 1000
+        lens = rng.integers(1, 9, n)
+        lens[700:] = 0
+        lens[0] += lens.sum() % 2
+        crow, col, val = random_csr(n, lens, seed=5)
+    else:                                                 # row-per-wavefront path, ragged lengths
+        n = 333
+        lens = rng.integers(60, 200, n)
+        lens[0] += lens.sum() % 2
+        crow, col, val = random_csr(n, lens, seed=6)
+    assert val.size % 2 == 0                              # 16-byte aligned val view at the allocation end
+    x, w, b = (rng.standard_normal(n) for _ in range(3))
+    keep = []
+    dval, k0 = _at_allocation_end(val)
+    dx, k1 = _at_allocation_end(x if n % 2 == 0 else np.concatenate([x, [0.0]]))
+    keep += [k0, k1]
+    h = hipk.CsrHandle(torch.from_numpy(crow).to(DEV), torch.from_numpy(col).to(DEV), dval, (n, n))
+    xin = dx[:n]
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        y = hipk.spmv(h, xin).cpu().numpy()
+        assert np.array_equal(y, oracle.spmv(crow, col, val, x)), (name, plain)
+        if n % 2 == 0:
+            dw, k2 = _at_allocation_end(w)
+            yd, dot = hipk.spmv_dot(h, xin, dw)
+            assert np.array_equal(yd.cpu().numpy(), y) and dot.item() == oracle.dot_tiled(w, y)
+            keep.append(k2)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("name,n,lens", [
     ("empty_rows", 700, lambda rng, n: rng.integers(0, 4, n) * (rng.random(n) < 0.5)),
     ("ragged", 3000, lambda rng, n: rng.integers(0, 40, n)),                  # crosses the long-row threshold (32)
