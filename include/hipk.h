@@ -216,6 +216,14 @@ int hipk_pbicgstab_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const v
 int hipk_pgmres_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user, const void *b, void *x, void *work,
                          size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
 
+/* ---- block-Jacobi preconditioner ------------------------------------------
+ * out = M in with M = blockdiag(A)^-1: `binv_dev` holds the inverted block_size x block_size diagonal blocks, row-major
+ * per block, ceil(n / block_size) of them (a ragged last block is padded with identity rows/columns).  The device kernel
+ * behind `BlockJacobiPreconditioner`, a callable for the reference's `M` hook (TSL:849, 908, 922, 351) that cg / bicgstab /
+ * gmres run between their fused kernels.  z_i is an fma chain over the block's columns in ascending order. */
+int hipk_block_jacobi_apply(int64_t n, int block_size, const void *binv_dev, const void *in, void *out, int dtype,
+                            hipk_stream_t stream);
+
 /* ---- step API: externally driven loops (row-partitioned multi-GPU CG) ------------
  * The reference is single-device; the row-partitioned solver (north_star) drives the
  * SAME fused kernels from the host side of each rank and exchanges (a) the x-vector
@@ -265,6 +273,49 @@ int hipk_cgm_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, c
 int hipk_cgm_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it, int64_t maxiter,
                        const double *part_pAp, const double *part_rz, const double *part_rr, const void *z,
                        void *p, void *x, int dtype, hipk_stream_t stream);
+
+/* ---- row-partitioned CG, the whole loop of one rank driven from C (north_star: "the SpMV shards row-blocks across the
+ * GPUs with an RCCL allgather of the x-vector halo and an allreduce for the global dot") ----------------------------------
+ * The collectives are called through function pointers the caller resolves from the librccl that created `comm`
+ * (signatures of ncclGroupStart / ncclGroupEnd / ncclAllGather / ncclSend / ncclRecv; datatype 8 = ncclFloat64), on the
+ * solver's stream.  Tests plug in host-staged stand-ins. */
+typedef struct {
+    int (*group_start)(void);
+    int (*group_end)(void);
+    int (*all_gather)(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);
+    int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
+    int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
+    void *comm;
+} hipk_rccl;
+
+/* One rank's view of the partition (pytorch_sparse_solver/distributed.py: RowPartition + HaloPlan). */
+typedef struct {
+    int32_t rank, world;
+    int64_t n_local;   /* rows this rank owns (> 0 on every rank)                                        */
+    int64_t n_ext;     /* n_local + number of halo entries: length of x, p, r                            */
+    int64_t n_global;
+    int32_t chunk_rows; /* reduction chunk of the GLOBAL problem (hipk_chunk_size(n_global))              */
+    int32_t g_red;      /* partials of all ranks (hipk_chunk_count(n_global))                             */
+    int32_t per;        /* chunks per rank, the all-gather count (per * world >= g_red)                   */
+    int32_t halo_mode;  /* 1: neighbour send/recv pairs; 0: all-gather of slabs padded to `slab` entries  */
+    int32_t n_send;     /* owned entries other ranks need, grouped by destination rank                    */
+    int32_t n_ghost;    /* = n_ext - n_local                                                              */
+    int32_t slab;       /* halo_mode 0: padded slab length                                                */
+    int32_t reserved;
+    const int32_t *send_idx_dev;  /* [n_send] local row of each packed entry                              */
+    const int32_t *ghost_src_dev; /* [n_ghost] halo_mode 0: position of each halo entry in the gathered slabs */
+    const int32_t *send_counts;   /* host, [world]: entries sent to each rank                             */
+    const int32_t *recv_counts;   /* host, [world]: halo entries received from each rank (in rank order)  */
+} hipk_dist_plan;
+
+size_t hipk_dist_cg_work_bytes(const hipk_dist_plan *plan);
+/* `A_local`: this rank's row block with columns renumbered to [0, n_ext) (hipk_csr_create_ex with the global chunk size).
+ * x_ext: n_ext doubles, x0 in the first n_local on entry, the solution there on return.  params.check_every = batch
+ * size of the loop (default 16).  Same `info` rule and, bit for bit, the same iterates as hipk_cg_solve on the whole
+ * system (TSL:806-856, 968-1016). */
+int hipk_dist_cg_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const hipk_rccl *coll, const void *b_local,
+                       void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
+                       hipk_stream_t stream);
 
 #ifdef __cplusplus
 }

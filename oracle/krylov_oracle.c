@@ -71,6 +71,8 @@ typedef double real;
 #define orc_spmv orc32_spmv
 #define orc_cg orc32_cg
 #define orc_pcg_jacobi orc32_pcg_jacobi
+#define orc_block_jacobi_apply orc32_block_jacobi_apply
+#define orc_pcg_blockjacobi orc32_pcg_blockjacobi
 #define orc_bicgstab orc32_bicgstab
 #define orc_bicgstab_jacobi orc32_bicgstab_jacobi
 #define orc_gmres orc32_gmres
@@ -415,6 +417,86 @@ int orc_pcg_jacobi(int64_t n, const int32_t *crow, const int32_t *col, const rea
     free(r);
     free(p);
     free(Ap);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ block-Jacobi
+ * z = blockdiag(binv) r: binv holds the inverted bs x bs diagonal blocks row-major per block (a ragged last block completed
+ * with identity).  z_i = fma chain over the block's columns in ascending order: restates hipk_block_jacobi_kernel. */
+void orc_block_jacobi_apply(int64_t n, int bs, const real *binv, const real *in, real *out) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t b0 = (i / bs) * bs;
+        const real *row = binv + i * bs;
+        real acc = (real)0;
+        for (int j = 0; j < bs && b0 + j < n; ++j) acc = (real)fma(row[j], in[b0 + j], acc);
+        out[i] = acc;
+    }
+}
+
+/* CG with M = blockdiag(binv) as a CALLABLE between the fused kernels (`_cg_solve` with M, TSL:806-856): restates
+ * pytorch_sparse_solver/_hipk.py::solve_cg_stepwise -- z = M r stored, <r,z> and <r,r> plain chunked dots, the rest as
+ * orc_pcg_jacobi (with a diagonal M the two agree bit for bit). */
+int orc_pcg_blockjacobi(int64_t n, const int32_t *crow, const int32_t *col, const real *val, int bs, const real *binv,
+                        const real *b, real *x /* in: x0, out: x */, double tol, double atol, int64_t maxiter,
+                        orc_stats *st) {
+    memset(st, 0, sizeof(*st));
+    if (maxiter < 0) maxiter = 10 * n;
+    real *r = (real *)malloc(sizeof(real) * (size_t)n);
+    real *p = (real *)malloc(sizeof(real) * (size_t)n);
+    real *Ap = (real *)malloc(sizeof(real) * (size_t)n);
+    real *z = (real *)malloc(sizeof(real) * (size_t)n);
+    const double bs2 = orc_dot(n, b, b);
+    const float tolf = (float)tol, atolf = (float)atol;
+    const double a2 = (double)(tolf * tolf) * bs2, a3 = (double)(atolf * atolf);
+    const double atol2 = a2 > a3 ? a2 : a3;
+    orc_spmv(n, crow, col, val, x, b, r);
+    int64_t matvecs = 1;
+    double rs = orc_dot_tiled(n, r, r); /* fused in the residual SpMV */
+    orc_block_jacobi_apply(n, bs, binv, r, z);
+    memcpy(p, z, sizeof(real) * (size_t)n);
+    double gamma = orc_dot(n, r, z);
+    int64_t k = 0;
+    while (!(k >= maxiter || rs <= atol2)) {
+        orc_spmv(n, crow, col, val, p, NULL, Ap);
+        ++matvecs;
+        const double pAp = orc_dot_tiled(n, p, Ap);
+        const double alpha = gamma / pAp;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const real m1 = (real)alpha * Ap[i];
+            r[i] = r[i] - m1;
+        }
+        const double rr = orc_dot(n, r, r);
+        orc_block_jacobi_apply(n, bs, binv, r, z);
+        const double rz = orc_dot(n, r, z);
+        const double beta = rz / gamma;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+        for (int64_t i = 0; i < n; ++i) {
+            const real m0 = (real)alpha * p[i];
+            x[i] = x[i] + m0;
+            const real m = (real)beta * p[i];
+            p[i] = z[i] + m;
+        }
+        gamma = rz;
+        rs = rr;
+        ++k;
+    }
+    orc_spmv(n, crow, col, val, x, b, Ap);
+    ++matvecs;
+    orc_block_jacobi_apply(n, bs, binv, Ap, z);
+    st->residual_norm = norm_from_sq(orc_dot(n, z, z));
+    st->b_norm = norm_from_sq(bs2);
+    st->x_norm = norm_from_sq(orc_dot(n, x, x));
+    st->threshold = tmax((double)(float)tol * st->b_norm, (double)(float)atol);
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+    st->iterations = k;
+    st->matvecs = matvecs;
+    st->recurrence_rs = rs;
+    free(r);
+    free(p);
+    free(Ap);
+    free(z);
     return 0;
 }
 

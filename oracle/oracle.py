@@ -83,6 +83,8 @@ def lib():
         L.orc_bicgstab.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_pcg_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_bicgstab_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
+        L.orc_block_jacobi_apply.argtypes = [i64, ctypes.c_int, dp, dp, dp]
+        L.orc_pcg_blockjacobi.argtypes = [i64, ip, ip, dp, ctypes.c_int, dp, dp, dp, ctypes.c_double, ctypes.c_double, i64, sp]
         L.orc_gmres.argtypes = [i64, ip, ip, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
                                 ctypes.c_int, ctypes.c_int, sp]
         L.orc_gmres_jacobi.argtypes = [i64, ip, ip, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, i64,
@@ -219,6 +221,25 @@ def pcg_jacobi(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, maxiter=Non
     st = _Stats()
     lib().orc_pcg_jacobi(b.size, _i(crow), _i(col), _d(val), _d(dinv), _d(b), _d(x), float(tol), float(atol),
                          -1 if maxiter is None else int(maxiter), ctypes.byref(st))
+    return _result(x, st)
+
+
+def block_jacobi_apply(binv, v) -> np.ndarray:
+    """z = blockdiag(binv) v; binv: [nb, bs, bs] (restates hipk_block_jacobi_kernel)."""
+    binv = np.ascontiguousarray(binv, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.empty_like(v)
+    lib().orc_block_jacobi_apply(v.size, int(binv.shape[1]), _d(binv), _d(v), _d(out))
+    return out
+
+
+def pcg_blockjacobi(crow, col, val, binv, b, x0=None, tol=1e-5, atol=0.0, maxiter=None) -> OracleResult:
+    """CG with M = blockdiag(binv) applied as a callable between the fused kernels (TSL:806-856 with a non-identity M)."""
+    crow, col, val, b, x = _prep(crow, col, val, b, x0)
+    binv = np.ascontiguousarray(binv, dtype=np.float64)
+    st = _Stats()
+    lib().orc_pcg_blockjacobi(b.size, _i(crow), _i(col), _d(val), int(binv.shape[1]), _d(binv), _d(b), _d(x), float(tol),
+                              float(atol), -1 if maxiter is None else int(maxiter), ctypes.byref(st))
     return _result(x, st)
 
 

@@ -563,6 +563,10 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
 #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
                     void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+                    // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
+                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !getenv("HIPK_SPMV_SELL_NO_MODE"))
+                        pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
+                                           : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
                         (pocc * h->n_cu >= a.g || pocc >= occ))

@@ -158,3 +158,56 @@ extern "C" int hipk_reduce_parts(const double *part_dev, int g, double *out_dev,
     HIPK_REQUIRE(part_dev && out_dev && g >= 0 && g <= HIPK_MAX_PARTS, HIPK_ERR_ARG, "bad argument");
     return hipk_launch_finish1(part_dev, g, out_dev, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------- block-Jacobi preconditioner
+// z = M r with M = blockdiag(A)^-1: the inverses of the bs x bs diagonal blocks, row-major per block (binv[b][i][j]),
+// precomputed once.  The reference's hook is any callable `M` (TSL:849, 908, 922, 351); this is the device kernel a
+// `BlockJacobiPreconditioner` runs between the fused solver kernels.  Thread per row: z_i = fma-chain over the block's
+// columns in ascending order (mirrored by oracle/krylov_oracle.c::orc_block_jacobi_apply): bitwise reproducible.
+// Traffic: bs*sizeof(T) per row of binv (streamed, non-temporal) + the vector in and out.
+template <typename T, int BS>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_block_jacobi_kernel(int64_t n, int bs_rt, const T *__restrict__ binv,
+                                                                         const T *__restrict__ in, T *__restrict__ out) {
+    const int bs = BS > 0 ? BS : bs_rt;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t b0 = (i / bs) * bs;
+        const T *__restrict__ row = binv + i * bs;   // block b, local row i - b0: (b*bs + (i - b0)) * bs = i * bs
+        T acc = (T)0;
+#pragma unroll
+        for (int j = 0; j < (BS > 0 ? BS : 32); ++j) {
+            if (j < bs && b0 + j < n) acc = fma(__builtin_nontemporal_load(row + j), in[b0 + j], acc);
+        }
+        out[i] = acc;
+    }
+}
+
+extern "C" int hipk_block_jacobi_apply(int64_t n, int block_size, const void *binv_dev, const void *in, void *out, int dtype,
+                                       hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(n >= 0 && block_size >= 1 && block_size <= 32, HIPK_ERR_ARG, "block_size must be in [1, 32]");
+    if (n == 0) return HIPK_OK;
+    HIPK_REQUIRE(binv_dev && in && out, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(in != out, HIPK_ERR_ARG, "in and out must not alias");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype");
+    int grid = (int)((n + HIPK_THREADS - 1) / HIPK_THREADS);
+    if (grid > 16384) grid = 16384;
+#define HIPK_BJ(T, B) hipk_block_jacobi_kernel<T, B><<<grid, HIPK_THREADS, 0, stream>>>(n, block_size, (const T *)binv_dev, (const T *)in, (T *)out)
+#define HIPK_BJ_T(T)                          \
+    switch (block_size) {                     \
+        case 2: HIPK_BJ(T, 2); break;         \
+        case 4: HIPK_BJ(T, 4); break;         \
+        case 8: HIPK_BJ(T, 8); break;         \
+        case 16: HIPK_BJ(T, 16); break;       \
+        default: HIPK_BJ(T, 0); break;        \
+    }
+    if (dtype == HIPK_F64) {
+        HIPK_BJ_T(double)
+    } else {
+        HIPK_BJ_T(float)
+    }
+#undef HIPK_BJ_T
+#undef HIPK_BJ
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}

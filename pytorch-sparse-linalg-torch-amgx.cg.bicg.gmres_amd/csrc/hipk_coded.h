@@ -724,7 +724,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
 // sums are independent instruction streams the scheduler interleaves (no idle hazard slots), and the loop is unrolled over
 // two pairs so that the prefetched requests change roles instead of being copied.  Same arithmetic per row, same tile /
 // chunk folds: same bits.  Pair codes only (VALS = false), exact tile sizes (UNITS = 4, 5, 8), chunks of <= 64 tiles.
-template <typename T, int UNITS, bool UNI>
+// MODE >= 0: the mode bits as a compile-time constant (the solver loops' hot forms: no per-tile scalar branches on the mode)
+template <typename T, int UNITS, bool UNI, int MODE = -1>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_spmv_args a) {
     constexpr int G0 = (UNITS + 3) / 4;
     constexpr int NE = UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8);
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
     const unsigned char *__restrict__ code = a.code;
     const char *__restrict__ xb = (const char *)a.x;
     T *__restrict__ y = (T *)a.y;
-    const int mode = a.mode;
+    const int mode = MODE >= 0 ? MODE : a.mode;
     const int n32 = (int)a.n;
     const unsigned long long *__restrict__ ucode = a.tile_ucode;
 

@@ -756,6 +756,7 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
     __shared__ double rv[HIPK_GM_LDH];
     __shared__ double cp[8];
     __shared__ double bc[2];
+    __shared__ double hc[HIPK_GM_LDH + 1];   // the Hessenberg column under rotation (thread 0 of workgroup 0)
     __shared__ int fail;
     __shared__ long long stop_lds;
     if (tid == 0) fail = 0;
@@ -763,6 +764,8 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
     __syncthreads();
     int epoch = 0;
     long long stop = a.m;
+    // phase stamps: a DIAGNOSTIC build only (make STAMPS=1 -> -DHIPK_GM_STAMPS; run with HIPK_GM_STAMPS=1)
+#ifdef HIPK_GM_STAMPS
     unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamping = a.stamps != nullptr && c == 0 && tid == 0;
 #define HIPK_STAMP(slot)                                              \
@@ -772,6 +775,9 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
         t_prev = now_;                                                \
     }
     if (stamping) t_prev = __builtin_amdgcn_s_memtime();
+#else
+#define HIPK_STAMP(slot)
+#endif
 
     for (int k = 0; k < a.m && k < stop; ++k) {
         const T *vk = a.V + (int64_t)k * a.ldv;
@@ -946,7 +952,6 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
                 stp = true;
             }
             if (scal->incremental) {
-                double hc[HIPK_GM_LDH + 1];
                 for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * HIPK_GM_LDH + k];
                 for (int i = 0; i < k; ++i) {
                     const double cs = scal->gv[2 * i], sn = scal->gv[2 * i + 1];
@@ -989,8 +994,10 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
         stop = stop_lds;
         __syncthreads();
     }
+#ifdef HIPK_GM_STAMPS
     if (stamping)
         for (int i = 0; i < 8; ++i) a.stamps[i] += t_acc[i];
+#endif
 #undef HIPK_STAMP
 }
 

@@ -16,7 +16,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libhipk.so")
+# HIPK_LIB_PATH: load another build of the library (diagnostic builds, e.g. `make STAMPS=1`); the default is the in-tree one
+LIB_PATH = os.environ.get("HIPK_LIB_PATH") or os.path.join(_HERE, "_lib", "libhipk.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 
 HIPK_F32, HIPK_F64 = 0, 1
@@ -29,7 +30,7 @@ SYMBOLS = [
     "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
-    "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby",
+    "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby", "hipk_block_jacobi_apply",
     "hipk_cg_work_bytes", "hipk_cg_solve", "hipk_pcg_work_bytes", "hipk_pcg_solve", "hipk_pgmres_solve", "hipk_pbicgstab_work_bytes", "hipk_pbicgstab_solve", "hipk_pbicgstab_solve_cb", "hipk_pgmres_solve_cb",
     "hipk_bicgstab_work_bytes", "hipk_bicgstab_solve",
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
@@ -38,6 +39,8 @@ SYMBOLS = [
     "hipk_cg_scal_bytes", "hipk_cg_start", "hipk_cg_update", "hipk_cg_direction",
     # step API: CG with a callable preconditioner
     "hipk_cgm_start", "hipk_cgm_direction",
+    # row-partitioned CG, the loop of one rank in C
+    "hipk_dist_cg_work_bytes", "hipk_dist_cg_solve",
 ]
 
 
@@ -96,6 +99,28 @@ class HipkError(RuntimeError):
     pass
 
 
+# hipk_rccl / hipk_dist_plan (include/hipk.h)
+COLL_GROUP_FN = ctypes.CFUNCTYPE(ctypes.c_int)
+COLL_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p)
+COLL_SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p)
+
+
+class Rccl(ctypes.Structure):
+    _fields_ = [("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p), ("all_gather", ctypes.c_void_p),
+                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("comm", ctypes.c_void_p)]
+
+
+class DistPlan(ctypes.Structure):
+    _fields_ = [("rank", ctypes.c_int32), ("world", ctypes.c_int32), ("n_local", ctypes.c_int64), ("n_ext", ctypes.c_int64),
+                ("n_global", ctypes.c_int64), ("chunk_rows", ctypes.c_int32), ("g_red", ctypes.c_int32),
+                ("per", ctypes.c_int32), ("halo_mode", ctypes.c_int32), ("n_send", ctypes.c_int32),
+                ("n_ghost", ctypes.c_int32), ("slab", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("send_idx_dev", ctypes.c_void_p), ("ghost_src_dev", ctypes.c_void_p),
+                ("send_counts", ctypes.POINTER(ctypes.c_int32)), ("recv_counts", ctypes.POINTER(ctypes.c_int32))]
+
+
 # hipk_precond_fn (include/hipk.h): int M(void *user, const void *in_dev, void *out_dev)
 PRECOND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 
@@ -145,6 +170,7 @@ def lib():
     L.hipk_dot.argtypes = [i64, vp, vp, i32, vp, vp, vp]
     L.hipk_axpy.argtypes = [i64, dbl, vp, vp, i32, vp]
     L.hipk_xpby.argtypes = [i64, vp, dbl, vp, i32, vp]
+    L.hipk_block_jacobi_apply.argtypes = [i64, i32, vp, vp, vp, i32, vp]
     for name in ("cg", "bicgstab"):
         wb = getattr(L, f"hipk_{name}_work_bytes")
         wb.argtypes = [i64, i32]
@@ -176,6 +202,10 @@ def lib():
     L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, i32, vp]
     L.hipk_cgm_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
     L.hipk_cgm_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.hipk_dist_cg_work_bytes.argtypes = [ctypes.POINTER(DistPlan)]
+    L.hipk_dist_cg_work_bytes.restype = ctypes.c_size_t
+    L.hipk_dist_cg_solve.argtypes = [vp, ctypes.POINTER(DistPlan), ctypes.POINTER(Rccl), vp, vp, vp, ctypes.c_size_t,
+                                     ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     _lib = L
     return L
 
@@ -470,6 +500,16 @@ def xpby(x: torch.Tensor, b: float, y: torch.Tensor) -> torch.Tensor:
         _check(lib().hipk_xpby(x.numel(), x.data_ptr(), float(b), y.data_ptr(), _dtype_code(x.dtype),
                                _stream(x.device)), "hipk_xpby")
     return y
+
+
+def block_jacobi_apply(binv: torch.Tensor, block_size: int, v: torch.Tensor) -> torch.Tensor:
+    """z = blockdiag(binv) v on the device (hipk_block_jacobi_apply); binv: [ceil(n / bs), bs, bs] contiguous."""
+    assert v.is_cuda and v.is_contiguous() and binv.is_contiguous() and binv.dtype == v.dtype and binv.device == v.device
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        _check(lib().hipk_block_jacobi_apply(v.numel(), int(block_size), binv.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                             _dtype_code(v.dtype), _stream(v.device)), "hipk_block_jacobi_apply")
+    return out
 
 
 # -------------------------------------------------------------------- whole solves

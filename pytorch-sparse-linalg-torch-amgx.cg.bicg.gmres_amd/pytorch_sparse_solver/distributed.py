@@ -271,6 +271,13 @@ class RcclComm:
             ro += nr
         self._ck(self.L.ncclGroupEnd(), "ncclGroupEnd")
 
+    def coll_struct(self):
+        """hipk_rccl (include/hipk.h): the entry points of THIS librccl + the communicator, for the C-driven loop."""
+        from . import _hipk
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value   # noqa: E731
+        return _hipk.Rccl(addr(self.L.ncclGroupStart), addr(self.L.ncclGroupEnd), addr(self.L.ncclAllGather),
+                          addr(self.L.ncclSend), addr(self.L.ncclRecv), self.comm.value)
+
     def close(self):
         if getattr(self, "comm", None):
             self.L.ncclCommDestroy(self.comm)
@@ -320,6 +327,10 @@ class DistProblem:
                 import warnings
                 warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed collectives")
 
+    def coll_struct(self):
+        """hipk_rccl for the C-driven loop, or None (then the Python loop with torch.distributed collectives runs)."""
+        return self.comm.coll_struct() if self.comm is not None else None
+
     # ---- the three collectives of the solver (overridable: tests stage them through the host)
     def halo_exchange(self, v_ext: torch.Tensor) -> None:
         """Fill v_ext[n_local:] with the peers' entries this rank's rows reference."""
@@ -367,10 +378,65 @@ class DistProblem:
         return int(t.item())
 
 
+def native_loop_ok(prob: DistProblem) -> bool:
+    """The C-driven loop (hipk_dist_cg_solve) needs the HIP kernels, a collective struct (direct RCCL, or whatever a
+    subclass provides through `coll_struct()`), and rows on every rank."""
+    import os
+    part = prob.part
+    return (isinstance(prob.ops, HipOps) and os.environ.get("HIPK_DIST_NATIVE", "1") != "0"
+            and getattr(prob, "coll_struct", None) is not None and prob.coll_struct() is not None
+            and part.per * (part.world - 1) < part.g and part.n_local > 0)
+
+
+def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every):
+    """One call into libhipk.so runs the whole loop of this rank (csrc/hipk_dist.hip): the host enqueues fixed batches
+    of iterations and reads the device stop word one batch late -- no Python between the kernels."""
+    import os
+    from . import _hipk
+    L, part, pl = _hipk.lib(), prob.part, prob.plan
+    dev = prob.ops.device
+    n, n_ext = part.n_local, max(prob.n_ext, 1)
+    peers = sum(1 for a, b in zip(pl.send_splits, pl.recv_splits) if a or b)
+    mode = os.environ.get("HIPK_DIST_HALO", "p2p" if peers <= 4 else "allgather")
+    plan = _hipk.DistPlan()
+    plan.rank, plan.world = part.rank, part.world
+    plan.n_local, plan.n_ext, plan.n_global = n, prob.n_ext, part.n_global
+    plan.chunk_rows, plan.g_red, plan.per = part.ch, part.g, part.per
+    plan.halo_mode = 1 if mode == "p2p" else 0
+    plan.n_send, plan.n_ghost, plan.slab = pl.n_send, pl.n_ghost, pl.slab
+    plan.send_idx_dev = pl.send_idx.data_ptr() if pl.n_send else None
+    plan.ghost_src_dev = pl.ghost_src.data_ptr() if pl.n_ghost else None
+    sc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.send_splits])
+    rc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.recv_splits])
+    plan.send_counts, plan.recv_counts = sc, rc
+    coll = prob.coll_struct()
+    x = prob.ops.zeros(n_ext)
+    if x0_local is not None:
+        x[:n] = x0_local
+    wb = int(L.hipk_dist_cg_work_bytes(ctypes.byref(plan)))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    prm = _hipk.Params()
+    prm.tol, prm.atol = float(tol), float(atol)
+    prm.maxiter = -1 if maxiter is None else int(maxiter)
+    prm.check_every = int(check_every)
+    st = _hipk.Stats()
+    with torch.cuda.device(dev):
+        rcode = L.hipk_dist_cg_solve(prob.A["h"], ctypes.byref(plan), ctypes.byref(coll), prob.b.data_ptr(), x.data_ptr(),
+                                     work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _hipk._check(rcode, "hipk_dist_cg_solve")
+    return x[:n], int(st.info), DistStats(int(st.iterations), int(st.matvecs), int(st.info), st.b_norm, st.residual_norm,
+                                          st.x_norm, st.threshold)
+
+
 def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,
             maxiter: Optional[int] = None, check_every: int = 32):
     """Row-partitioned CG; returns (x_local, info, DistStats). Same stopping rule, same `info` rule and,
-    bit for bit, the same iterates as the single-device solve."""
+    bit for bit, the same iterates as the single-device solve.  On GPUs with direct RCCL the whole loop runs in C
+    (`_dist_cg_native`); the Python loop below is the backend-agnostic form (CPU test double, torch.distributed
+    collectives, ranks without rows)."""
+    if native_loop_ok(prob):
+        return _dist_cg_native(prob, x0_local, tol, atol, maxiter, min(check_every, 16))
     ops, part, group = prob.ops, prob.part, prob.group
     n, ch, G, per, world = part.n_local, part.ch, part.g, part.per, part.world
     maxiter = 10 * part.n_global if maxiter is None else int(maxiter)

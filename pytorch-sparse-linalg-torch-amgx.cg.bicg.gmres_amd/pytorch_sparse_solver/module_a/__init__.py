@@ -11,14 +11,14 @@ from .torch_sparse_linalg import (
     LinearSolveFunction, ImplicitAdjointFunction, get_last_stats,
 )
 from .torch_tree_util import tree_leaves, tree_map, tree_flatten, tree_unflatten, Partial
-from .preconditioners import JacobiPreconditioner
+from .preconditioners import BlockJacobiPreconditioner, JacobiPreconditioner
 
 __all__ = [
     'cg', 'bicgstab', 'gmres',
     'cg_differentiable', 'bicgstab_differentiable', 'gmres_differentiable',
     'LinearSolveFunction',
     'tree_leaves', 'tree_map', 'tree_flatten', 'tree_unflatten', 'Partial',
-    'get_last_stats', 'JacobiPreconditioner',
+    'get_last_stats', 'JacobiPreconditioner', 'BlockJacobiPreconditioner',
 ]
 
 __version__ = '1.0.0'

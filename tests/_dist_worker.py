@@ -60,9 +60,102 @@ class HostStagedProblem(DistProblem):
         return int(t.item())
 
 
+class HostStagedNative(HostStagedProblem):
+    """The C-DRIVEN loop (hipk_dist_cg_solve) under a real multi-rank partition on ONE GPU: the hipk_rccl entry points are
+    Python callbacks that stage the collectives through the host over gloo (RCCL refuses several ranks on one device).
+    Calls between group_start and group_end are deferred to group_end, like RCCL does."""
+
+    def coll_struct(self):
+        import ctypes
+        from pytorch_sparse_solver import _hipk
+        if getattr(self, "_coll", None) is not None:
+            return self._coll
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        D2H, H2D = 2, 1
+        pending, depth = [], [0]
+
+        def to_host(ptr, count):
+            a = np.empty(count, dtype=np.float64)
+            assert hip.hipMemcpy(a.ctypes.data, ptr, count * 8, D2H) == 0
+            return torch.from_numpy(a)
+
+        def to_dev(ptr, t):
+            a = np.ascontiguousarray(t.numpy())
+            assert hip.hipMemcpy(ptr, a.ctypes.data, a.size * 8, H2D) == 0
+
+        def run(ops, stream):
+            hip.hipStreamSynchronize(stream)
+            p2p, keep = [], []
+            for op in ops:
+                if op[0] == "ag":
+                    _, send, recv, count = op
+                    out = torch.empty(count * dist.get_world_size(), dtype=torch.float64)
+                    dist.all_gather_into_tensor(out, to_host(send, count))
+                    to_dev(recv, out)
+                elif op[0] == "send":
+                    p2p.append(dist.P2POp(dist.isend, to_host(op[1], op[2]), op[3]))
+                else:
+                    buf = torch.empty(op[2], dtype=torch.float64)
+                    keep.append((op[1], buf))
+                    p2p.append(dist.P2POp(dist.irecv, buf, op[3]))
+            if p2p:
+                for w in dist.batch_isend_irecv(p2p):
+                    w.wait()
+            for ptr, buf in keep:
+                to_dev(ptr, buf)
+
+        def issue(op, stream):
+            try:
+                if depth[0] > 0:
+                    pending.append((op, stream))
+                else:
+                    run([op], stream)
+                return 0
+            except BaseException as e:   # never unwind through the C frames
+                print("collective callback failed:", repr(e), flush=True)
+                return 1
+
+        def group_start():
+            depth[0] += 1
+            return 0
+
+        def group_end():
+            depth[0] -= 1
+            if depth[0] == 0 and pending:
+                ops, stream = [o for o, _ in pending], pending[0][1]
+                pending.clear()
+                try:
+                    run(ops, stream)
+                except BaseException as e:
+                    print("collective callback failed:", repr(e), flush=True)
+                    return 1
+            return 0
+
+        def all_gather(send, recv, count, dtype, comm, stream):
+            assert dtype == 8
+            return issue(("ag", send, recv, count), stream)
+
+        def send(buf, count, dtype, peer, comm, stream):
+            return issue(("send", buf, count, peer), stream)
+
+        def recv(buf, count, dtype, peer, comm, stream):
+            return issue(("recv", buf, count, peer), stream)
+
+        self._cbs = (_hipk.COLL_GROUP_FN(group_start), _hipk.COLL_GROUP_FN(group_end), _hipk.COLL_ALLGATHER_FN(all_gather),
+                     _hipk.COLL_SENDRECV_FN(send), _hipk.COLL_SENDRECV_FN(recv))
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value   # noqa: E731
+        self._coll = _hipk.Rccl(*[addr(f) for f in self._cbs], None)
+        return self._coll
+
+
 def main():
     kind, nx, ny, tol, maxiter, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-    use_hip = len(sys.argv) > 7 and sys.argv[7] == "hip"
+    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag")
+    native = len(sys.argv) > 7 and sys.argv[7].startswith("native")
+    if len(sys.argv) > 7 and sys.argv[7] == "native_ag":
+        os.environ["HIPK_DIST_HALO"] = "allgather"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     A, b = build_global(kind, nx, ny)
@@ -76,7 +169,8 @@ def main():
         from pytorch_sparse_solver.distributed import HaloPlan, HipOps
         plan = HaloPlan(lcol, part)                       # plan collectives on CPU tensors (gloo)
         dev = torch.device("cuda", 0)
-        prob = HostStagedProblem.__new__(HostStagedProblem)
+        cls = HostStagedNative if native else HostStagedProblem
+        prob = cls.__new__(cls)
         ops = HipOps(dev)
         for name in ("col_local", "send_idx", "ghost_src"):
             setattr(plan, name, getattr(plan, name).to(dev))
@@ -91,6 +185,9 @@ def main():
         prob.comm = None
     else:
         prob = DistProblem(lc, lcol, lval, lb, part, OracleOps())
+    if native:
+        from pytorch_sparse_solver.distributed import native_loop_ok
+        assert native_loop_ok(prob), "the C-driven loop was expected to run"
     x_loc, info, st = dist_cg(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
     pieces = [None] * world
     dist.all_gather_object(pieces, (part.row0, x_loc.cpu().numpy().copy(), info, st.iterations, st.residual_norm))

@@ -80,6 +80,26 @@ def test_dist_cg_hip_kernels_multi_rank_on_one_gpu(world, kind, nx, ny, tmp_path
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny,mode", [(2, "poisson", 96, 64, "native"), (2, "random_spd", 80, 77, "native"),
+                                                   (2, "random_spd", 80, 77, "native_ag"), (3, "poisson", 96, 64, "native"),
+                                                   (3, "poisson", 96, 64, "native_ag"), (2, "poisson", 4, 8000, "native")])
+def test_dist_cg_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, mode, tmp_path):
+    """hipk_dist_cg_solve (the loop of a rank in C: fixed batches, stop word read one batch late, halo by neighbour
+    send/recv pairs or by all-gathered slabs) under a multi-rank partition: ranks share cuda:0, the collective entry points
+    are host-staged stand-ins (tests/_dist_worker.py).  Bitwise equal to the single-rank oracle solve."""
+    r = _run(world, kind, nx, ny, 1e-8, -1, tmp_path, mode=mode)
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {0} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+
+
+@pytest.mark.gpu
+def test_dist_cg_c_driven_loop_maxiter_cutoff(tmp_path):
+    r = _run(2, "poisson", 96, 64, 1e-12, 9, tmp_path, mode="native")
+    assert r["bitwise_equal"] and set(r["iterations"]) == {9} and set(r["info"]) == {-1} and r["ref_info"] == -1
+
+
+@pytest.mark.gpu
 def test_dist_cg_nccl_world1_equals_single_gpu(tmp_path):
     """RCCL path smoke test at world_size 1 (the only size the 1-GPU box allows): DistPoissonProblem + dist_cg
     through torch.distributed 'nccl' must equal the single-device cg() bit for bit."""
@@ -92,6 +112,8 @@ from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 prob = DistPoissonProblem(nx_per_rank=96, ny=64, rank=0, world=1, device=torch.device("cuda", 0))
 assert prob.comm is not None, "direct RCCL communicator expected on the nccl backend"
+from pytorch_sparse_solver.distributed import native_loop_ok
+assert native_loop_ok(prob), "the C-driven loop (hipk_dist_cg_solve) is the default with direct RCCL"
 # exercise the grouped send/recv wrapper (a rank never sends to itself in the solver): self exchange of 3 + 2 doubles
 a = torch.arange(5, dtype=torch.float64, device="cuda:0"); r = torch.zeros(5, dtype=torch.float64, device="cuda:0")
 prob.comm.all_to_all(r, a, [5], [5]); torch.cuda.synchronize(); assert torch.equal(r, a)
