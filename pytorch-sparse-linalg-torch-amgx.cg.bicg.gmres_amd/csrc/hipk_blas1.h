@@ -86,7 +86,9 @@ __device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
 //     ... stop test, fold of the partials ...
 //     pre.run([&](int64_t i, int nv, T (&v)[NV][VEC]) { ... });   // same element order as hipk_chunk_loop
 // Larger chunks continue with ordinary loads.  NV = 2 keeps the kernels at 8 workgroups per CU.
-template <typename T, int NV>
+// NT: the operands are STREAMS (the iteration's working set is far larger than the 256 MiB Infinity Cache, N >> 8 M rows):
+// non-temporal loads, so that they do not displace each other's lines on their way through.
+template <typename T, int NV, bool NT = false>
 struct hipk_pre {
     static constexpr int VEC = hipk_vec<T>::VEC;
     static constexpr int N = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // register-resident steps per thread
@@ -108,7 +110,10 @@ struct hipk_pre {
             nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
             if (nvs[k] > 0) {
 #pragma unroll
-                for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nvs[k], v[k][a]);
+                for (int a = 0; a < NV; ++a) {
+                    if (NT) hipk_ld_nt_vec<T>(ptr[a], i, nvs[k], v[k][a]);
+                    else hipk_ld<T>(ptr[a], i, nvs[k], v[k][a]);
+                }
             }
         }
     }
@@ -121,7 +126,10 @@ struct hipk_pre {
             const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
             T w[NV][VEC];
 #pragma unroll
-            for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nv, w[a]);
+            for (int a = 0; a < NV; ++a) {
+                if (NT) hipk_ld_nt_vec<T>(ptr[a], i, nv, w[a]);
+                else hipk_ld<T>(ptr[a], i, nv, w[a]);
+            }
             f(i, nv, w);
         }
     }

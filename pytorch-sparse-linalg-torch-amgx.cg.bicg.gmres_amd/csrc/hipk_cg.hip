@@ -69,13 +69,14 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_start_kernel(
 // until the stop test has passed).  Order of operations per element is unchanged.
 // SMALL (systems of <= 8 reduction chunks, launch-bound): <p,Ap> is folded here from the SpMV's per-wavefront tile
 // sums (hipk_fold_tiles8: part_pAp then points at them, `ntiles` tiles), the combine launch is skipped.
-template <typename T, bool SMALL = false>
+// NT (systems whose CG working set -- x, r, p, Ap -- is far beyond the Infinity Cache): every vector is a stream.
+template <typename T, bool SMALL = false, bool NT = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal, int64_t it,
     const double *__restrict__ part_pAp, const T *__restrict__ Ap, T *__restrict__ r, double *__restrict__ part_rr,
     int ntiles = 0) {
     const int c = blockIdx.x;
-    hipk_pre<T, 2> pre;
+    hipk_pre<T, 2, NT> pre;
     pre.issue(n, ch, c, {Ap, (const T *)r});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[HIPK_THREADS];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     if (threadIdx.x == 0) part_rr[c] = acc;
 }
 
-template <typename T, bool SMALL = false>
+template <typename T, bool SMALL = false, bool NT = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const int c = blockIdx.x;
     // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
     // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
-    hipk_pre<T, 2> pre;
+    hipk_pre<T, 2, NT> pre;
     pre.issue(n, ch, c, {r, (const T *)p});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T xv[VEC], pv[VEC];
-        hipk_ld<T>((const T *)x, i, nv, xv);
+        if (NT) hipk_ld_nt_vec<T>((const T *)x, i, nv, xv);
+        else hipk_ld<T>((const T *)x, i, nv, xv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const T m0 = alpha * v[1][k];
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
             const T m = beta * v[1][k];
             pv[k] = v[0][k] + m;  // TSL:852
         }
-        hipk_st<T>(x, i, nv, xv);
+        if (NT) hipk_st_nt_vec<T>(x, i, nv, xv);   // x is not read again before the next direction kernel
+        else hipk_st<T>(x, i, nv, xv);
         hipk_st<T>(p, i, nv, pv);
     });
     if (c == 0 && threadIdx.x == 0) {
@@ -232,6 +235,10 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     const bool small = gm.g <= 8 && !getenv("HIPK_CG_NO_SMALL");
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     sa.skip_combine = small ? 1 : 0;
+    // x, r, p, Ap beyond 1.5 x the 256 MiB Infinity Cache: the vector kernels treat every operand as a stream
+    // (HIPK_CG_STREAMS=0/1 forces the choice: A/B measurements)
+    bool streams = 4 * (size_t)n * sizeof(T) > (size_t)384 << 20;
+    if (const char *e = getenv("HIPK_CG_STREAMS")) streams = e[0] == '1';
 
     int64_t it = 0, stop = INT64_MAX;
     for (; it < maxiter; ++it) {
@@ -245,6 +252,8 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             if (small)
                 hipk_cg_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, A->tile_part, Ap, r,
                                                                                   part_b, ntiles);
+            else if (streams)
+                hipk_cg_update_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
             else
                 hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
             if (prm->profile == 2) prof.after(stream);
@@ -252,6 +261,9 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             if (small)
                 hipk_cg_direction_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter,
                                                                                      A->tile_part, part_b, r, p, x, ntiles);
+            else if (streams)
+                hipk_cg_direction_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
+                                                                                            part_b, r, p, x);
             else
                 hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
                                                                                 part_b, r, p, x);
