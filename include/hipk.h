@@ -306,6 +306,10 @@ typedef struct {
     const int32_t *ghost_src_dev; /* [n_ghost] halo_mode 0: position of each halo entry in the gathered slabs */
     const int32_t *send_counts;   /* host, [world]: entries sent to each rank                             */
     const int32_t *recv_counts;   /* host, [world]: halo entries received from each rank (in rank order)  */
+    const int64_t *send_first;    /* host, [world] or NULL: halo_mode 1, >= 0 where the entries for that rank are the
+                                     CONTIGUOUS local rows send_first[p] .. + send_counts[p] (row blocks of a stencil):
+                                     they are sent straight from the vector, and when that holds for every peer the pack
+                                     kernel is not launched at all                                       */
 } hipk_dist_plan;
 
 size_t hipk_dist_cg_work_bytes(const hipk_dist_plan *plan);

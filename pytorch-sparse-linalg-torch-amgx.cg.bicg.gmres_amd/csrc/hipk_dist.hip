@@ -125,11 +125,16 @@ extern "C" int hipk_dist_cg_solve(hipk_csr_t A, const hipk_dist_plan *pl, const 
         return HIPK_OK;
     };
     // the peers' entries this rank's rows reference -> v[n .. n_ext)   (neighbour send/recv pairs, one group)
+    // contiguous send ranges go out straight from the vector; the pack kernel runs only if some peer's list is scattered
+    bool need_pack = false;
+    for (int peer = 0; peer < W; ++peer)
+        if (pl->send_counts[peer] > 0 && !(pl->send_first && pl->send_first[peer] >= 0)) need_pack = true;
     auto halo_p2p_calls = [&](double *v) -> int {
         size_t so = 0, ro = 0;
         for (int peer = 0; peer < W; ++peer) {
             const size_t ns = (size_t)pl->send_counts[peer], nr = (size_t)pl->recv_counts[peer];
-            if (ns) HIPK_NCCL(cc->send(send_buf + so, ns, NCCL_F64, peer, cc->comm, stream), "send(halo)");
+            const bool direct = pl->send_first && pl->send_first[peer] >= 0;
+            if (ns) HIPK_NCCL(cc->send(direct ? v + pl->send_first[peer] : send_buf + so, ns, NCCL_F64, peer, cc->comm, stream), "send(halo)");
             if (nr) HIPK_NCCL(cc->recv(v + n + ro, nr, NCCL_F64, peer, cc->comm, stream), "recv(halo)");
             so += ns;
             ro += nr;
@@ -139,7 +144,7 @@ extern "C" int hipk_dist_cg_solve(hipk_csr_t A, const hipk_dist_plan *pl, const 
     auto halo_exchange = [&](double *v) -> int {   // stand-alone form (setup and the final residual)
         if (W == 1 || (pl->n_send == 0 && pl->n_ghost == 0 && pl->halo_mode == 1)) return HIPK_OK;
         if (pl->halo_mode == 1) {
-            if (pl->n_send) HIPK_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, send_buf, HIPK_F64, stream));
+            if (pl->n_send && need_pack) HIPK_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, send_buf, HIPK_F64, stream));
             HIPK_NCCL(cc->group_start(), "group_start");
             HIPK_TRY(halo_p2p_calls(v));
             HIPK_NCCL(cc->group_end(), "group_end");
@@ -154,7 +159,7 @@ extern "C" int hipk_dist_cg_solve(hipk_csr_t A, const hipk_dist_plan *pl, const 
     auto gather_parts_and_halo = [&](double *dst, double *v) -> int {
         if (W == 1) return gather_parts(dst);
         if (pl->halo_mode == 1) {
-            if (pl->n_send) HIPK_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, send_buf, HIPK_F64, stream));
+            if (pl->n_send && need_pack) HIPK_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, send_buf, HIPK_F64, stream));
             HIPK_NCCL(cc->group_start(), "group_start");
             HIPK_NCCL(cc->all_gather(part_loc, dst, (size_t)per, NCCL_F64, cc->comm, stream), "all_gather(partials)");
             HIPK_TRY(halo_p2p_calls(v));

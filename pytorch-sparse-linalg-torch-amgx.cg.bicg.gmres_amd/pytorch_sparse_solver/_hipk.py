@@ -118,7 +118,8 @@ class DistPlan(ctypes.Structure):
                 ("per", ctypes.c_int32), ("halo_mode", ctypes.c_int32), ("n_send", ctypes.c_int32),
                 ("n_ghost", ctypes.c_int32), ("slab", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("send_idx_dev", ctypes.c_void_p), ("ghost_src_dev", ctypes.c_void_p),
-                ("send_counts", ctypes.POINTER(ctypes.c_int32)), ("recv_counts", ctypes.POINTER(ctypes.c_int32))]
+                ("send_counts", ctypes.POINTER(ctypes.c_int32)), ("recv_counts", ctypes.POINTER(ctypes.c_int32)),
+                ("send_first", ctypes.POINTER(ctypes.c_int64))]
 
 
 # hipk_precond_fn (include/hipk.h): int M(void *user, const void *in_dev, void *out_dev)

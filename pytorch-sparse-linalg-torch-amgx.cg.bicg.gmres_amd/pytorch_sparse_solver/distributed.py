@@ -99,6 +99,14 @@ class HaloPlan:
         self.n_send = int(self.send_idx.numel())
         if self.n_send:
             assert int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < part.n_local
+        # per destination: first local row if its list is one contiguous ascending range (row blocks of a stencil), else -1
+        self.send_first, o = [], 0
+        idx_h = self.send_idx.cpu()
+        for cnt in self.send_splits:
+            seg = idx_h[o:o + cnt]
+            ok = cnt > 0 and bool((seg[1:] - seg[:-1] == 1).all())
+            self.send_first.append(int(seg[0]) if ok else -1)
+            o += cnt
         # all-gather form of the same exchange (the halo can then ride with another all-gather):
         # every rank contributes its packed send list padded to `slab` entries; ghost k of owner o sits at
         # o*slab + (offset of my block in o's send list) + (k's index in my request to o)
@@ -409,6 +417,8 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     sc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.send_splits])
     rc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.recv_splits])
     plan.send_counts, plan.recv_counts = sc, rc
+    sf = (ctypes.c_int64 * part.world)(*[int(v) for v in pl.send_first])
+    plan.send_first = sf
     coll = prob.coll_struct()
     x = prob.ops.zeros(n_ext)
     if x0_local is not None:
