@@ -567,17 +567,6 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !getenv("HIPK_SPMV_SELL_NO_MODE"))
                         pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
-                    // uniform tiles decoded into scalar registers (hipk_spmv_sell_uni_kernel): needs the per-tile code words
-                    static const bool no_uni = getenv("HIPK_SPMV_SELL_NO_UNI") != nullptr;
-                    if (!no_uni && h->tile_ucode) {
-#define HIPK_PICK_UNI(T, M) (h->sell_w == 5 ? hipk_spmv_sell_uni_kernel<T, 5, M> : h->sell_w == 8 ? hipk_spmv_sell_uni_kernel<T, 8, M> : hipk_spmv_sell_uni_kernel<T, 4, M>)
-                        if (h->dtype == HIPK_F64)
-                            pk = (a.mode == HIPK_SPMV_DOT_W && h->sell_w == 5) ? hipk_spmv_sell_uni_kernel<double, 5, HIPK_SPMV_DOT_W>
-                                                                               : HIPK_PICK_UNI(double, -1);
-                        else
-                            pk = HIPK_PICK_UNI(float, -1);
-#undef HIPK_PICK_UNI
-                    }
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
                         (pocc * h->n_cu >= a.g || pocc >= occ))

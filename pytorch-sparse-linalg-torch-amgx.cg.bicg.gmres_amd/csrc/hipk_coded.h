@@ -873,210 +873,4 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
         }
     }
 }
-// ------------------------------------------------------------------ uniform tiles from SCALAR registers
-// PMC of the kernels above on the N = 4 M Poisson matrix (profiles/r02_spmv_counters.md): 113 vector-ALU instructions per
-// tile and wavefront (906 per wavefront of 8 tiles), the vector ALU 60 % busy, 40 % of the wave cycles waiting for their turn
-// to issue: the kernel is bound by instruction issue, not by bytes or by the gather round trip (two tiles per trip changed
-// nothing).  Most of those instructions re-derive, in every lane, what is the same for all 256 rows of a UNIFORM tile (87 %
-// of the tiles of a constant-coefficient stencil): byte extraction, two dictionary look-ups, address arithmetic and a
-// padding select per entry.  Here a uniform tile's offsets and values are decoded ONCE per distinct code word into scalar
-// registers; its x gathers are `scalar base + lane offset` loads (the tile index and the entry's column offset are folded
-// into the scalar base, the lane offset t * sizeof(T) never changes), its row sum is NE multiplies and adds with scalar
-// coefficients.  Tiles whose rows differ (grid-line ends) take the per-lane path of hipk_spmv_sell_pair_kernel.  Rows are
-// summed from the same rounded products in the same (CSR) order: same bits.
-template <typename T, int UNITS, int MODE = -1>
-__global__ __launch_bounds__(HIPK_THREADS, 8) void hipk_spmv_sell_uni_kernel(hipk_spmv_args a) {  // 8 workgroups per CU: one round for 1954 chunks
-    constexpr int G0 = (UNITS + 3) / 4;
-    constexpr int NE = UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8);
-    static_assert(UNITS == 4 || UNITS == 5 || UNITS == 8, "exact tile sizes only");
-    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
-    const int tpc = a.ch / HIPK_TILE;
-    const int chunk = hipk_xcd_chunk(blockIdx.x, a.g);
-    if (chunk < 0) return;
-    const int t_first = chunk * tpc;
-    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;
-    __shared__ double wsum0[HIPK_SELL_MAX_TPC * 4];
-    __shared__ double wsum1[HIPK_SELL_MAX_TPC * 4];
-    __shared__ T dval[HIPK_CODED_MAX];
-    __shared__ int doff[HIPK_CODED_MAX];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned voff = (unsigned)t * (unsigned)sizeof(T);   // this lane's byte offset inside ANY tile-aligned vector slice
-    const unsigned char *__restrict__ code = a.code;
-    const char *__restrict__ xb = (const char *)a.x;
-    const int mode = MODE >= 0 ? MODE : a.mode;
-    const int n32 = (int)a.n;
-    const unsigned long long *__restrict__ ucode = a.tile_ucode;
-
-    T dv = (T)0;
-    int dofs = 0;
-    if (t < a.n_codes) {
-        dv = ((const T *)a.dict_val)[t];
-        dofs = a.dict_off[t];
-    }
-    // ---- decoded code word (wave-uniform: scalar registers).  Validated at every use: re-decoded when the word differs.
-    unsigned long long dec_uc = 0ull;
-    int dec_off[NE];
-    T dec_val[NE];
-    int dec_ne = 0;
-    auto decode = [&](unsigned long long uc) {
-        dec_ne = 0;
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;   // bytes 0..3 = group 0, 4..7 = group 1
-            dec_off[k] = __builtin_amdgcn_readfirstlane(doff[ck]);
-            if (sizeof(T) == 8) {
-                const double dvv = (double)dval[ck];
-                const int lo = __builtin_amdgcn_readfirstlane(__double2loint(dvv)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(dvv));
-                dec_val[k] = (T)__hiloint2double(hi, lo);
-            } else {
-                dec_val[k] = (T)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)dval[ck])));
-            }
-            if (ck != HIPK_SELL_PAD) dec_ne = k + 1;   // padding only at a row's tail
-        }
-        dec_uc = uc;
-    };
-    struct req_t {
-        unsigned long long uc;   // the tile's shared code word (scalar; fetched one trip ahead), 0: rows differ
-    };
-    struct ops_t {
-        T w, b, d;
-    };
-    auto request = [&](int tl, req_t &q) {
-        const unsigned long long u = ucode[tl];  // wave-uniform: scalar load
-        q.uc = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)u) |
-               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32);
-    };
-    // per-lane code groups of a tile whose rows differ (13 % of a stencil's tiles: loaded where they are used)
-    auto lane_codes = [&](int tl, unsigned(&c)[G0]) {
-        const unsigned char *tp = code + (size_t)tl * (UNITS * HIPK_TILE);
-        constexpr int D = UNITS >> 2, Bp = UNITS & 3;
-#pragma unroll
-        for (int g = 0; g < G0; ++g) {
-            unsigned wv = 0xFFFFFFFFu;
-            if (g < D) {
-                wv = ((const unsigned *)tp)[g * HIPK_TILE + t];
-            } else {
-                const unsigned char *bp = tp + (size_t)D * 1024 + t;
-                if (Bp >= 1) wv = (wv & 0xFFFFFF00u) | bp[0];
-                if (Bp >= 2) wv = (wv & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
-            }
-            c[g] = wv;
-        }
-    };
-    auto load_ops = [&](int tl, ops_t &o) {   // epilogue operands: scalar tile base + lane offset
-        const int row = tl * HIPK_TILE + t;
-        o.w = (T)0;
-        o.b = (T)0;
-        o.d = (T)0;
-        if (row < n32) {
-            const size_t tb = (size_t)tl * HIPK_TILE * sizeof(T);
-            if (mode & HIPK_SPMV_DOT_W) o.w = *(const T *)((const char *)a.w + tb + voff);
-            if (mode & HIPK_SPMV_RESID) o.b = *(const T *)((const char *)a.bsub + tb + voff);
-            if (mode & HIPK_SPMV_SCALE) o.d = *(const T *)((const char *)a.dscale + tb + voff);
-        }
-    };
-    auto gather = [&](const req_t &q, int tl, T(&xv)[NE], ops_t &o, unsigned(&cw)[G0]) {
-        if (q.uc != 0ull) {   // uniform tile: all 256 rows exist and share offsets (scalar) -- wave-uniform branch
-            if (q.uc != dec_uc) decode(q.uc);
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                xv[k] = (T)0;
-                if (k < dec_ne) {
-                    const char *sb = xb + ((long long)tl * HIPK_TILE + dec_off[k]) * (long long)sizeof(T);   // scalar
-                    xv[k] = *(const T *)(sb + voff);
-                }
-            }
-        } else {
-            lane_codes(tl, cw);
-            const int row = tl * HIPK_TILE + t;
-            const int rowx = row < n32 ? row : n32 - 1;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
-                xv[k] = *(const T *)(xb + bo);
-            }
-        }
-        load_ops(tl, o);
-    };
-    auto finish = [&](const req_t &q, int tl, const T(&xv)[NE], const ops_t &o, const unsigned(&cw)[G0]) {
-        const int row = tl * HIPK_TILE + t;
-        T s = (T)0;
-        if (q.uc != 0ull) {
-            if (q.uc != dec_uc) decode(q.uc);
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                if (k < dec_ne) {
-                    const T p = dec_val[k] * xv[k];
-                    s = s + p;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const T p = dval[ck] * xv[k];
-                const T s1 = s + p;
-                s = (ck != HIPK_SELL_PAD) ? s1 : s;
-            }
-        }
-        double d0 = 0.0, d1 = 0.0;
-        if (row < n32) {
-            T out = s;
-            if (mode & HIPK_SPMV_RESID) out = o.b - out;
-            if (mode & HIPK_SPMV_SCALE) out = o.d * out;
-            *(T *)((char *)a.y + (size_t)tl * HIPK_TILE * sizeof(T) + voff) = out;
-            if (mode & HIPK_SPMV_DOT_W) d0 = (double)o.w * (double)out;
-            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
-        }
-        const int slot = (tl - t_first) * 4 + wave;
-        if (mode & HIPK_SPMV_DOT_W) {
-            d0 = hipk_wave_sum(d0);
-            if (lane == 0) wsum0[slot] = d0;
-        }
-        if (mode & HIPK_SPMV_DOT_YY) {
-            d1 = hipk_wave_sum(d1);
-            if (lane == 0) wsum1[slot] = d1;
-        }
-    };
-    auto trip = [&](req_t &ca, req_t &cb, req_t &na, req_t &nb, int tp) {
-        const bool hb = tp + 1 < t_end;
-        T xa[NE], xbv[NE];
-        ops_t oa, ob;
-        unsigned cwa[G0], cwb[G0];
-        gather(ca, tp, xa, oa, cwa);
-        if (hb) gather(cb, tp + 1, xbv, ob, cwb);
-        if (tp + 2 < t_end) request(tp + 2, na);
-        if (tp + 3 < t_end) request(tp + 3, nb);
-        finish(ca, tp, xa, oa, cwa);
-        if (hb) finish(cb, tp + 1, xbv, ob, cwb);
-    };
-
-    req_t r0, r1, r2, r3;
-    r0.uc = r1.uc = r2.uc = r3.uc = 0ull;
-    if (t_first < t_end) request(t_first, r0);
-    if (t_first + 1 < t_end) request(t_first + 1, r1);
-    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
-    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
-    doff[t] = dofs;
-    __syncthreads();
-    for (int tp = t_first; tp < t_end; tp += 4) {
-        trip(r0, r1, r2, r3, tp);
-        if (tp + 2 < t_end) trip(r2, r3, r0, r1, tp + 2);
-    }
-    if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
-        __syncthreads();
-        if (wave == 0) {
-            const int cnt = t_end - t_first;
-            if (mode & HIPK_SPMV_DOT_W) {
-                const double r = hipk_wave_fold(wsum0, cnt, lane);
-                if (lane == 0) a.part0[chunk] = r;
-            }
-            if (mode & HIPK_SPMV_DOT_YY) {
-                const double r = hipk_wave_fold(wsum1, cnt, lane);
-                if (lane == 0) a.part1[chunk] = r;
-            }
-        }
-    }
-}
 #endif
