@@ -280,8 +280,9 @@ def main():
 
         path = h.path()
         fbytes = h.format_bytes()
-        chunked = "true" if nx == NX else "*"   # the chunk-per-workgroup form needs chunks of <= 64 tiles
-        spmv_name = {"coded": f"hipk_spmv_sell_loop_kernel<double,5,{chunked},false,true> (coded SpMV, uniform tiles from one word per tile, + fused <p,Ap> chunk partials)",
+        # the chunk-per-workgroup pair form needs chunks of <= 64 tiles; larger chunks take the persistent loop kernel
+        spmv_kernel = "hipk_spmv_sell_pair_kernel<double,5,true,1>" if nx == NX else "hipk_spmv_sell_loop_kernel<double,5,false,false,true>"
+        spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles from one word per tile, + fused <p,Ap> chunk partials)",
                      "tile_fast": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, path)
         coded = path in ("coded", "offset_coded")
         legs = [("spmv", 1, spmv_name, fbytes if coded else spmv_bytes,

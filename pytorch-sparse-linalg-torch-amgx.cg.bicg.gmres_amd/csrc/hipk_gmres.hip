@@ -411,49 +411,77 @@ __device__ __forceinline__ double hipk_peek(const double *p) {
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// NC-column tree of the spec (hipk_block_sum8 for NC <= 8 live columns: no LDS traffic for dead ones)
+template <int NC>
+__device__ __forceinline__ void hipk_block_sumN(double (&v)[NC], double *sbuf) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int b = 0; b < NC; ++b) sbuf[b * HIPK_THREADS + t] = v[b];
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+        for (int b = 0; b < NC; ++b)
+            sbuf[b * HIPK_THREADS + t] = sbuf[b * HIPK_THREADS + t] + sbuf[b * HIPK_THREADS + t + 128];
+    }
+    __syncthreads();
+    if (t < 64) {
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+            double a = sbuf[b * HIPK_THREADS + t] + sbuf[b * HIPK_THREADS + t + 64];
+            a = hipk_wave_sum(a);
+            v[b] = a;  // valid in lane 0
+        }
+    }
+    __syncthreads();
+}
+
 // part[j*MAXP + c] = chunk partial of <V_j, w>.  grid = g * (k/8 + 1): workgroup b takes chunk b % g of column group b / g.
-template <typename T>
+// NC = live columns of the workgroup's group, a compile-time bound (1, 2, 4, 8): the early Arnoldi steps (64-320 MB) are
+// latency-bound -- with NC <= 2 the chunk's four steps are all in flight at once and the tree only carries live columns.
+template <typename T, int NC>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_stream_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
     const T *__restrict__ w, double *__restrict__ part, int g, int nres) {
     if (k >= scal->stop_step) return;
     if (pass == 1 && !scal->pass2) return;
     const int grp = blockIdx.x / g, c = blockIdx.x % g;
-    __shared__ double sbuf[8 * HIPK_THREADS];
+    __shared__ double sbuf[NC * HIPK_THREADS];
     const int j0 = 8 * grp;
-    double acc[8];
+    double acc[NC];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[b] = 0.0;
-    hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
+    for (int b = 0; b < NC; ++b) acc[b] = 0.0;
+    hipk_chunk_loop<T, (NC <= 2 ? 4 : 1)>(n, ch, c, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T wv[VEC];
         hipk_ld<T>(w, i, nv, wv);
-        T vv[8][VEC];
+        T vv[NC][VEC];
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < NC; ++b)
             if (j0 + b <= k) {
                 if (j0 + b < nres) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
                 else hipk_ld_nt_vec<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
             }
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < NC; ++b)
             if (j0 + b <= k) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
                     if (e < nv) acc[b] = fma((double)vv[b][e], (double)wv[e], acc[b]);
             }
     });
-    hipk_block_sum8(acc, 8, sbuf);
+    hipk_block_sumN<NC>(acc, sbuf);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < NC; ++b)
             if (j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = acc[b];
     }
 }
 
 // q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305).  grid = g.
-template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_stream_kernel(
+// KC = compile-time bound on the live columns (8: the first eight Arnoldi steps, one round of column loads and few enough
+// registers for 8 workgroups per CU -- those steps are latency-bound; 32: the general form).
+template <typename T, int KC>
+__global__ __launch_bounds__(HIPK_THREADS, (KC <= 8 ? 8 : 1)) void hipk_gm_update_stream_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
     T *__restrict__ w, double *__restrict__ part_qq, int nres) {
     if (k >= scal->stop_step) return;
@@ -472,7 +500,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_stream_kernel(
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s[e] = 0.0;
 #pragma unroll
-        for (int j0 = 0; j0 < HIPK_GM_LDH; j0 += 8) {  // batches of eight column loads, then their FMAs in column order
+        for (int j0 = 0; j0 < KC; j0 += 8) {  // batches of eight column loads, then their FMAs in column order
             if (j0 <= k) {
                 T vv[8][VEC];
 #pragma unroll
@@ -1379,16 +1407,25 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                                                                                           part_qq, part_md, gm.g);
                 } else {
                     if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
-                    if (stream_k)
-                        hipk_gm_multidot_stream_kernel<T><<<gm.g * (k / 8 + 1), HIPK_THREADS, 0, stream>>>(
-                            n, gm.ch, scal, k, pass, V, ldv, w, part_md, gm.g, gm_nres);
+                    if (stream_k) {
+                        const int mg = gm.g * (k / 8 + 1);
+#define HIPK_MD(NC) hipk_gm_multidot_stream_kernel<T, NC><<<mg, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_md, gm.g, gm_nres)
+                        if (k == 0) HIPK_MD(1);
+                        else if (k == 1) HIPK_MD(2);
+                        else if (k < 4) HIPK_MD(4);
+                        else HIPK_MD(8);
+#undef HIPK_MD
+                    }
                     else
                         hipk_gm_multidot_kernel<T, false><<<mgrid, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
                                                                                               part_md, part_qq, gm.g, eps_t);
                     hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, gm.g, part_md);
-                    if (stream_k)
-                        hipk_gm_update_stream_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                            part_qq, gm_nres);
+                    if (stream_k && k < 8)
+                        hipk_gm_update_stream_kernel<T, 8><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                               part_qq, gm_nres);
+                    else if (stream_k)
+                        hipk_gm_update_stream_kernel<T, HIPK_GM_LDH><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
+                                                                                                         part_qq, gm_nres);
                     else
                         hipk_gm_update_kernel<T, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
                                                                                            part_qq, part_md, gm.g);
