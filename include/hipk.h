@@ -321,6 +321,22 @@ int hipk_dist_cg_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const hip
                        void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
                        hipk_stream_t stream);
 
+/* ---- EXPERIMENTAL peer-to-peer exchange provider for the loop above (csrc/hipk_p2p.hip) ---------------------------------
+ * Each rank owns a device mailbox that every peer maps through HIP IPC; an all-gather is ONE small kernel per rank (publish
+ * blocks store into the peers' mailboxes, collect blocks wait on per-source sequence flags).  No reference counterpart.
+ * Protocol: create on every rank -> export the 64-byte handle -> exchange the handles out of band (rank order) -> connect.
+ * hipk_p2p_group_start/_group_end/_all_gather have the signatures of the hipk_rccl members (comm = the hipk_p2p_t);
+ * leave hipk_rccl.send/.recv NULL and hipk_dist_plan.halo_mode 0.  max_count = the largest `count` of any call. */
+typedef struct hipk_p2p_s *hipk_p2p_t;
+int hipk_p2p_create(hipk_p2p_t *out, int rank, int world, size_t max_count);
+int hipk_p2p_export(hipk_p2p_t c, void *handle64);
+int hipk_p2p_connect(hipk_p2p_t c, const void *handles /* world x 64 bytes */);
+int hipk_p2p_destroy(hipk_p2p_t c);
+int hipk_p2p_error(hipk_p2p_t c); /* 1: a wait gave up (a peer never published); results of that call are void */
+int hipk_p2p_group_start(void);
+int hipk_p2p_group_end(void);
+int hipk_p2p_all_gather(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

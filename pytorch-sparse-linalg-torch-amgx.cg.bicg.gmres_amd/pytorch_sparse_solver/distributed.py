@@ -292,6 +292,45 @@ class RcclComm:
             self.comm = None
 
 
+class P2PComm:
+    """EXPERIMENTAL exchange provider (csrc/hipk_p2p.hip, HIPK_DIST_COMM=p2p): every rank's device mailbox is mapped by
+    its peers through HIP IPC and an all-gather is one small kernel per rank instead of an RCCL collective launch.
+    Only the C-driven loop uses it (all-gathered-slab halo); the IPC handles travel once through torch.distributed."""
+
+    def __init__(self, rank: int, world: int, device, max_count: int, group=None):
+        from . import _hipk
+        self.L = L = _hipk.lib()
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        self.ctx = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hipk._check(L.hipk_p2p_create(ctypes.byref(self.ctx), rank, world, max(int(max_count), 1)), "hipk_p2p_create")
+            mine = ctypes.create_string_buffer(64)
+            _hipk._check(L.hipk_p2p_export(self.ctx, mine), "hipk_p2p_export")
+            box = [None] * world
+            if world > 1:
+                dist.all_gather_object(box, mine.raw, group=group)
+            else:
+                box[0] = mine.raw
+            assert all(len(h) == 64 for h in box)
+            _hipk._check(L.hipk_p2p_connect(self.ctx, b"".join(box)), "hipk_p2p_connect")
+        if world > 1:
+            dist.barrier(group=group)   # every mailbox is mapped before anyone publishes
+
+    def coll_struct(self):
+        from . import _hipk
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value   # noqa: E731
+        return _hipk.Rccl(addr(self.L.hipk_p2p_group_start), addr(self.L.hipk_p2p_group_end),
+                          addr(self.L.hipk_p2p_all_gather), None, None, self.ctx.value)
+
+    def failed(self) -> bool:
+        return bool(self.L.hipk_p2p_error(self.ctx))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.hipk_p2p_destroy(self.ctx)
+            self.ctx = None
+
+
 @dataclass
 class DistStats:
     iterations: int
@@ -334,9 +373,16 @@ class DistProblem:
             except Exception as e:  # stay functional on the well-trodden torch.distributed path
                 import warnings
                 warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed collectives")
+        # opt-in: device mailboxes instead of RCCL for the C-driven loop's two exchanges (experimental, see P2PComm)
+        self.p2p = None
+        if want == "p2p" and isinstance(ops, HipOps) and (part.world == 1 or dist.is_initialized()):
+            self.p2p = P2PComm(part.rank, part.world, ops.device, max(part.per, self.plan.slab), group)
+            self.comm_kind = "p2p-mailbox"
 
     def coll_struct(self):
         """hipk_rccl for the C-driven loop, or None (then the Python loop with torch.distributed collectives runs)."""
+        if getattr(self, "p2p", None) is not None:
+            return self.p2p.coll_struct()
         return self.comm.coll_struct() if self.comm is not None else None
 
     # ---- the three collectives of the solver (overridable: tests stage them through the host)
@@ -406,6 +452,9 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     n, n_ext = part.n_local, max(prob.n_ext, 1)
     peers = sum(1 for a, b in zip(pl.send_splits, pl.recv_splits) if a or b)
     mode = os.environ.get("HIPK_DIST_HALO", "p2p" if peers <= 4 else "allgather")
+    coll = prob.coll_struct()
+    if not coll.send or not coll.recv:
+        mode = "allgather"          # a provider without send/recv (P2PComm): the halo rides in the gathered slabs
     plan = _hipk.DistPlan()
     plan.rank, plan.world = part.rank, part.world
     plan.n_local, plan.n_ext, plan.n_global = n, prob.n_ext, part.n_global
@@ -419,7 +468,6 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     plan.send_counts, plan.recv_counts = sc, rc
     sf = (ctypes.c_int64 * part.world)(*[int(v) for v in pl.send_first])
     plan.send_first = sf
-    coll = prob.coll_struct()
     x = prob.ops.zeros(n_ext)
     if x0_local is not None:
         x[:n] = x0_local
@@ -435,6 +483,8 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
                                      work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st),
                                      torch.cuda.current_stream(dev).cuda_stream)
     _hipk._check(rcode, "hipk_dist_cg_solve")
+    if getattr(prob, "p2p", None) is not None and prob.p2p.failed():
+        raise RuntimeError("hipk_p2p: a rank never published its part of an exchange (wait bound hit); results discarded")
     return x[:n], int(st.info), DistStats(int(st.iterations), int(st.matvecs), int(st.info), st.b_norm, st.residual_norm,
                                           st.x_norm, st.threshold)
 

@@ -150,9 +150,18 @@ class HostStagedNative(HostStagedProblem):
         return self._coll
 
 
+class MailboxNative(HostStagedProblem):
+    """The C-driven loop with the product's device-mailbox exchange (P2PComm, csrc/hipk_p2p.hip): several ranks on ONE
+    GPU map each other's mailboxes through HIP IPC -- no host staging anywhere in the iteration."""
+
+    def coll_struct(self):
+        return self.p2p.coll_struct()
+
+
 def main():
     kind, nx, ny, tol, maxiter, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag")
+    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag", "native_p2p")
+    mailbox = len(sys.argv) > 7 and sys.argv[7] == "native_p2p"
     native = len(sys.argv) > 7 and sys.argv[7].startswith("native")
     if len(sys.argv) > 7 and sys.argv[7] == "native_ag":
         os.environ["HIPK_DIST_HALO"] = "allgather"
@@ -169,7 +178,7 @@ def main():
         from pytorch_sparse_solver.distributed import HaloPlan, HipOps
         plan = HaloPlan(lcol, part)                       # plan collectives on CPU tensors (gloo)
         dev = torch.device("cuda", 0)
-        cls = HostStagedNative if native else HostStagedProblem
+        cls = MailboxNative if mailbox else HostStagedNative if native else HostStagedProblem
         prob = cls.__new__(cls)
         ops = HipOps(dev)
         for name in ("col_local", "send_idx", "ghost_src"):
@@ -183,6 +192,9 @@ def main():
         prob.send_buf = ops.empty(max(plan.n_send, 1))
         prob.slab_loc, prob.slab_all = ops.zeros(plan.slab), ops.zeros(plan.slab * world)
         prob.comm = None
+        if mailbox:
+            from pytorch_sparse_solver.distributed import P2PComm
+            prob.p2p = P2PComm(rank, world, dev, max(part.per, plan.slab))
     else:
         prob = DistProblem(lc, lcol, lval, lb, part, OracleOps())
     if native:

@@ -94,6 +94,19 @@ def test_dist_cg_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, mode, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny", [(2, "poisson", 96, 64), (3, "poisson", 96, 64), (2, "random_spd", 80, 77),
+                                              (2, "poisson", 4, 8000)])
+def test_dist_cg_c_driven_loop_device_mailboxes(world, kind, nx, ny, tmp_path):
+    """The same loop with the experimental device-mailbox exchange (csrc/hipk_p2p.hip, HIPK_DIST_COMM=p2p): ranks share
+    cuda:0 and map each other's mailboxes through HIP IPC, so NOTHING in the iteration is staged through the host --
+    the exchange kernels of different processes really wait on each other's flags.  Bitwise equal to the oracle."""
+    r = _run(world, kind, nx, ny, 1e-8, -1, tmp_path, mode="native_p2p")
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {0} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+
+
+@pytest.mark.gpu
 def test_dist_cg_c_driven_loop_maxiter_cutoff(tmp_path):
     r = _run(2, "poisson", 96, 64, 1e-12, 9, tmp_path, mode="native")
     assert r["bitwise_equal"] and set(r["iterations"]) == {9} and set(r["info"]) == {-1} and r["ref_info"] == -1
