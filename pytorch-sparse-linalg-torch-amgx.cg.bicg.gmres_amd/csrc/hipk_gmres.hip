@@ -1029,6 +1029,328 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
 #undef HIPK_STAMP
 }
 
+// =====================================================================================================================
+// The same cycle with the BASIS RESIDENT IN LDS and each reduction chunk shared by EIGHT workgroups.
+// hipk_gm_cycle_small_kernel keeps one workgroup per chunk busy: at n = 10^4 that is 5 compute units, and every multi-dot /
+// update re-reads the live columns of its chunk from L2 (a step costs ~33 us).  The spec's chunk tree
+// (v[t] += v[t+s], s = 128 .. 1 over the 256 virtual threads) keeps the residues t mod 8 apart until its last three levels:
+// sub-workgroup s of chunk c owns the 32 virtual threads t = s + 8u (their 256 rows: 16-byte pieces, 128 bytes apart), runs
+// their chains and the five tree levels s = 128 .. 8 on its own (a 32-lane register reduction) and publishes a SUB-partial;
+// whoever needs the chunk partial adds the eight sub-partials ((p0+p4)+(p2+p6))+((p1+p5)+(p3+p7)) -- the tree's levels
+// s = 4, 2, 1.  Same additions, same order, same bits as the one-workgroup-per-chunk form.
+//   * thread (u = tid & 31, e = tid >> 5) owns ONE row -- element e (0..7) of virtual thread u's chain -- with the row's
+//     matrix entries in registers for the whole cycle (rows > 16 entries: the tail is re-read);
+//   * the 256 rows x m basis columns of the sub-workgroup live in LDS (61 KB fp64 at restart 30): multi-dot and update
+//     never touch memory; the only global traffic of a step is the new vector (published for the gathers of the next SpMV
+//     and for the x update after the cycle), the sub-partials and the tile sums of <w,w>;
+//   * <w,w> is the TILED dot of the SpMV epilogue (wavefront sums over 64 CONTIGUOUS rows): sub-workgroup s re-reads tile s
+//     of its chunk (published by the eight owners of those rows) one barrier later and forms the four wavefront sums.
+// Three counter barriers per step as before; 8 g workgroups (<= 64) on one XCD, at most two per compute unit.
+template <typename T, class F>
+__device__ __forceinline__ double hipk_fold_8x8(int i8, int g, F val) {
+    // lanes i8 = 0..7 of an 8-lane group: inner fold of val(i8, 0..7), then the spec's fold of <= 8 chunk partials across
+    // the group (row_shl 4, 2, 1); valid where i8 == 0.  All 8 lanes must be active.
+    double a = 0.0;
+    if (i8 < g) {
+        double p[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) p[s] = val(i8, s);
+        a = 0.0 + (((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7])));
+    } else {
+        a = 0.0 + 0.0;
+    }
+    a = a + hipk_row_shl<4>(a);
+    a = a + hipk_row_shl<2>(a);
+    a = a + hipk_row_shl<1>(a);
+    return a;
+}
+// sum over the 32 lanes of a half wavefront with the strides 16 .. 1 of the spec's tree; valid in lanes 0 and 32
+__device__ __forceinline__ double hipk_half_sum(double d) {
+    d = d + hipk_lane_up16(d);
+    d = d + hipk_row_shl<8>(d);
+    d = d + hipk_row_shl<4>(d);
+    d = d + hipk_row_shl<2>(d);
+    d = d + hipk_row_shl<1>(d);
+    return d;
+}
+// column k of H from rvec and ||q||, breakdown, and for 'incremental' the Givens update + early-exit test (TSL:358-387,
+// 595-623); one thread.  Returns true when the cycle stops after this step.
+__device__ __forceinline__ bool hipk_gm_hcolumn(hipk_gm_scal *scal, int k, const double *rv, double norm1, double *hc) {
+    double *H = scal->H;
+    for (int j = 0; j <= k; ++j) H[j * HIPK_GM_LDH + k] = rv[j];
+    H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+    scal->steps_done = k + 1;
+    bool stp = false;
+    if (norm1 == 0.0) {  // TSL:387
+        scal->breakdown = 1;
+        stp = true;
+    }
+    if (scal->incremental) {
+        for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * HIPK_GM_LDH + k];
+        for (int i = 0; i < k; ++i) {
+            const double cs = scal->gv[2 * i], sn = scal->gv[2 * i + 1];
+            const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+            const double t0 = p0 - p1;
+            const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
+            hc[i + 1] = p2 + p3;
+            hc[i] = t0;
+        }
+        double cs, sn;
+        hipk_givens(hc[k], hc[k + 1], cs, sn);
+        scal->gv[2 * k] = cs;
+        scal->gv[2 * k + 1] = sn;
+        {
+            const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
+            hc[k] = p0 - p1;
+        }
+        hc[k + 1] = 0.0;
+        for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
+        double *bv = scal->beta_vec;
+        const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
+        const double t0 = p0 - p1;
+        const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
+        bv[k + 1] = p2 + p3;
+        bv[k] = t0;
+        const double err = fabs(bv[k + 1]);
+        scal->err = err;
+        if (!(err > scal->ptol)) stp = true;  // TSL:591
+    }
+    return stp;
+}
+
+static constexpr int kGmSub = 8;        // sub-workgroups per reduction chunk
+static constexpr int kGmRowRegs = 16;   // matrix entries of the own row held in registers
+// LDS of hipk_gm_cycle_lds_kernel: m basis columns of 256 rows + w + small arrays
+template <typename T>
+static inline size_t hipk_gm_cycle_lds_bytes(int m) {
+    return (size_t)m * 256 * sizeof(T) + 256 * sizeof(T) + (3 * HIPK_GM_LDH + 8) * sizeof(double) + 64;
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm_cyc_args<T> a) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
+    const int wg = blockIdx.x >> 3;
+    const int c = wg / kGmSub, s = wg % kGmSub;
+    const int g = a.g, nwg = g * kGmSub;
+    if (c >= g) return;
+    hipk_gm_scal *scal = a.scal;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = tid & 31, e8 = tid >> 5;           // virtual thread s + 8u of the chunk, element e8 of its chain
+    const int64_t n = a.n;
+    const int m = a.m;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t row = base + (int64_t)VEC * (s + kGmSub * u) + (int64_t)(e8 / VEC) * (VEC * HIPK_THREADS) + (e8 % VEC);
+    const bool live = row < n;
+    const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tile = c * (HIPK_BASE_CHUNK / HIPK_TILE) + s;          // the tile whose <w,w> wavefront sums this workgroup forms
+    const int64_t trow = (int64_t)tile * HIPK_TILE + tid;
+
+    extern __shared__ __align__(16) unsigned char hipk_gm_lds_raw[];
+    T *Vl = (T *)hipk_gm_lds_raw;                                    // [m][8][32]
+    T *wl = Vl + (size_t)m * 256;                                    // [8][32]
+    double *hs = (double *)(wl + 256);                               // [32]
+    double *rv = hs + HIPK_GM_LDH;                                   // [32]
+    double *hc = rv + HIPK_GM_LDH;                                   // [33] (thread 0 of workgroup 0)
+    double *bc = hc + HIPK_GM_LDH + 1;                               // [4]
+    int *fail = (int *)(bc + 4);
+    long long *stop_lds = (long long *)(bc + 5);
+    if (tid == 0) {
+        *fail = 0;
+        *stop_lds = m;
+    }
+    if (tid < HIPK_GM_LDH) rv[tid] = 0.0;
+
+    // the own row of the matrix, for the whole cycle
+    int lo = 0, len = 0;
+    if (live) {
+        lo = a.crow[row];
+        len = a.crow[row + 1] - lo;
+    }
+    int cj[kGmRowRegs];
+    T vj[kGmRowRegs];
+#pragma unroll
+    for (int j = 0; j < kGmRowRegs; ++j) {
+        cj[j] = (j < len) ? a.col[lo + j] : 0;
+        vj[j] = (j < len) ? a.val[lo + j] : (T)0;
+    }
+    const T dsc = (a.dscale && live) ? a.dscale[row] : (T)1;
+    Vl[tid] = live ? a.V[row] : (T)0;                // column 0: written by the launch before this one
+    __syncthreads();
+    int epoch = 0;
+#ifdef HIPK_GM_STAMPS
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
+#define HIPK_STAMP(slot)                                              \
+    if (stamping) {                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        t_acc[slot] += now_ - t_prev;                                 \
+        t_prev = now_;                                                \
+    }
+    if (stamping) t_prev = __builtin_amdgcn_s_memtime();
+#else
+#define HIPK_STAMP(slot)
+#endif
+
+    for (int k = 0; k < m; ++k) {
+        const T *vk = a.V + (int64_t)k * a.ldv;
+        T *wg_col = a.V + (int64_t)(k + 1) * a.ldv;
+        // ---------------- A: w = (M) A v_k on the own row; the stop word of the previous step travels with the gathers
+        if (tid == 0 && k > 0)
+            *stop_lds = __hip_atomic_load((const long long *)&scal->stop_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T xs[kGmRowRegs];
+#pragma unroll
+        for (int j = 0; j < kGmRowRegs; ++j) xs[j] = (j < len) ? hipk_peek_t<T>(vk + cj[j]) : (T)0;
+        T acc_row = (T)0;
+#pragma unroll
+        for (int j = 0; j < kGmRowRegs; ++j)
+            if (j < len) {
+                const T p = vj[j] * xs[j];
+                acc_row = acc_row + p;
+            }
+        for (int j = kGmRowRegs; j < len; ++j) {
+            const T p = a.val[lo + j] * hipk_peek_t<T>(vk + a.col[lo + j]);
+            acc_row = acc_row + p;
+        }
+        T w_own = acc_row;
+        if (a.dscale) w_own = dsc * w_own;
+        if (!live) w_own = (T)0;
+        __syncthreads();
+        if (k >= *stop_lds) break;                   // uniform: every workgroup reads the same word after the same barrier
+        wl[tid] = w_own;
+        if (live) hipk_publish_t(wg_col + row, w_own);   // for the tile sums of <w,w> (formed by the tile's workgroup in B)
+        __syncthreads();
+        HIPK_STAMP(0)
+        for (int pass = 0; pass < 2; ++pass) {
+            // ---------------- multi-dot sub-partials: thread (u, e8) runs the chains of columns e8, e8 + 8, e8 + 16, e8 + 24
+            {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double wv = (double)wl[e * 32 + u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = e8 + 8 * i;
+                        if (j <= k) acc[i] = fma((double)Vl[((size_t)j * 8 + e) * 32 + u], wv, acc[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = e8 + 8 * i;
+                    const double v = hipk_half_sum(acc[i]);
+                    if (u == 0 && j <= k) hipk_publish(&a.part_md[(size_t)j * HIPK_MAX_PARTS + wg], v);
+                }
+            }
+            HIPK_STAMP(1)
+            if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+                if (tid == 0) scal->redo = -1;
+                return;
+            }
+            HIPK_STAMP(2)
+            // ---------------- B: h = fold of the sub-partials (thread (j, chunk i8): 8 loads, register folds)
+            T wt = (T)0;
+            if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wg_col + trow);     // tile sums of <w,w>: in flight with the fold
+            {
+                const int j = tid >> 3, i8 = tid & 7;
+                const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
+                double hj = 0.0;
+                if (j <= k)   // uniform per 8-lane group
+                    hj = hipk_fold_8x8<T>(i8, g, [&](int ci, int ss) { return hipk_peek(pj + ci * kGmSub + ss); });
+                if (i8 == 0) {
+                    hj = (j <= k) ? hj : 0.0;
+                    hs[j] = hj;
+                    rv[j] = ((pass == 0) ? 0.0 : rv[j]) + hj;   // rvec += h (TSL:305), kept by every workgroup
+                }
+            }
+            if (pass == 0) {
+                double d1 = (double)wt * (double)wt;
+                d1 = hipk_wave_sum(d1);
+                if (lane == 0 && tile < ntiles) hipk_publish(&a.tile_ww[(size_t)tile * 4 + wave], d1);
+            }
+            __syncthreads();
+            // q = w - V h on the own row
+            {
+                double sacc = 0.0;
+                for (int j = 0; j <= k; ++j) sacc = fma((double)Vl[((size_t)j * 8 + e8) * 32 + u], hs[j], sacc);
+                w_own = (T)((double)w_own - sacc);
+                wl[tid] = w_own;
+            }
+            __syncthreads();
+            if (tid < 32) {   // <q,q>: the chain of virtual thread u, then the 32-lane tree
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double x = (double)wl[e * 32 + tid];
+                    acc = fma(x, x, acc);
+                }
+                acc = hipk_half_sum(acc);
+                if (tid == 0) hipk_publish(&a.part_qq[wg], acc);
+            }
+            HIPK_STAMP(3)
+            if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+                if (tid == 0) scal->redo = -1;
+                return;
+            }
+            HIPK_STAMP(4)
+            // ---------------- C: ||q||^2 (every workgroup, same bits); CGS2 decision after the first pass (TSL:313-326)
+            if (tid < 8) {
+                const double qq = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.part_qq + ci * kGmSub + ss); });
+                if (tid == 0) {
+                    bc[1] = qq;
+                    double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+                    if (!(qnorm > a.eps)) qnorm = 0.0;
+                    double rr = 0.0;
+                    for (int j = 0; j <= k; ++j) rr = fma(rv[j], rv[j], rr);
+                    double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                    if (!(rnorm > a.eps)) rnorm = 0.0;
+                    bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
+                }
+            } else if (tid >= 64 && tid < 72 && pass == 0) {
+                // ||A v||^2 from the tile sums (hipk_fold_tiles8: per chunk the fold of its <= 8 tiles, then the chunks)
+                const double *tp = a.tile_ww;
+                const double ww = hipk_fold_8x8<T>(tid - 64, g, [&](int ci, int tt) {
+                    const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
+                    if (tl >= ntiles) return 0.0;
+                    const double *w4 = tp + (size_t)tl * 4;
+                    const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+                    return 0.0 + ((w0 + w1) + (w2 + w3));
+                });
+                if (tid == 64) bc[2] = ww;
+            }
+            __syncthreads();
+            if (pass == 1 || bc[0] == 0.0) break;
+            __syncthreads();
+        }
+        // ---------------- normalise: v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), TSL:358-387
+        const double qq = bc[1], ww = bc[2];
+        double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
+        double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
+        if (!(norm0 > a.eps)) norm0 = 0.0;
+        const double thr = a.eps * norm0;
+        const bool use = norm1 > thr;
+        const T nrm = (T)norm1;
+        const T vnew = (use && live) ? w_own / nrm : (T)0;
+        if (k + 1 < m) Vl[(size_t)(k + 1) * 256 + tid] = vnew;
+        if (live) hipk_publish_t(wg_col + row, vnew);   // gathered by the next SpMV; read by the x update after the cycle
+        if (wg == 0 && tid == 0) {
+            if (!use) norm1 = 0.0;
+            if (hipk_gm_hcolumn(scal, k, rv, norm1, hc))
+                __hip_atomic_store((long long *)&scal->stop_step, (long long)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        HIPK_STAMP(5)
+        if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+            if (tid == 0) scal->redo = -1;
+            return;
+        }
+        HIPK_STAMP(6)
+    }
+#ifdef HIPK_GM_STAMPS
+    if (stamping)
+        for (int i = 0; i < 8; ++i) a.stamps[i] += t_acc[i];
+#endif
+#undef HIPK_STAMP
+}
+
 // after a speculation miss at step k (hipk_gm_normalize_kernel, guard): steps >= k of the cycle are enqueued again
 __global__ void hipk_gm_resume_kernel(hipk_gm_scal *__restrict__ scal) {
     scal->stop_step = INT64_MAX;
@@ -1338,7 +1660,9 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     const bool small = gm.g <= 8 && !getenv("HIPK_GMRES_NO_SMALL");  // launch-bound systems: fewer launches per step
     const bool wide = small && gm.ch == HIPK_BASE_CHUNK && !getenv("HIPK_GMRES_NO_WIDE");  // hipk_gm_update_wide_kernel
     // small systems with short rows: the whole restart cycle in ONE launch (hipk_gm_cycle_small_kernel)
-    const bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
+    bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
+    // ... with the basis in LDS and eight workgroups per chunk (hipk_gm_cycle_lds_kernel) when m columns of 256 rows fit
+    bool cyc_lds = cyc && hipk_gm_cycle_lds_bytes<T>(m) <= 65536 && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     const bool stream_k = !small && !getenv("HIPK_GMRES_NO_STREAM");  // large systems: hipk_gm_*_stream_kernel
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
@@ -1374,7 +1698,10 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
             if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 64, stream);
-            hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
+            if (cyc_lds)
+                hipk_gm_cycle_lds_kernel<T><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
+            else
+                hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
         for (int k = cyc ? m : k_start; k < m; ++k) {
             T *w = V + (int64_t)(k + 1) * ldv;
@@ -1443,9 +1770,12 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             break;
         }
         if (hs->redo < 0) {
-            hipk_set_error("hipk_gmres_solve: the resident workgroups of the small-system cycle kernel did not all arrive");
-            rc = HIPK_ERR_HIP;
-            break;
+            // the resident workgroups of a one-launch cycle did not all arrive (the device is shared and they were not
+            // co-resident): nothing of the cycle is kept -- column 0 is untouched -- and this solve goes on with one launch
+            // per kernel
+            if (getenv("HIPK_GM_STAMPS")) fprintf(stderr, "hipk_gmres_solve: one-launch cycle abandoned (workgroups not co-resident)\n");
+            cyc = cyc_lds = false;
+            continue;
         }
         if (hs->redo > 0) {  // speculation miss: second pass wanted at redo_step; enqueue the cycle again from there
             k_start = (int)hs->redo_step;
@@ -1486,7 +1816,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     }
     free(hs);
     if (rc != HIPK_OK) return rc;
-    if (cyc && getenv("HIPK_GM_STAMPS")) {  // diagnostic build-in: where workgroup 0 of the cycle kernel spent its shader clocks
+    if ((cyc || cyc_lds) && getenv("HIPK_GM_STAMPS")) {  // diagnostic build-in: where workgroup 0 of the cycle kernel spent its shader clocks
         unsigned long long st8[8];
         HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1024, sizeof(st8), hipMemcpyDeviceToHost, stream));
         HIPK_CHECK_HIP(hipStreamSynchronize(stream));

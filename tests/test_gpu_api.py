@@ -463,12 +463,30 @@ def test_gmres_wide_small_system_kernels_are_bit_identical(monkeypatch):
     monkeypatch.delenv("HIPK_GMRES_NO_WIDE", raising=False)
 
 
+def _banded_csr(n, half, dev, dtype):
+    """Nonsymmetric diagonally dominant band matrix with 2*half+1 entries per interior row (rows longer than the 16 entries
+    the LDS cycle kernel keeps in registers)."""
+    import torch
+    offs = torch.arange(-half, half + 1)
+    rows = torch.arange(n).repeat_interleave(offs.numel())
+    cols = rows + offs.repeat(n)
+    keep = (cols >= 0) & (cols < n)
+    rows, cols = rows[keep], cols[keep]
+    g = torch.Generator().manual_seed(n + half)
+    vals = torch.rand(rows.numel(), generator=g, dtype=torch.float64) - 0.3
+    vals[rows == cols] = 2.0 * half + 1.0
+    A = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, n)).coalesce().to_sparse_csr()
+    return torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().to(dtype), size=(n, n)).to(dev)
+
+
 @pytest.mark.gpu
 def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
-    """small systems with short rows run a whole restart cycle in ONE launch
-    (hipk_gm_cycle_small_kernel: a resident workgroup per chunk, counter barriers between the phases);
-    HIPK_GMRES_NO_CYCLE=1 selects the multi-launch small-system path: same bits -- ragged tails, one to eight chunks,
-    second CGS passes, breakdown / early exit, Jacobi scaling and fp32 storage included."""
+    """small systems with short rows run a whole restart cycle in ONE launch -- by default
+    hipk_gm_cycle_lds_kernel (basis resident in LDS, eight workgroups per reduction chunk, sub-partials folded with the last
+    three levels of the spec's tree), with HIPK_GMRES_NO_LDS_CYCLE=1 hipk_gm_cycle_small_kernel (one workgroup per chunk);
+    HIPK_GMRES_NO_CYCLE=1 selects the multi-launch small-system path.  Same bits from all three -- ragged tails, one to
+    eight chunks, second CGS passes, breakdown / early exit, Jacobi scaling, fp32 storage, rows beyond the register-held
+    16 entries and restart lengths on either side of a multiple of 8 included."""
     import torch
     from pytorch_sparse_solver.module_a import JacobiPreconditioner, get_last_stats, gmres
     from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_ldc_pressure_csr,
@@ -476,7 +494,10 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
     dev = "cuda:0"
     mats = [create_convdiff_2d_csr(100, 100, device=dev), create_ldc_pressure_csr(100, device=dev),
             create_convdiff_2d_csr(7, 5, device=dev), create_convdiff_2d_csr(128, 128, device=dev),
-            create_ldc_pressure_csr(47, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev)]
+            create_ldc_pressure_csr(47, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
+            _banded_csr(5000, 12, dev, torch.float64), _banded_csr(2049, 9, dev, torch.float64)]
+    restarts = {3: 7, 6: 17, 7: 9}
+    variants = ({}, {"HIPK_GMRES_NO_LDS_CYCLE": "1"}, {"HIPK_GMRES_NO_CYCLE": "1"})
     for mi, A in enumerate(mats):
         n = A.shape[0]
         for dt in (torch.float64, torch.float32):
@@ -486,20 +507,22 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
             for method, M in (("batched", None), ("incremental", None), ("batched", "jacobi")):
                 if M == "jacobi" and mi not in (0, 5):
                     continue
-                kw = dict(tol=1e-9 if dt == torch.float64 else 1e-4, restart=30 if mi != 3 else 7, maxiter=6, solve_method=method)
+                kw = dict(tol=1e-9 if dt == torch.float64 else 1e-4, restart=restarts.get(mi, 30), maxiter=6, solve_method=method)
                 if M == "jacobi":
                     kw["M"] = JacobiPreconditioner(Ad)
-                out = {}
-                for flag in ("0", "1"):
-                    if flag == "1":
-                        monkeypatch.setenv("HIPK_GMRES_NO_CYCLE", "1")
-                    else:
-                        monkeypatch.delenv("HIPK_GMRES_NO_CYCLE", raising=False)
+                out = []
+                for env in variants:
+                    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE"):
+                        monkeypatch.delenv(key, raising=False)
+                    for key, v in env.items():
+                        monkeypatch.setenv(key, v)
                     x, info = gmres(Ad, b, **kw)
                     st = get_last_stats()
-                    out[flag] = (x.clone(), info, st.iterations, st.matvecs, st.residual_norm)
-                assert torch.equal(out["0"][0], out["1"][0]) and out["0"][1:] == out["1"][1:], (n, dt, method, M)
-    monkeypatch.delenv("HIPK_GMRES_NO_CYCLE", raising=False)
+                    out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
+                for o in out[1:]:
+                    assert torch.equal(out[0][0], o[0]) and out[0][1:] == o[1:], (n, dt, method, M)
+    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE"):
+        monkeypatch.delenv(key, raising=False)
     # a tiny exactly solvable system: happy breakdown inside the cycle kernel
     A = torch.eye(5, dtype=torch.float64, device=dev).to_sparse_csr()
     x, info = gmres(A, torch.arange(1.0, 6.0, dtype=torch.float64, device=dev), tol=1e-12, restart=5)
