@@ -52,6 +52,11 @@ struct hipk_gm_scal {
     int32_t bar;        // counter barrier of hipk_gm_cycle_small_kernel (zeroed by hipk_gm_cycle_init_kernel)
     int32_t redo;       // speculation miss: a second CGS pass was wanted at a step whose pass-2 launches were not enqueued
     int64_t redo_step;
+    // hipk_gm_cycle_lds_kernel: per-workgroup hand-off flags and the XCDs its workgroups found themselves on
+    unsigned long long flag_md[64];
+    unsigned long long flag_q[64];
+    unsigned xcc_mask;
+    unsigned pad2;
 };
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
@@ -672,6 +677,10 @@ struct hipk_gm_cyc_args {
     double *part_md;   // [m + 1][HIPK_MAX_PARTS]
     double *part_qq;   // [HIPK_MAX_PARTS]
     double *tile_ww;   // [ntiles * 4] per-wavefront sums of <w,w>
+    T *q;              // hipk_gm_cycle_lds_kernel: the unnormalised q of the step, gathered by the next SpMV
+    int incremental;   //   solve_method 'incremental' (TSL:557-638)
+    double ptol;       //   its early-exit threshold (TSL:591)
+    double beta0;      //   ||r|| at the start of the cycle (beta_vec[0])
     int32_t *bar;      // barrier counter, zeroed by hipk_gm_cycle_init_kernel
     double eps;
     unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
@@ -1123,11 +1132,66 @@ static constexpr int kGmRowRegs = 16;   // matrix entries of the own row held in
 // LDS of hipk_gm_cycle_lds_kernel: m basis columns of 256 rows + w + small arrays
 template <typename T>
 static inline size_t hipk_gm_cycle_lds_bytes(int m) {
-    return (size_t)m * 256 * sizeof(T) + 256 * sizeof(T) + (3 * HIPK_GM_LDH + 8) * sizeof(double) + 64;
+    return (size_t)m * 256 * sizeof(T) + 256 * sizeof(T) + (5 * HIPK_GM_LDH + 12) * sizeof(double) + 64;
 }
 
-template <typename T>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm_cyc_args<T> a) {
+// ---- hand-offs between the workgroups of hipk_gm_cycle_lds_kernel
+// LOCAL = true: every workgroup runs on the SAME XCD (verified at kernel start from HW_REG_XCC_ID, else the launch gives up):
+// that XCD's L2 is their coherence point, so payload and flags are PLAIN stores (the lines stay in L2) read with sc1 loads
+// (which only bypass the reader's L1): a hand-off costs L2 round trips.  LOCAL = false: agent-scope (sc1, write-through)
+// stores, valid on any placement, every trip through the fabric.  Each workgroup owns one flag word per hand-off kind and
+// stores the hand-off's sequence number into it after ALL its waves have drained their stores; a consumer polls the
+// <= 64 flags with one wave-wide load.
+template <bool LOCAL>
+__device__ __forceinline__ void hipk_ho_store(double *p, double v) {
+    if (LOCAL)
+        __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else
+        hipk_publish(p, v);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void hipk_ho_store(float *p, float v) {
+    if (LOCAL)
+        __hip_atomic_store((unsigned *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else
+        hipk_publish_t(p, v);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void hipk_ho_flag(unsigned long long *p, unsigned long long v) {
+    if (LOCAL)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// signal hand-off number `seq` (flag value 2 seq + bit) for this workgroup, then wait until every workgroup has signalled it.
+// Returns the flag word of workgroup 0 (its low bit carries the stop decision), or ~0 when the spin bound was hit.
+template <bool LOCAL>
+__device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *flags, int wg, int nwg, unsigned long long seq,
+                                                           unsigned bit, unsigned long long *res_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront: its stores have arrived
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) hipk_ho_flag<LOCAL>(flags + wg, 2 * seq + bit);
+        unsigned long long f, f0 = ~0ull;
+        unsigned spins = 0;
+        for (;;) {
+            f = (lane < nwg) ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            if (__all(f >= 2 * seq)) {
+                f0 = __shfl(f, 0);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) break;   // seconds: a workgroup of this launch is not running
+        }
+        if (lane == 0) *res_lds = f0;
+    }
+    __syncthreads();
+    return *res_lds;
+}
+
+template <typename T, bool LOCAL>
+__global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk_gm_cyc_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
     if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
     const int wg = blockIdx.x >> 3;
@@ -1154,10 +1218,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
     double *hc = rv + HIPK_GM_LDH;                                   // [33] (thread 0 of workgroup 0)
     double *bc = hc + HIPK_GM_LDH + 1;                               // [4]
     int *fail = (int *)(bc + 4);
-    long long *stop_lds = (long long *)(bc + 5);
+    unsigned long long *res_lds = (unsigned long long *)(bc + 5);
+    double *gvl = bc + 6;                                            // [64] Givens rotations of the cycle (workgroup 0)
+    double *bvl = gvl + 2 * HIPK_GM_LDH;                             // [2] beta_vec[k], beta_vec[k+1]
     if (tid == 0) {
         *fail = 0;
-        *stop_lds = m;
+        bvl[0] = a.beta0;
+        bvl[1] = 0.0;
     }
     if (tid < HIPK_GM_LDH) rv[tid] = 0.0;
 
@@ -1175,9 +1242,41 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
         vj[j] = (j < len) ? a.val[lo + j] : (T)0;
     }
     const T dsc = (a.dscale && live) ? a.dscale[row] : (T)1;
+    int wmax = len < kGmRowRegs ? len : kGmRowRegs;   // register-held entries of the longest row of this wavefront
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(wmax, off);
+        wmax = o > wmax ? o : wmax;
+    }
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
     Vl[tid] = live ? a.V[row] : (T)0;                // column 0: written by the launch before this one
-    __syncthreads();
     int epoch = 0;
+    if (LOCAL) {
+        // all workgroups on one XCD?  (the only exchange of this launch that does not rely on it: agent-scope atomics)
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+            if (tid == 0) scal->redo = -1;
+            return;
+        }
+        if (tid == 0) {
+            const unsigned mask = __hip_atomic_load(&scal->xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *fail = (__builtin_popcount(mask) == 1) ? 0 : 1;
+        }
+        __syncthreads();
+        if (*fail) {                                 // uniform over the launch: every workgroup reads the same mask
+            if (tid == 0) scal->redo = -2;
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
+    unsigned long long seq = 0;                      // hand-offs so far (uniform over the launch)
+    unsigned stop_bit = 0;                           // workgroup 0: the cycle stops after the step just finished
+    T nrm_prev = (T)1;
+    bool use_prev = true;
 #ifdef HIPK_GM_STAMPS
     unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
@@ -1193,63 +1292,74 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
 #endif
 
     for (int k = 0; k < m; ++k) {
-        const T *vk = a.V + (int64_t)k * a.ldv;
-        T *wg_col = a.V + (int64_t)(k + 1) * a.ldv;
-        // ---------------- A: w = (M) A v_k on the own row; the stop word of the previous step travels with the gathers
-        if (tid == 0 && k > 0)
-            *stop_lds = __hip_atomic_load((const long long *)&scal->stop_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---------------- A: w = (M) A v_k on the own row.  v_k = q / ||q|| is formed HERE from the unnormalised q the owners
+        // published before the last hand-off (same division, same bits as the owner's own copy): no hand-off after normalising.
+        const T *src = (k == 0) ? a.V : a.q;
+        T *wcol = a.V + (int64_t)(k + 1) * a.ldv;
         T xs[kGmRowRegs];
 #pragma unroll
-        for (int j = 0; j < kGmRowRegs; ++j) xs[j] = (j < len) ? hipk_peek_t<T>(vk + cj[j]) : (T)0;
+        for (int j = 0; j < kGmRowRegs; ++j)
+            if (j < wmax) xs[j] = hipk_peek_t<T>(src + cj[j]);   // uniform per wavefront; unused slots gather entry 0
         T acc_row = (T)0;
 #pragma unroll
         for (int j = 0; j < kGmRowRegs; ++j)
-            if (j < len) {
-                const T p = vj[j] * xs[j];
-                acc_row = acc_row + p;
+            if (j < wmax) {
+                const T xv = (k == 0) ? xs[j] : (use_prev ? xs[j] / nrm_prev : (T)0);
+                const T p = vj[j] * xv;
+                acc_row = (j < len) ? acc_row + p : acc_row;
             }
         for (int j = kGmRowRegs; j < len; ++j) {
-            const T p = a.val[lo + j] * hipk_peek_t<T>(vk + a.col[lo + j]);
+            T xv = hipk_peek_t<T>(src + a.col[lo + j]);
+            if (k > 0) xv = use_prev ? xv / nrm_prev : (T)0;
+            const T p = a.val[lo + j] * xv;
             acc_row = acc_row + p;
         }
         T w_own = acc_row;
         if (a.dscale) w_own = dsc * w_own;
         if (!live) w_own = (T)0;
-        __syncthreads();
-        if (k >= *stop_lds) break;                   // uniform: every workgroup reads the same word after the same barrier
         wl[tid] = w_own;
-        if (live) hipk_publish_t(wg_col + row, w_own);   // for the tile sums of <w,w> (formed by the tile's workgroup in B)
+        if (live) hipk_ho_store<LOCAL>(wcol + row, w_own);   // for the tile sums of <w,w> (formed by the tile's workgroup in B)
         __syncthreads();
         HIPK_STAMP(0)
+        bool stopped = false;
         for (int pass = 0; pass < 2; ++pass) {
             // ---------------- multi-dot sub-partials: thread (u, e8) runs the chains of columns e8, e8 + 8, e8 + 16, e8 + 24
+            // (all LDS loads of a column group issued before its chain: no per-element branches)
             {
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                double wv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const double wv = (double)wl[e * 32 + u];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = e8 + 8 * i;
-                        if (j <= k) acc[i] = fma((double)Vl[((size_t)j * 8 + e) * 32 + u], wv, acc[i]);
-                    }
-                }
+                for (int e = 0; e < 8; ++e) wv[e] = (double)wl[e * 32 + u];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int j = e8 + 8 * i;
-                    const double v = hipk_half_sum(acc[i]);
-                    if (u == 0 && j <= k) hipk_publish(&a.part_md[(size_t)j * HIPK_MAX_PARTS + wg], v);
+                    if (8 * i <= k) {   // uniform
+                        const int j = e8 + 8 * i;
+                        const bool on = j <= k;
+                        const int jj = on ? j : 0;
+                        T vv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] = Vl[((size_t)jj * 8 + e) * 32 + u];
+                        double acc = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc = fma((double)vv[e], wv[e], acc);
+                        const double v = hipk_half_sum(acc);
+                        if (u == 0 && on) hipk_ho_store<LOCAL>(&a.part_md[(size_t)j * HIPK_MAX_PARTS + wg], v);
+                    }
                 }
             }
             HIPK_STAMP(1)
-            if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+            const unsigned long long f0 = hipk_ho_sync<LOCAL>(scal->flag_md, wg, nwg, ++seq, (pass == 0) ? stop_bit : 0u, res_lds);
+            if (f0 == ~0ull) {
                 if (tid == 0) scal->redo = -1;
                 return;
             }
             HIPK_STAMP(2)
+            if (pass == 0 && (f0 & 1ull)) {          // workgroup 0 closed the cycle at the step before this one
+                stopped = true;
+                break;
+            }
             // ---------------- B: h = fold of the sub-partials (thread (j, chunk i8): 8 loads, register folds)
             T wt = (T)0;
-            if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wg_col + trow);     // tile sums of <w,w>: in flight with the fold
+            if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wcol + trow);     // tile sums of <w,w>: in flight with the fold
             {
                 const int j = tid >> 3, i8 = tid & 7;
                 const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
@@ -1265,15 +1375,42 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
             if (pass == 0) {
                 double d1 = (double)wt * (double)wt;
                 d1 = hipk_wave_sum(d1);
-                if (lane == 0 && tile < ntiles) hipk_publish(&a.tile_ww[(size_t)tile * 4 + wave], d1);
+                if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
             }
             __syncthreads();
-            // q = w - V h on the own row
+            if (tid == 192) {   // ||rvec|| for the CGS2 decision (TSL:313-326), while the other wavefronts update
+                double rr = 0.0;
+                for (int j0 = 0; j0 <= k; j0 += 8) {
+                    double r_[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) r_[b] = rv[(j0 + b <= k) ? j0 + b : k];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j0 + b <= k) rr = fma(r_[b], r_[b], rr);
+                }
+                double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                if (!(rnorm > a.eps)) rnorm = 0.0;
+                bc[3] = rnorm;
+            }
+            // q = w - V h on the own row; published unnormalised for the gathers of the next SpMV
             {
                 double sacc = 0.0;
-                for (int j = 0; j <= k; ++j) sacc = fma((double)Vl[((size_t)j * 8 + e8) * 32 + u], hs[j], sacc);
+                for (int j0 = 0; j0 <= k; j0 += 8) {   // eight columns' loads in flight, then their links of the chain
+                    T vv[8];
+                    double hh[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int jj = (j0 + b <= k) ? j0 + b : k;
+                        vv[b] = Vl[(size_t)jj * 256 + tid];
+                        hh[b] = hs[jj];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j0 + b <= k) sacc = fma((double)vv[b], hh[b], sacc);
+                }
                 w_own = (T)((double)w_own - sacc);
                 wl[tid] = w_own;
+                if (live) hipk_ho_store<LOCAL>(a.q + row, w_own);
             }
             __syncthreads();
             if (tid < 32) {   // <q,q>: the chain of virtual thread u, then the 32-lane tree
@@ -1284,10 +1421,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
                     acc = fma(x, x, acc);
                 }
                 acc = hipk_half_sum(acc);
-                if (tid == 0) hipk_publish(&a.part_qq[wg], acc);
+                if (tid == 0) hipk_ho_store<LOCAL>(&a.part_qq[wg], acc);
             }
             HIPK_STAMP(3)
-            if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
+            if (hipk_ho_sync<LOCAL>(scal->flag_q, wg, nwg, ++seq, 0u, res_lds) == ~0ull) {
                 if (tid == 0) scal->redo = -1;
                 return;
             }
@@ -1299,10 +1436,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
                     bc[1] = qq;
                     double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
                     if (!(qnorm > a.eps)) qnorm = 0.0;
-                    double rr = 0.0;
-                    for (int j = 0; j <= k; ++j) rr = fma(rv[j], rv[j], rr);
-                    double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
-                    if (!(rnorm > a.eps)) rnorm = 0.0;
+                    const double rnorm = bc[3];
                     bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
                 }
             } else if (tid >= 64 && tid < 72 && pass == 0) {
@@ -1321,6 +1455,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
             if (pass == 1 || bc[0] == 0.0) break;
             __syncthreads();
         }
+        if (stopped) break;
         // ---------------- normalise: v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), TSL:358-387
         const double qq = bc[1], ww = bc[2];
         double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
@@ -1331,18 +1466,76 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_cycle_lds_kernel(hipk_gm
         const T nrm = (T)norm1;
         const T vnew = (use && live) ? w_own / nrm : (T)0;
         if (k + 1 < m) Vl[(size_t)(k + 1) * 256 + tid] = vnew;
-        if (live) hipk_publish_t(wg_col + row, vnew);   // gathered by the next SpMV; read by the x update after the cycle
-        if (wg == 0 && tid == 0) {
+        if (live) wcol[row] = vnew;                  // read by the x update after the cycle (a later launch)
+        nrm_prev = nrm;
+        use_prev = use;
+        if (wg == 0) {   // column k of H, breakdown, 'incremental': Givens update + early exit (TSL:358-387, 595-623)
             if (!use) norm1 = 0.0;
-            if (hipk_gm_hcolumn(scal, k, rv, norm1, hc))
-                __hip_atomic_store((long long *)&scal->stop_step, (long long)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid <= k) scal->H[tid * HIPK_GM_LDH + k] = rv[tid];
+            if (tid == 0) {
+                scal->H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+                scal->steps_done = k + 1;
+                bool stp = false;
+                if (norm1 == 0.0) {  // TSL:387
+                    scal->breakdown = 1;
+                    stp = true;
+                }
+                if (a.incremental) {
+                    // the rotations of the earlier steps live in LDS (gvl); eight at a time: loads first, then the dependent chain
+                    double cur = rv[0];   // hc[i] under rotation i; hc[i+1] is still rvec[i+1] when rotation i reads it
+                    for (int i0 = 0; i0 < k; i0 += 8) {
+                        double cs8[8], sn8[8], nx8[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const int ii = (i0 + b < k) ? i0 + b : k - 1;
+                            cs8[b] = gvl[2 * ii];
+                            sn8[b] = gvl[2 * ii + 1];
+                            nx8[b] = rv[ii + 1];
+                        }
+#pragma unroll
+                        for (int b = 0; b < 8; ++b)
+                            if (i0 + b < k) {
+                                const double cs = cs8[b], sn = sn8[b];
+                                const double p0 = cs * cur, p1 = sn * nx8[b];
+                                const double t0 = p0 - p1;
+                                const double p2 = sn * cur, p3 = cs * nx8[b];
+                                scal->R[(i0 + b) * HIPK_GM_LDH + k] = t0;
+                                cur = p2 + p3;
+                            }
+                    }
+                    double hk = cur;
+                    const double hk1 = norm1;
+                    double cs, sn;
+                    hipk_givens(hk, hk1, cs, sn);
+                    gvl[2 * k] = cs;
+                    gvl[2 * k + 1] = sn;
+                    scal->gv[2 * k] = cs;
+                    scal->gv[2 * k + 1] = sn;
+                    {
+                        const double p0 = cs * hk, p1 = sn * hk1;
+                        hk = p0 - p1;
+                    }
+                    scal->R[k * HIPK_GM_LDH + k] = hk;
+                    const double b0 = bvl[0], b1 = bvl[1];   // beta_vec[k], beta_vec[k+1]
+                    const double p0 = cs * b0, p1 = sn * b1;
+                    const double t0 = p0 - p1;
+                    const double p2 = sn * b0, p3 = cs * b1;
+                    const double bk1 = p2 + p3;
+                    scal->beta_vec[k] = t0;
+                    scal->beta_vec[k + 1] = bk1;
+                    bvl[0] = bk1;
+                    bvl[1] = 0.0;
+                    const double err = fabs(bk1);
+                    scal->err = err;
+                    if (!(err > a.ptol)) stp = true;  // TSL:591
+                }
+                if (stp) scal->stop_step = k + 1;
+                bc[3] = stp ? 1.0 : 0.0;
+            }
         }
+        __syncthreads();                             // Vl[k+1], bc[3]
+        if (wg == 0) stop_bit = (bc[3] != 0.0) ? 1u : 0u;
         HIPK_STAMP(5)
-        if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
-            if (tid == 0) scal->redo = -1;
-            return;
-        }
-        HIPK_STAMP(6)
     }
 #ifdef HIPK_GM_STAMPS
     if (stamping)
@@ -1366,8 +1559,10 @@ __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int i
         scal->R[i] = ((i / HIPK_GM_LDH) == (i % HIPK_GM_LDH)) ? 1.0 : 0.0;  // TSL:581
     for (int i = t; i < HIPK_GM_LDH * 2; i += blockDim.x) scal->gv[i] = 0.0;
     for (int i = t; i <= HIPK_GM_LDH; i += blockDim.x) scal->beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
+    for (int i = t; i < 64; i += blockDim.x) scal->flag_md[i] = scal->flag_q[i] = 0ull;
     if (t == 0) {
         scal->bar = 0;
+        scal->xcc_mask = 0;
         scal->redo = 0;
         scal->redo_step = -1;
         scal->stop_step = INT64_MAX;
@@ -1663,6 +1858,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
     // ... with the basis in LDS and eight workgroups per chunk (hipk_gm_cycle_lds_kernel) when m columns of 256 rows fit
     bool cyc_lds = cyc && hipk_gm_cycle_lds_bytes<T>(m) <= 65536 && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    // its hand-offs through the shared L2 of ONE XCD (plain stores; placement verified by the kernel), else agent-scope stores
+    bool cyc_local = !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     const bool stream_k = !small && !getenv("HIPK_GMRES_NO_STREAM");  // large systems: hipk_gm_*_stream_kernel
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
@@ -1694,12 +1891,18 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.part_md = part_md;
             ca.part_qq = part_qq;
             ca.tile_ww = A->tile_part + 4 * (size_t)nt;
+            ca.q = tmp;
+            ca.incremental = incremental;
+            ca.ptol = ptol;
+            ca.beta0 = res_norm;
             ca.bar = &scal->bar;
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
             if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 64, stream);
-            if (cyc_lds)
-                hipk_gm_cycle_lds_kernel<T><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
+            if (cyc_lds && cyc_local)
+                hipk_gm_cycle_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
+            else if (cyc_lds)
+                hipk_gm_cycle_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
             else
                 hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
@@ -1774,7 +1977,10 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             // co-resident): nothing of the cycle is kept -- column 0 is untouched -- and this solve goes on with one launch
             // per kernel
             if (getenv("HIPK_GM_STAMPS")) fprintf(stderr, "hipk_gmres_solve: one-launch cycle abandoned (workgroups not co-resident)\n");
-            cyc = cyc_lds = false;
+            if (hs->redo == -2 && cyc_lds && cyc_local)
+                cyc_local = false;      // its workgroups were spread over several XCDs: hand-offs at agent scope from now on
+            else
+                cyc = cyc_lds = false;
             continue;
         }
         if (hs->redo > 0) {  // speculation miss: second pass wanted at redo_step; enqueue the cycle again from there
