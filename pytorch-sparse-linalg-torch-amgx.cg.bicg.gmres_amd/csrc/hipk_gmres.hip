@@ -52,11 +52,18 @@ struct hipk_gm_scal {
     int32_t bar;        // counter barrier of hipk_gm_cycle_small_kernel (zeroed by hipk_gm_cycle_init_kernel)
     int32_t redo;       // speculation miss: a second CGS pass was wanted at a step whose pass-2 launches were not enqueued
     int64_t redo_step;
-    // hipk_gm_cycle_lds_kernel: per-workgroup hand-off flags and the XCDs its workgroups found themselves on
+    // hipk_gm_solve_lds_kernel: per-workgroup hand-off flags and the XCDs its workgroups found themselves on
     unsigned long long flag_md[64];
     unsigned long long flag_q[64];
     unsigned xcc_mask;
     unsigned pad2;
+    // what a launch of hipk_gm_solve_lds_kernel reports
+    long long rep_cycles;   // restart cycles finished by the launch
+    long long rep_matvecs;  // operator applications of the launch
+    int rep_status;         // 0: cycle budget of the launch used up; 1: converged or out of cycles; 2: the Cholesky factorisation
+                            // of the current cycle's normal equations failed -- H, steps_done and the basis are in memory, the
+                            // host finishes this cycle (general solve, TSL:424-428)
+    int rep_breakdown;      // a breakdown (TSL:387) happened in one of the launch's cycles
 };
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
@@ -677,10 +684,15 @@ struct hipk_gm_cyc_args {
     double *part_md;   // [m + 1][HIPK_MAX_PARTS]
     double *part_qq;   // [HIPK_MAX_PARTS]
     double *tile_ww;   // [ntiles * 4] per-wavefront sums of <w,w>
-    T *q;              // hipk_gm_cycle_lds_kernel: the unnormalised q of the step, gathered by the next SpMV
+    T *q;              // hipk_gm_solve_lds_kernel: the unnormalised q of the step, gathered by the next SpMV
     int incremental;   //   solve_method 'incremental' (TSL:557-638)
     double ptol;       //   its early-exit threshold (TSL:591)
     double beta0;      //   ||r|| at the start of the cycle (beta_vec[0])
+    const T *b;        // hipk_gm_solve_lds_kernel: right-hand side, solution (updated in place),
+    T *x;
+    double atol_eff;   //   the loop test `res_norm > atol_eff` (TSL:754),
+    long long cycles_left;  // cycles the solve may still run (maxiter - cycles so far),
+    long long max_cycles;   // and the cycle budget of one launch
     int32_t *bar;      // barrier counter, zeroed by hipk_gm_cycle_init_kernel
     double eps;
     unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
@@ -1128,14 +1140,8 @@ __device__ __forceinline__ bool hipk_gm_hcolumn(hipk_gm_scal *scal, int k, const
 }
 
 static constexpr int kGmSub = 8;        // sub-workgroups per reduction chunk
-static constexpr int kGmRowRegs = 16;   // matrix entries of the own row held in registers
-// LDS of hipk_gm_cycle_lds_kernel: m basis columns of 256 rows + w + small arrays
-template <typename T>
-static inline size_t hipk_gm_cycle_lds_bytes(int m) {
-    return (size_t)m * 256 * sizeof(T) + 256 * sizeof(T) + (5 * HIPK_GM_LDH + 12) * sizeof(double) + 64;
-}
-
-// ---- hand-offs between the workgroups of hipk_gm_cycle_lds_kernel
+static constexpr int kGmRowRegs = 12;   // matrix entries of the own row held in registers
+// ---- hand-offs between the workgroups of hipk_gm_solve_lds_kernel
 // LOCAL = true: every workgroup runs on the SAME XCD (verified at kernel start from HW_REG_XCC_ID, else the launch gives up):
 // that XCD's L2 is their coherence point, so payload and flags are PLAIN stores (the lines stay in L2) read with sc1 loads
 // (which only bypass the reader's L1): a hand-off costs L2 round trips.  LOCAL = false: agent-scope (sc1, write-through)
@@ -1190,8 +1196,177 @@ __device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *f
     return *res_lds;
 }
 
+// LDS carve of hipk_gm_solve_lds_kernel (doubles after the T arrays)
+struct hipk_gm_lds_off {
+    static constexpr int hs = 0;                                   // [32]
+    static constexpr int rv = hs + HIPK_GM_LDH;                    // [32]
+    static constexpr int bc = rv + HIPK_GM_LDH;                    // [8]  broadcast slots
+    static constexpr int gv = bc + 8;                              // [64] Givens rotations of the cycle
+    static constexpr int bv = gv + 2 * HIPK_GM_LDH;                // [34] beta_vec of the cycle
+    static constexpr int hr = bv + HIPK_GM_LDH + 2;                // [33][32] H ('batched') or R ('incremental') of the cycle
+    static constexpr int lp = hr + (HIPK_GM_LDH + 1) * HIPK_GM_LDH;  // [496] packed lower triangle: A^T A, then its Cholesky factor
+    static constexpr int yl = lp + HIPK_GM_LDH * (HIPK_GM_LDH - 1) / 2;  // [32] y
+    static constexpr int zl = yl + HIPK_GM_LDH;                    // [32] z
+    static constexpr int total = zl + HIPK_GM_LDH;
+};
+template <typename T>
+static inline size_t hipk_gm_solve_lds_bytes(int m) {
+    return (size_t)(m + 1) * 256 * sizeof(T) + (size_t)hipk_gm_lds_off::total * sizeof(double) + 64;
+}
+
+// y of the cycle from the LDS copy of H (TSL:391-421: normal equations + Cholesky) in the operation order of
+// hipk_lstsq_normal / the oracle.  All 256 threads form the lower triangle of H^T H (each entry its own fma chain over
+// p = 0..k); the factorisation and the two triangular solves run in wavefront 0, lane i owning row i: every chain keeps
+// the ascending order of the sequential code.  Returns false when a pivot is not positive.
+__device__ __forceinline__ bool hipk_gm_lstsq_lds(double *sm, int k, double beta0, int tid) {
+    using O = hipk_gm_lds_off;
+    const double *Hl = sm + O::hr;
+    double *Lp = sm + O::lp, *yl = sm + O::yl, *zl = sm + O::zl, *bc = sm + O::bc;
+    const int nent = k * (k + 1) / 2;
+    for (int idx = tid; idx < nent; idx += HIPK_THREADS) {
+        int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > idx) --i;
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        const int j = idx - i * (i + 1) / 2;
+        double acc = 0.0;
+        for (int p0 = 0; p0 <= k; p0 += 8) {
+            double a8[8], b8[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int pp = (p0 + b <= k) ? p0 + b : k;
+                a8[b] = Hl[pp * HIPK_GM_LDH + i];
+                b8[b] = Hl[pp * HIPK_GM_LDH + j];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (p0 + b <= k) acc = fma(a8[b], b8[b], acc);
+        }
+        Lp[idx] = acc;
+    }
+    if (tid < k) zl[tid] = Hl[tid] * beta0;   // b2[i] = H[0][i] * beta0
+    if (tid == 0) bc[4] = 1.0;
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        const int ri = lane * (lane + 1) / 2;   // start of row `lane`
+        bool ok = true;
+        for (int j = 0; j < k; ++j) {
+            const int rj = j * (j + 1) / 2;
+            if (lane == j) {
+                double d = Lp[rj + j];
+                for (int p0 = 0; p0 < j; p0 += 8) {
+                    double l8[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) l8[b] = Lp[rj + ((p0 + b < j) ? p0 + b : 0)];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (p0 + b < j) d = fma(-l8[b], l8[b], d);
+                }
+                if (!(d > 0.0)) bc[4] = 0.0;
+                Lp[rj + j] = sqrt(d);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (bc[4] == 0.0) {
+                ok = false;
+                break;
+            }
+            const double ljj = Lp[rj + j];
+            if (lane > j && lane < k) {
+                double sacc = Lp[ri + j];
+                for (int p0 = 0; p0 < j; p0 += 8) {
+                    double a8[8], b8[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int pp = (p0 + b < j) ? p0 + b : 0;
+                        a8[b] = Lp[ri + pp];
+                        b8[b] = Lp[rj + pp];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (p0 + b < j) sacc = fma(-a8[b], b8[b], sacc);
+                }
+                Lp[ri + j] = sacc / ljj;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (ok) {
+            // forward: z[i] = (b2[i] - sum_{p<i} L[i][p] z[p]) / L[i][i]; lane i applies the updates in ascending p
+            double si = (lane < k) ? zl[lane] : 0.0;
+            for (int p = 0; p < k; ++p) {
+                if (lane == p) zl[p] = si / Lp[ri + p];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const double zp = zl[p];
+                if (lane > p && lane < k) si = fma(-Lp[ri + p], zp, si);
+            }
+            // backward: y[i] = (z[i] - sum_{p>i} L[p][i] y[p]) / L[i][i], ascending p: one lane at a time
+            for (int i = k - 1; i >= 0; --i) {
+                if (lane == i) {
+                    double sacc = zl[i];
+                    for (int p0 = i + 1; p0 < k; p0 += 8) {
+                        double a8[8], b8[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const int pp = (p0 + b < k) ? p0 + b : k - 1;
+                            a8[b] = Lp[pp * (pp + 1) / 2 + i];
+                            b8[b] = yl[pp];
+                        }
+#pragma unroll
+                        for (int b = 0; b < 8; ++b)
+                            if (p0 + b < k) sacc = fma(-a8[b], b8[b], sacc);
+                    }
+                    yl[i] = sacc / Lp[ri + i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    __syncthreads();
+    return bc[4] != 0.0;
+}
+// 'incremental': y from the triangular system R y = beta_vec (TSL:630), R in the LDS copy; one lane at a time
+__device__ __forceinline__ void hipk_gm_trisolve_lds(double *sm, int k, int tid) {
+    using O = hipk_gm_lds_off;
+    const double *Rl = sm + O::hr, *bv = sm + O::bv;
+    double *yl = sm + O::yl;
+    if (tid < 64) {
+        for (int i = k - 1; i >= 0; --i) {
+            if (tid == i) {
+                double sacc = bv[i];
+                for (int p0 = i + 1; p0 < k; p0 += 8) {
+                    double a8[8], b8[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int pp = (p0 + b < k) ? p0 + b : k - 1;
+                        a8[b] = Rl[i * HIPK_GM_LDH + pp];
+                        b8[b] = yl[pp];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (p0 + b < k) sacc = fma(-a8[b], b8[b], sacc);
+                }
+                yl[i] = sacc / Rl[i * HIPK_GM_LDH + i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+}
+
+// The WHOLE restarted solve of a small system in one launch: restart cycles one after the other -- Arnoldi steps as described
+// above, then on the device what the host path does between two cycle launches: y (every workgroup solves the small
+// least-squares problem itself, from its own LDS copy of H or R), x += V y on the own rows from the LDS basis, the residual
+// b - A x with its tiled norm, the unit residual as column 0, and the loop test (TSL:754-764).  The host reads one small report
+// per launch (a launch is bounded to `max_cycles` cycles).
+// sc1 load of base[byte_off / sizeof(T)]: an SGPR base + 32-bit VGPR offset, so that gathers through several bases (column 0,
+// a.q, x) do not each keep sixteen 64-bit addresses alive
+template <typename T>
+__device__ __forceinline__ T hipk_peek_off(const T *base, unsigned byte_off) {
+    return hipk_peek_t<T>((const T *)((const char *)base + (size_t)byte_off));
+}
+
 template <typename T, bool LOCAL>
-__global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk_gm_cyc_args<T> a) {
+__global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk_gm_cyc_args<T> a) {
+    using O = hipk_gm_lds_off;
     constexpr int VEC = hipk_vec<T>::VEC;
     if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
     const int wg = blockIdx.x >> 3;
@@ -1207,41 +1382,36 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk
     const int64_t row = base + (int64_t)VEC * (s + kGmSub * u) + (int64_t)(e8 / VEC) * (VEC * HIPK_THREADS) + (e8 % VEC);
     const bool live = row < n;
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
-    const int tile = c * (HIPK_BASE_CHUNK / HIPK_TILE) + s;          // the tile whose <w,w> wavefront sums this workgroup forms
+    const int tile = c * (HIPK_BASE_CHUNK / HIPK_TILE) + s;          // the tile whose wavefront sums this workgroup forms
     const int64_t trow = (int64_t)tile * HIPK_TILE + tid;
 
     extern __shared__ __align__(16) unsigned char hipk_gm_lds_raw[];
     T *Vl = (T *)hipk_gm_lds_raw;                                    // [m][8][32]
     T *wl = Vl + (size_t)m * 256;                                    // [8][32]
-    double *hs = (double *)(wl + 256);                               // [32]
-    double *rv = hs + HIPK_GM_LDH;                                   // [32]
-    double *hc = rv + HIPK_GM_LDH;                                   // [33] (thread 0 of workgroup 0)
-    double *bc = hc + HIPK_GM_LDH + 1;                               // [4]
-    int *fail = (int *)(bc + 4);
-    unsigned long long *res_lds = (unsigned long long *)(bc + 5);
-    double *gvl = bc + 6;                                            // [64] Givens rotations of the cycle (workgroup 0)
-    double *bvl = gvl + 2 * HIPK_GM_LDH;                             // [2] beta_vec[k], beta_vec[k+1]
-    if (tid == 0) {
-        *fail = 0;
-        bvl[0] = a.beta0;
-        bvl[1] = 0.0;
-    }
-    if (tid < HIPK_GM_LDH) rv[tid] = 0.0;
+    double *sm = (double *)(hipk_gm_lds_raw + (size_t)(m + 1) * 256 * sizeof(T));   // a multiple of 1 KB
+    double *hs = sm + O::hs, *rv = sm + O::rv, *bc = sm + O::bc, *gvl = sm + O::gv, *bvl = sm + O::bv, *HRl = sm + O::hr;
+    double *yl = sm + O::yl;
+    int *fail = (int *)(sm + O::total);
+    unsigned long long *res_lds = (unsigned long long *)(sm + O::total + 1);
+    if (tid == 0) *fail = 0;
+    for (int i = tid; i < (HIPK_GM_LDH + 1) * HIPK_GM_LDH; i += HIPK_THREADS) HRl[i] = 0.0;   // H below its subdiagonal stays zero
 
-    // the own row of the matrix, for the whole cycle
+    // the own row of the matrix, of b and of x, for the whole solve
     int lo = 0, len = 0;
     if (live) {
         lo = a.crow[row];
         len = a.crow[row + 1] - lo;
     }
-    int cj[kGmRowRegs];
+    unsigned cj[kGmRowRegs];   // byte offsets of the row's columns
     T vj[kGmRowRegs];
 #pragma unroll
     for (int j = 0; j < kGmRowRegs; ++j) {
-        cj[j] = (j < len) ? a.col[lo + j] : 0;
+        cj[j] = (j < len) ? (unsigned)a.col[lo + j] * (unsigned)sizeof(T) : 0u;
         vj[j] = (j < len) ? a.val[lo + j] : (T)0;
     }
     const T dsc = (a.dscale && live) ? a.dscale[row] : (T)1;
+    const T b_own = live ? a.b[row] : (T)0;
+    T x_own = live ? a.x[row] : (T)0;
     int wmax = len < kGmRowRegs ? len : kGmRowRegs;   // register-held entries of the longest row of this wavefront
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(wmax, off);
@@ -1274,9 +1444,19 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk
         __syncthreads();
     }
     unsigned long long seq = 0;                      // hand-offs so far (uniform over the launch)
-    unsigned stop_bit = 0;                           // workgroup 0: the cycle stops after the step just finished
+    // the vector the next SpMV gathers: column 0 as the launch before left it (first cycle), afterwards the UNNORMALISED q or
+    // residual in a.q, divided by its norm on the fly (same division, same bits as the owner's own copy)
+    bool from_q = false;
     T nrm_prev = (T)1;
     bool use_prev = true;
+    double beta0 = a.beta0;                          // ||r|| at the start of the cycle
+    long long cycles = 0, matvecs = 0;
+    int status = 0, breakdown_any = 0;
+#define HIPK_HO(flags)                                                         \
+    if (hipk_ho_sync<LOCAL>(flags, wg, nwg, ++seq, 0u, res_lds) == ~0ull) {    \
+        if (tid == 0) scal->redo = -1;                                         \
+        return;                                                                \
+    }
 #ifdef HIPK_GM_STAMPS
     unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
@@ -1291,193 +1471,200 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk
 #define HIPK_STAMP(slot)
 #endif
 
-    for (int k = 0; k < m; ++k) {
-        // ---------------- A: w = (M) A v_k on the own row.  v_k = q / ||q|| is formed HERE from the unnormalised q the owners
-        // published before the last hand-off (same division, same bits as the owner's own copy): no hand-off after normalising.
-        const T *src = (k == 0) ? a.V : a.q;
-        T *wcol = a.V + (int64_t)(k + 1) * a.ldv;
-        T xs[kGmRowRegs];
-#pragma unroll
-        for (int j = 0; j < kGmRowRegs; ++j)
-            if (j < wmax) xs[j] = hipk_peek_t<T>(src + cj[j]);   // uniform per wavefront; unused slots gather entry 0
-        T acc_row = (T)0;
-#pragma unroll
-        for (int j = 0; j < kGmRowRegs; ++j)
-            if (j < wmax) {
-                const T xv = (k == 0) ? xs[j] : (use_prev ? xs[j] / nrm_prev : (T)0);
-                const T p = vj[j] * xv;
-                acc_row = (j < len) ? acc_row + p : acc_row;
-            }
-        for (int j = kGmRowRegs; j < len; ++j) {
-            T xv = hipk_peek_t<T>(src + a.col[lo + j]);
-            if (k > 0) xv = use_prev ? xv / nrm_prev : (T)0;
-            const T p = a.val[lo + j] * xv;
-            acc_row = acc_row + p;
+    for (;;) {   // restart cycles
+        if (tid < HIPK_GM_LDH) rv[tid] = 0.0;
+        if (tid == 0) {
+            bvl[0] = beta0;
+            bvl[1] = 0.0;
+            bc[5] = 0.0;
+            bc[6] = 0.0;
+            if (wg == 0) scal->breakdown = 0;
         }
-        T w_own = acc_row;
-        if (a.dscale) w_own = dsc * w_own;
-        if (!live) w_own = (T)0;
-        wl[tid] = w_own;
-        if (live) hipk_ho_store<LOCAL>(wcol + row, w_own);   // for the tile sums of <w,w> (formed by the tile's workgroup in B)
-        __syncthreads();
-        HIPK_STAMP(0)
-        bool stopped = false;
-        for (int pass = 0; pass < 2; ++pass) {
-            // ---------------- multi-dot sub-partials: thread (u, e8) runs the chains of columns e8, e8 + 8, e8 + 16, e8 + 24
-            // (all LDS loads of a column group issued before its chain: no per-element branches)
-            {
-                double wv[8];
+        int kk = m;                                  // Arnoldi steps of this cycle
+        for (int k = 0; k < m; ++k) {
+            // ---------------- A: w = (M) A v_k on the own row
+            const T *src = from_q ? a.q : a.V;
+            T *wcol = a.V + (int64_t)(k + 1) * a.ldv;
+            T xs[kGmRowRegs];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) wv[e] = (double)wl[e * 32 + u];
+            for (int j = 0; j < kGmRowRegs; ++j)
+                if (j < wmax) xs[j] = hipk_peek_off<T>(src, cj[j]);   // uniform per wavefront; unused slots gather entry 0
+            T acc_row = (T)0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (8 * i <= k) {   // uniform
-                        const int j = e8 + 8 * i;
-                        const bool on = j <= k;
-                        const int jj = on ? j : 0;
+            for (int j = 0; j < kGmRowRegs; ++j)
+                if (j < wmax) {
+                    const T xv = !from_q ? xs[j] : (use_prev ? xs[j] / nrm_prev : (T)0);
+                    const T p = vj[j] * xv;
+                    acc_row = (j < len) ? acc_row + p : acc_row;
+                }
+            for (int j = kGmRowRegs; j < len; ++j) {
+                T xv = hipk_peek_t<T>(src + a.col[lo + j]);
+                if (from_q) xv = use_prev ? xv / nrm_prev : (T)0;
+                const T p = a.val[lo + j] * xv;
+                acc_row = acc_row + p;
+            }
+            T w_own = acc_row;
+            if (a.dscale) w_own = dsc * w_own;
+            if (!live) w_own = (T)0;
+            wl[tid] = w_own;
+            if (live) hipk_ho_store<LOCAL>(wcol + row, w_own);   // for the tile sums of <w,w> (formed by the tile's workgroup in B)
+            __syncthreads();
+            HIPK_STAMP(0)
+            for (int pass = 0; pass < 2; ++pass) {
+                // ---------------- multi-dot sub-partials: thread (u, e8) runs the chains of columns e8, e8 + 8, e8 + 16, e8 + 24
+                // (all LDS loads of a column group issued before its chain: no per-element branches)
+                {
+                    double wv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wv[e] = (double)wl[e * 32 + u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (8 * i <= k) {   // uniform
+                            const int j = e8 + 8 * i;
+                            const bool on = j <= k;
+                            const int jj = on ? j : 0;
+                            T vv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) vv[e] = Vl[((size_t)jj * 8 + e) * 32 + u];
+                            double acc = 0.0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc = fma((double)vv[e], wv[e], acc);
+                            const double v = hipk_half_sum(acc);
+                            if (u == 0 && on) hipk_ho_store<LOCAL>(&a.part_md[(size_t)j * HIPK_MAX_PARTS + wg], v);
+                        }
+                    }
+                }
+                HIPK_STAMP(1)
+                HIPK_HO(scal->flag_md)
+                HIPK_STAMP(2)
+                // ---------------- B: h = fold of the sub-partials (thread (j, chunk i8): 8 loads, register folds)
+                T wt = (T)0;
+                if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wcol + trow);     // tile sums of <w,w>: in flight with the fold
+                {
+                    const int j = tid >> 3, i8 = tid & 7;
+                    const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
+                    double hj = 0.0;
+                    if (j <= k)   // uniform per 8-lane group
+                        hj = hipk_fold_8x8<T>(i8, g, [&](int ci, int ss) { return hipk_peek(pj + ci * kGmSub + ss); });
+                    if (i8 == 0) {
+                        hj = (j <= k) ? hj : 0.0;
+                        hs[j] = hj;
+                        rv[j] = ((pass == 0) ? 0.0 : rv[j]) + hj;   // rvec += h (TSL:305), kept by every workgroup
+                    }
+                }
+                if (pass == 0) {
+                    double d1 = (double)wt * (double)wt;
+                    d1 = hipk_wave_sum(d1);
+                    if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
+                }
+                __syncthreads();
+                if (tid == 192) {   // ||rvec|| for the CGS2 decision (TSL:313-326), while the other wavefronts update
+                    double rr = 0.0;
+                    for (int j0 = 0; j0 <= k; j0 += 8) {
+                        double r_[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) r_[b] = rv[(j0 + b <= k) ? j0 + b : k];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b)
+                            if (j0 + b <= k) rr = fma(r_[b], r_[b], rr);
+                    }
+                    double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                    if (!(rnorm > a.eps)) rnorm = 0.0;
+                    bc[3] = rnorm;
+                }
+                // q = w - V h on the own row; published unnormalised for the gathers of the next SpMV
+                {
+                    double sacc = 0.0;
+                    for (int j0 = 0; j0 <= k; j0 += 8) {   // eight columns' loads in flight, then their links of the chain
                         T vv[8];
+                        double hh[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) vv[e] = Vl[((size_t)jj * 8 + e) * 32 + u];
-                        double acc = 0.0;
+                        for (int b = 0; b < 8; ++b) {
+                            const int jj = (j0 + b <= k) ? j0 + b : k;
+                            vv[b] = Vl[(size_t)jj * 256 + tid];
+                            hh[b] = hs[jj];
+                        }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc = fma((double)vv[e], wv[e], acc);
-                        const double v = hipk_half_sum(acc);
-                        if (u == 0 && on) hipk_ho_store<LOCAL>(&a.part_md[(size_t)j * HIPK_MAX_PARTS + wg], v);
+                        for (int b = 0; b < 8; ++b)
+                            if (j0 + b <= k) sacc = fma((double)vv[b], hh[b], sacc);
                     }
+                    w_own = (T)((double)w_own - sacc);
+                    wl[tid] = w_own;
+                    if (live) hipk_ho_store<LOCAL>(a.q + row, w_own);
                 }
-            }
-            HIPK_STAMP(1)
-            const unsigned long long f0 = hipk_ho_sync<LOCAL>(scal->flag_md, wg, nwg, ++seq, (pass == 0) ? stop_bit : 0u, res_lds);
-            if (f0 == ~0ull) {
-                if (tid == 0) scal->redo = -1;
-                return;
-            }
-            HIPK_STAMP(2)
-            if (pass == 0 && (f0 & 1ull)) {          // workgroup 0 closed the cycle at the step before this one
-                stopped = true;
-                break;
-            }
-            // ---------------- B: h = fold of the sub-partials (thread (j, chunk i8): 8 loads, register folds)
-            T wt = (T)0;
-            if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wcol + trow);     // tile sums of <w,w>: in flight with the fold
-            {
-                const int j = tid >> 3, i8 = tid & 7;
-                const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
-                double hj = 0.0;
-                if (j <= k)   // uniform per 8-lane group
-                    hj = hipk_fold_8x8<T>(i8, g, [&](int ci, int ss) { return hipk_peek(pj + ci * kGmSub + ss); });
-                if (i8 == 0) {
-                    hj = (j <= k) ? hj : 0.0;
-                    hs[j] = hj;
-                    rv[j] = ((pass == 0) ? 0.0 : rv[j]) + hj;   // rvec += h (TSL:305), kept by every workgroup
-                }
-            }
-            if (pass == 0) {
-                double d1 = (double)wt * (double)wt;
-                d1 = hipk_wave_sum(d1);
-                if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
-            }
-            __syncthreads();
-            if (tid == 192) {   // ||rvec|| for the CGS2 decision (TSL:313-326), while the other wavefronts update
-                double rr = 0.0;
-                for (int j0 = 0; j0 <= k; j0 += 8) {
-                    double r_[8];
+                __syncthreads();
+                if (tid < 32) {   // <q,q>: the chain of virtual thread u, then the 32-lane tree
+                    double acc = 0.0;
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) r_[b] = rv[(j0 + b <= k) ? j0 + b : k];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (j0 + b <= k) rr = fma(r_[b], r_[b], rr);
-                }
-                double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
-                if (!(rnorm > a.eps)) rnorm = 0.0;
-                bc[3] = rnorm;
-            }
-            // q = w - V h on the own row; published unnormalised for the gathers of the next SpMV
-            {
-                double sacc = 0.0;
-                for (int j0 = 0; j0 <= k; j0 += 8) {   // eight columns' loads in flight, then their links of the chain
-                    T vv[8];
-                    double hh[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const int jj = (j0 + b <= k) ? j0 + b : k;
-                        vv[b] = Vl[(size_t)jj * 256 + tid];
-                        hh[b] = hs[jj];
+                    for (int e = 0; e < 8; ++e) {
+                        const double x = (double)wl[e * 32 + tid];
+                        acc = fma(x, x, acc);
                     }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (j0 + b <= k) sacc = fma((double)vv[b], hh[b], sacc);
+                    acc = hipk_half_sum(acc);
+                    if (tid == 0) hipk_ho_store<LOCAL>(&a.part_qq[wg], acc);
                 }
-                w_own = (T)((double)w_own - sacc);
-                wl[tid] = w_own;
-                if (live) hipk_ho_store<LOCAL>(a.q + row, w_own);
-            }
-            __syncthreads();
-            if (tid < 32) {   // <q,q>: the chain of virtual thread u, then the 32-lane tree
-                double acc = 0.0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const double x = (double)wl[e * 32 + tid];
-                    acc = fma(x, x, acc);
+                HIPK_STAMP(3)
+                HIPK_HO(scal->flag_q)
+                HIPK_STAMP(4)
+                // ---------------- C: ||q||^2 (every workgroup, same bits); CGS2 decision after the first pass (TSL:313-326)
+                if (tid < 8) {
+                    const double qq = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.part_qq + ci * kGmSub + ss); });
+                    if (tid == 0) {
+                        bc[1] = qq;
+                        double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+                        if (!(qnorm > a.eps)) qnorm = 0.0;
+                        const double rnorm = bc[3];
+                        bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
+                    }
+                } else if (tid >= 64 && tid < 72 && pass == 0) {
+                    // ||A v||^2 from the tile sums (hipk_fold_tiles8: per chunk the fold of its <= 8 tiles, then the chunks)
+                    const double *tp = a.tile_ww;
+                    const double ww = hipk_fold_8x8<T>(tid - 64, g, [&](int ci, int tt) {
+                        const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
+                        if (tl >= ntiles) return 0.0;
+                        const double *w4 = tp + (size_t)tl * 4;
+                        const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+                        return 0.0 + ((w0 + w1) + (w2 + w3));
+                    });
+                    if (tid == 64) bc[2] = ww;
                 }
-                acc = hipk_half_sum(acc);
-                if (tid == 0) hipk_ho_store<LOCAL>(&a.part_qq[wg], acc);
+                __syncthreads();
+                if (pass == 1 || bc[0] == 0.0) break;
+                __syncthreads();
             }
-            HIPK_STAMP(3)
-            if (hipk_ho_sync<LOCAL>(scal->flag_q, wg, nwg, ++seq, 0u, res_lds) == ~0ull) {
-                if (tid == 0) scal->redo = -1;
-                return;
-            }
-            HIPK_STAMP(4)
-            // ---------------- C: ||q||^2 (every workgroup, same bits); CGS2 decision after the first pass (TSL:313-326)
-            if (tid < 8) {
-                const double qq = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.part_qq + ci * kGmSub + ss); });
-                if (tid == 0) {
-                    bc[1] = qq;
-                    double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
-                    if (!(qnorm > a.eps)) qnorm = 0.0;
-                    const double rnorm = bc[3];
-                    bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
-                }
-            } else if (tid >= 64 && tid < 72 && pass == 0) {
-                // ||A v||^2 from the tile sums (hipk_fold_tiles8: per chunk the fold of its <= 8 tiles, then the chunks)
-                const double *tp = a.tile_ww;
-                const double ww = hipk_fold_8x8<T>(tid - 64, g, [&](int ci, int tt) {
-                    const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
-                    if (tl >= ntiles) return 0.0;
-                    const double *w4 = tp + (size_t)tl * 4;
-                    const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
-                    return 0.0 + ((w0 + w1) + (w2 + w3));
-                });
-                if (tid == 64) bc[2] = ww;
-            }
-            __syncthreads();
-            if (pass == 1 || bc[0] == 0.0) break;
-            __syncthreads();
-        }
-        if (stopped) break;
-        // ---------------- normalise: v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), TSL:358-387
-        const double qq = bc[1], ww = bc[2];
-        double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
-        double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
-        if (!(norm0 > a.eps)) norm0 = 0.0;
-        const double thr = a.eps * norm0;
-        const bool use = norm1 > thr;
-        const T nrm = (T)norm1;
-        const T vnew = (use && live) ? w_own / nrm : (T)0;
-        if (k + 1 < m) Vl[(size_t)(k + 1) * 256 + tid] = vnew;
-        if (live) wcol[row] = vnew;                  // read by the x update after the cycle (a later launch)
-        nrm_prev = nrm;
-        use_prev = use;
-        if (wg == 0) {   // column k of H, breakdown, 'incremental': Givens update + early exit (TSL:358-387, 595-623)
+            // ---------------- normalise: v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), TSL:358-387
+            const double qq = bc[1], ww = bc[2];
+            double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
+            double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
+            if (!(norm0 > a.eps)) norm0 = 0.0;
+            const double thr = a.eps * norm0;
+            const bool use = norm1 > thr;
+            const T nrm = (T)norm1;
+            const T vnew = (use && live) ? w_own / nrm : (T)0;
+            if (k + 1 < m) Vl[(size_t)(k + 1) * 256 + tid] = vnew;
+            if (live) wcol[row] = vnew;              // only read by launches after this one (the host's fallback path)
+            from_q = true;
+            nrm_prev = nrm;
+            use_prev = use;
+            // column k of H, breakdown, 'incremental': Givens update + early exit (TSL:358-387, 595-623): EVERY workgroup, from
+            // its own copies -- the same bits everywhere, so the loop test needs no exchange; workgroup 0 also writes memory
             if (!use) norm1 = 0.0;
-            if (tid <= k) scal->H[tid * HIPK_GM_LDH + k] = rv[tid];
+            if (!a.incremental) {
+                if (tid <= k) HRl[tid * HIPK_GM_LDH + k] = rv[tid];
+                if (tid == 0) HRl[(k + 1) * HIPK_GM_LDH + k] = norm1;
+            }
+            if (wg == 0) {
+                if (tid <= k) scal->H[tid * HIPK_GM_LDH + k] = rv[tid];
+                if (tid == 0) {
+                    scal->H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+                    scal->steps_done = k + 1;
+                }
+            }
             if (tid == 0) {
-                scal->H[(k + 1) * HIPK_GM_LDH + k] = norm1;
-                scal->steps_done = k + 1;
                 bool stp = false;
                 if (norm1 == 0.0) {  // TSL:387
-                    scal->breakdown = 1;
+                    if (wg == 0) scal->breakdown = 1;
+                    bc[5] = 1.0;
                     stp = true;
                 }
                 if (a.incremental) {
@@ -1499,7 +1686,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk
                                 const double p0 = cs * cur, p1 = sn * nx8[b];
                                 const double t0 = p0 - p1;
                                 const double p2 = sn * cur, p3 = cs * nx8[b];
-                                scal->R[(i0 + b) * HIPK_GM_LDH + k] = t0;
+                                HRl[(i0 + b) * HIPK_GM_LDH + k] = t0;
+                                if (wg == 0) scal->R[(i0 + b) * HIPK_GM_LDH + k] = t0;
                                 cur = p2 + p3;
                             }
                     }
@@ -1509,39 +1697,153 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_cycle_lds_kernel(hipk
                     hipk_givens(hk, hk1, cs, sn);
                     gvl[2 * k] = cs;
                     gvl[2 * k + 1] = sn;
-                    scal->gv[2 * k] = cs;
-                    scal->gv[2 * k + 1] = sn;
                     {
                         const double p0 = cs * hk, p1 = sn * hk1;
                         hk = p0 - p1;
                     }
-                    scal->R[k * HIPK_GM_LDH + k] = hk;
-                    const double b0 = bvl[0], b1 = bvl[1];   // beta_vec[k], beta_vec[k+1]
+                    HRl[k * HIPK_GM_LDH + k] = hk;
+                    const double b0 = bvl[k], b1 = bvl[k + 1];
                     const double p0 = cs * b0, p1 = sn * b1;
                     const double t0 = p0 - p1;
                     const double p2 = sn * b0, p3 = cs * b1;
                     const double bk1 = p2 + p3;
-                    scal->beta_vec[k] = t0;
-                    scal->beta_vec[k + 1] = bk1;
-                    bvl[0] = bk1;
-                    bvl[1] = 0.0;
+                    bvl[k] = t0;
+                    bvl[k + 1] = bk1;
+                    bvl[k + 2] = 0.0;
                     const double err = fabs(bk1);
-                    scal->err = err;
+                    if (wg == 0) {
+                        scal->gv[2 * k] = cs;
+                        scal->gv[2 * k + 1] = sn;
+                        scal->R[k * HIPK_GM_LDH + k] = hk;
+                        scal->beta_vec[k] = t0;
+                        scal->beta_vec[k + 1] = bk1;
+                        scal->err = err;
+                    }
                     if (!(err > a.ptol)) stp = true;  // TSL:591
                 }
-                if (stp) scal->stop_step = k + 1;
-                bc[3] = stp ? 1.0 : 0.0;
+                bc[6] = stp ? 1.0 : 0.0;
+            }
+            __syncthreads();                         // Vl[k+1], HRl, bc[6]
+            HIPK_STAMP(5)
+            if (bc[6] != 0.0) {
+                kk = k + 1;
+                break;
             }
         }
-        __syncthreads();                             // Vl[k+1], bc[3]
-        if (wg == 0) stop_bit = (bc[3] != 0.0) ? 1u : 0u;
-        HIPK_STAMP(5)
+        // ================ end of the cycle (TSL:754-764) ================
+        matvecs += kk;
+        if (bc[5] != 0.0) breakdown_any = 1;
+        bool solved;
+        if (a.incremental) {
+            hipk_gm_trisolve_lds(sm, kk, tid);
+            solved = true;
+        } else {
+            solved = hipk_gm_lstsq_lds(sm, kk, beta0, tid);
+        }
+        if (!solved) {   // uniform (every workgroup factorises the same bits): the host finishes this cycle
+            matvecs -= kk;
+            status = 2;
+            break;
+        }
+        // x += V[:, :kk] y on the own row (TSL:488-490), published for the residual's gathers
+        {
+            double sacc = 0.0;
+            for (int j0 = 0; j0 < kk; j0 += 8) {
+                T vv[8];
+                double yy[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int jj = (j0 + b < kk) ? j0 + b : kk - 1;
+                    vv[b] = Vl[(size_t)jj * 256 + tid];
+                    yy[b] = yl[jj];
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + b < kk) sacc = fma((double)vv[b], yy[b], sacc);
+            }
+            x_own = (T)((double)x_own + sacc);
+            if (live) hipk_ho_store<LOCAL>(a.x + row, x_own);
+        }
+        HIPK_HO(scal->flag_md)
+        // r = (M)(b - A x) on the own row (TSL:791), unnormalised into a.q
+        T r_own;
+        {
+            T xs[kGmRowRegs];
+#pragma unroll
+            for (int j = 0; j < kGmRowRegs; ++j)
+                if (j < wmax) xs[j] = hipk_peek_off<T>(a.x, cj[j]);
+            T acc_row = (T)0;
+#pragma unroll
+            for (int j = 0; j < kGmRowRegs; ++j)
+                if (j < wmax) {
+                    const T p = vj[j] * xs[j];
+                    acc_row = (j < len) ? acc_row + p : acc_row;
+                }
+            for (int j = kGmRowRegs; j < len; ++j) {
+                const T p = a.val[lo + j] * hipk_peek_t<T>(a.x + a.col[lo + j]);
+                acc_row = acc_row + p;
+            }
+            r_own = b_own - acc_row;
+            if (a.dscale) r_own = dsc * r_own;
+            if (!live) r_own = (T)0;
+            if (live) hipk_ho_store<LOCAL>(a.q + row, r_own);
+        }
+        matvecs += 1;
+        HIPK_HO(scal->flag_q)
+        {   // wavefront sums of <r,r> over the own tile
+            T rt = (T)0;
+            if (trow < n) rt = hipk_peek_t<T>(a.q + trow);
+            double d1 = (double)rt * (double)rt;
+            d1 = hipk_wave_sum(d1);
+            if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
+        }
+        HIPK_HO(scal->flag_md)
+        if (tid < 8) {
+            const double *tp = a.tile_ww;
+            const double r2 = hipk_fold_8x8<T>(tid, g, [&](int ci, int tt) {
+                const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
+                if (tl >= ntiles) return 0.0;
+                const double *w4 = tp + (size_t)tl * 4;
+                const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+                return 0.0 + ((w0 + w1) + (w2 + w3));
+            });
+            if (tid == 0) bc[7] = r2;
+        }
+        __syncthreads();
+        {   // unit residual + norm (`_safe_normalize`, TSL:217-273)
+            const double res2 = bc[7];
+            const double norm = sqrt(res2 < 0.0 ? 0.0 : res2);
+            const bool use = norm > a.eps;
+            const T nrm = (T)norm;
+            const T v0 = (use && live) ? r_own / nrm : (T)0;
+            Vl[tid] = v0;
+            if (live) a.V[row] = v0;                 // only read by launches after this one
+            from_q = true;
+            nrm_prev = nrm;
+            use_prev = use;
+            beta0 = use ? norm : 0.0;
+        }
+        ++cycles;
+        __syncthreads();
+        if (!(cycles < a.cycles_left && beta0 > a.atol_eff)) {
+            status = 1;
+            break;
+        }
+        if (cycles >= a.max_cycles) break;           // status 0: the host launches again
+    }
+    if (wg == 0 && tid == 0) {
+        scal->res_norm = beta0;
+        scal->rep_cycles = cycles;
+        scal->rep_matvecs = matvecs;
+        scal->rep_status = status;
+        scal->rep_breakdown = breakdown_any;
     }
 #ifdef HIPK_GM_STAMPS
     if (stamping)
         for (int i = 0; i < 8; ++i) a.stamps[i] += t_acc[i];
 #endif
 #undef HIPK_STAMP
+#undef HIPK_HO
 }
 
 // after a speculation miss at step k (hipk_gm_normalize_kernel, guard): steps >= k of the cycle are enqueued again
@@ -1856,8 +2158,17 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     const bool wide = small && gm.ch == HIPK_BASE_CHUNK && !getenv("HIPK_GMRES_NO_WIDE");  // hipk_gm_update_wide_kernel
     // small systems with short rows: the whole restart cycle in ONE launch (hipk_gm_cycle_small_kernel)
     bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
-    // ... with the basis in LDS and eight workgroups per chunk (hipk_gm_cycle_lds_kernel) when m columns of 256 rows fit
-    bool cyc_lds = cyc && hipk_gm_cycle_lds_bytes<T>(m) <= 65536 && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    // ... with the basis in LDS and eight workgroups per chunk (hipk_gm_solve_lds_kernel) when m columns of 256 rows fit
+    // two workgroups share a compute unit's 160 KB of LDS
+    bool cyc_lds = cyc && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    if (cyc_lds) {
+        static bool attr_done[2] = {false, false};   // the launches ask for more than the default 64 KB of dynamic LDS
+        if (!attr_done[sizeof(T) == 8]) {
+            (void)hipFuncSetAttribute((const void *)hipk_gm_solve_lds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void *)hipk_gm_solve_lds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr_done[sizeof(T) == 8] = true;
+        }
+    }
     // its hand-offs through the shared L2 of ONE XCD (plain stores; placement verified by the kernel), else agent-scope stores
     bool cyc_local = !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
@@ -1895,14 +2206,19 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.incremental = incremental;
             ca.ptol = ptol;
             ca.beta0 = res_norm;
+            ca.b = b;
+            ca.x = x;
+            ca.atol_eff = atol_eff;
+            ca.cycles_left = maxiter - cycles;
+            ca.max_cycles = env_int("HIPK_GM_LAUNCH_CYCLES", 64);
             ca.bar = &scal->bar;
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
             if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 64, stream);
             if (cyc_lds && cyc_local)
-                hipk_gm_cycle_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
+                hipk_gm_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
             else if (cyc_lds)
-                hipk_gm_cycle_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_cycle_lds_bytes<T>(m), stream>>>(ca);
+                hipk_gm_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
             else
                 hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
@@ -1982,6 +2298,15 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             else
                 cyc = cyc_lds = false;
             continue;
+        }
+        if (cyc && cyc_lds) {  // hipk_gm_solve_lds_kernel ran whole cycles, loop test included
+            cycles += hs->rep_cycles;
+            matvecs += hs->rep_matvecs;
+            if (hs->rep_breakdown) happy = 1;
+            res_norm = hs->res_norm;
+            if (hs->rep_status != 2) continue;
+            // 2: the Arnoldi steps of one more cycle are in memory, its normal equations were not positive definite:
+            // the general solve and the rest of that cycle below
         }
         if (hs->redo > 0) {  // speculation miss: second pass wanted at redo_step; enqueue the cycle again from there
             k_start = (int)hs->redo_step;

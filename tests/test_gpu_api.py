@@ -481,10 +481,12 @@ def _banded_csr(n, half, dev, dtype):
 
 @pytest.mark.gpu
 def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
-    """small systems with short rows run a whole restart cycle in ONE launch -- by default
-    hipk_gm_cycle_lds_kernel (basis resident in LDS, eight workgroups per reduction chunk, sub-partials folded with the last
-    three levels of the spec's tree), with HIPK_GMRES_NO_LDS_CYCLE=1 hipk_gm_cycle_small_kernel (one workgroup per chunk);
-    HIPK_GMRES_NO_CYCLE=1 selects the multi-launch small-system path.  Same bits from all three -- ragged tails, one to
+    """small systems with short rows run whole restart cycles -- the whole solve -- in ONE launch: by
+    default hipk_gm_solve_lds_kernel (basis resident in LDS, eight workgroups per reduction chunk, sub-partials folded with
+    the last three levels of the spec's tree; least squares, x update, residual and loop test on the device), with
+    HIPK_GMRES_NO_LDS_CYCLE=1 hipk_gm_cycle_small_kernel (one workgroup per chunk, one launch per cycle);
+    HIPK_GMRES_NO_CYCLE=1 selects the multi-launch small-system path; HIPK_GM_LAUNCH_CYCLES bounds the cycles of one launch
+    and HIPK_GM_CYCLE_AGENT=1 selects agent-scope hand-offs.  Same bits from all of them -- ragged tails, one to
     eight chunks, second CGS passes, breakdown / early exit, Jacobi scaling, fp32 storage, rows beyond the register-held
     16 entries and restart lengths on either side of a multiple of 8 included."""
     import torch
@@ -497,7 +499,8 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
             create_ldc_pressure_csr(47, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
             _banded_csr(5000, 12, dev, torch.float64), _banded_csr(2049, 9, dev, torch.float64)]
     restarts = {3: 7, 6: 17, 7: 9}
-    variants = ({}, {"HIPK_GMRES_NO_LDS_CYCLE": "1"}, {"HIPK_GMRES_NO_CYCLE": "1"})
+    variants = ({}, {"HIPK_GMRES_NO_LDS_CYCLE": "1"}, {"HIPK_GMRES_NO_CYCLE": "1"}, {"HIPK_GM_LAUNCH_CYCLES": "1"},
+                {"HIPK_GM_CYCLE_AGENT": "1", "HIPK_GM_LAUNCH_CYCLES": "2"})
     for mi, A in enumerate(mats):
         n = A.shape[0]
         for dt in (torch.float64, torch.float32):
@@ -512,7 +515,7 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
                     kw["M"] = JacobiPreconditioner(Ad)
                 out = []
                 for env in variants:
-                    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE"):
+                    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE", "HIPK_GM_LAUNCH_CYCLES", "HIPK_GM_CYCLE_AGENT"):
                         monkeypatch.delenv(key, raising=False)
                     for key, v in env.items():
                         monkeypatch.setenv(key, v)
@@ -521,7 +524,7 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
                     out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
                 for o in out[1:]:
                     assert torch.equal(out[0][0], o[0]) and out[0][1:] == o[1:], (n, dt, method, M)
-    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE"):
+    for key in ("HIPK_GMRES_NO_LDS_CYCLE", "HIPK_GMRES_NO_CYCLE", "HIPK_GM_LAUNCH_CYCLES", "HIPK_GM_CYCLE_AGENT"):
         monkeypatch.delenv(key, raising=False)
     # a tiny exactly solvable system: happy breakdown inside the cycle kernel
     A = torch.eye(5, dtype=torch.float64, device=dev).to_sparse_csr()
