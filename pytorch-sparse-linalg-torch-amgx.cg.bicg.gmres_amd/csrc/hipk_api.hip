@@ -564,9 +564,14 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
 #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
                     void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
                     // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
-                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !getenv("HIPK_SPMV_SELL_NO_MODE"))
+                    static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
+                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !no_mode)
                         pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
+                    // the Arnoldi step's form (w = A v with ||w||^2, TSL:351-352)
+                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_YY && !no_mode)
+                        pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
+                                           : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
                         (pocc * h->n_cu >= a.g || pocc >= occ))

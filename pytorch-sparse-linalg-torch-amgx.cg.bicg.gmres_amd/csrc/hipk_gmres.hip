@@ -1214,14 +1214,101 @@ static inline size_t hipk_gm_solve_lds_bytes(int m) {
     return (size_t)(m + 1) * 256 * sizeof(T) + (size_t)hipk_gm_lds_off::total * sizeof(double) + 64;
 }
 
-// y of the cycle from the LDS copy of H (TSL:391-421: normal equations + Cholesky) in the operation order of
-// hipk_lstsq_normal / the oracle.  All 256 threads form the lower triangle of H^T H (each entry its own fma chain over
-// p = 0..k); the factorisation and the two triangular solves run in wavefront 0, lane i owning row i: every chain keeps
-// the ascending order of the sequential code.  Returns false when a pivot is not positive.
+// ---- the small dense solves of a cycle, in REGISTERS of wavefront 0 (lane i owns row i)
+__device__ __forceinline__ double hipk_readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// 'batched' (TSL:391-421): Cholesky of the normal equations (lower triangle packed in LDS at O::lp, right-hand side at O::zl),
+// forward and back substitution, y -> O::yl.  Right-looking in registers: after column p is known every entry (i, j) of the
+// trailing triangle takes its p-th chain link fma(-L[i][p], L[j][p], .) -- for each entry the links still come in ascending p,
+// the order of hipk_lstsq_normal / the oracle.  Fully unrolled (compile-time register indices; uniform branches skip what lies
+// beyond k): 15 k instructions of straight-line code, of which a k = 30 solve executes ~5 k.  A rolled variant (rows shifted
+// by one register per step) executed more instructions and was slower (0.321 vs 0.308 ms per cycle); keeping the triangle in
+// LDS cost 0.333.  Sets bc[4] = 0 when a pivot is not positive.  'incremental' (TSL:630): the triangular system
+// R y = beta_vec from the LDS copies.  Called by wavefront 0 only.
+__device__ __noinline__ void hipk_gm_small_solve_wave0(double *sm, int k, int incremental) {
+    using O = hipk_gm_lds_off;
+    constexpr int KM = HIPK_GM_MAXM;
+    k = __builtin_amdgcn_readfirstlane(k);                     // arguments of a device function arrive in vector registers:
+    incremental = __builtin_amdgcn_readfirstlane(incremental);  // make the branch conditions scalar again
+    double *Lp = sm + O::lp, *yl = sm + O::yl, *zl = sm + O::zl, *bc = sm + O::bc;
+    const int lane = threadIdx.x & 63;
+    const int ri = lane * (lane + 1) / 2;
+    const bool mine = lane < k;
+    double c[KM];   // back substitution: c[p] multiplies y_p, p > lane
+    double zi, di;
+    if (incremental) {
+        const double *Rl = sm + O::hr, *bv = sm + O::bv;
+#pragma unroll
+        for (int p = 0; p < KM; ++p) c[p] = (mine && p > lane && p < k) ? Rl[lane * HIPK_GM_LDH + p] : 0.0;
+        zi = mine ? bv[lane] : 0.0;
+        di = mine ? Rl[lane * HIPK_GM_LDH + lane] : 1.0;
+    } else {
+        double r[KM];   // row `lane` of A^T A, becoming row `lane` of L
+#pragma unroll
+        for (int j = 0; j < KM; ++j) r[j] = (mine && j <= lane) ? Lp[ri + j] : 0.0;
+        double si = mine ? zl[lane] : 0.0;   // b2, then the forward substitution's running sums
+        zi = 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int p = 0; p < KM; ++p) {
+            if (ok && p < k) {   // uniform
+                const double d = hipk_readlane_d(r[p], p);   // entry (p, p), all its links applied
+                if (!(d > 0.0)) {
+                    ok = false;
+                } else {
+                    const double lpp = sqrt(d);
+                    const double lip = (lane == p) ? lpp : r[p] / lpp;   // L[lane][p] (lanes < p: unused)
+                    r[p] = lip;
+                    // forward: z_p = s_p / L[p][p]; lanes i > p take the link fma(-L[i][p], z_p, s_i)
+                    const double zp = hipk_readlane_d(si / lpp, p);
+                    zi = (lane == p) ? zp : zi;
+                    si = fma(-lip, zp, si);
+#pragma unroll
+                    for (int j = p + 1; j < KM; ++j)
+                        if (j < k) r[j] = fma(-lip, hipk_readlane_d(lip, j), r[j]);   // lanes < j: an entry above the diagonal, unused
+                }
+            }
+        }
+        if (!ok) {
+            if (lane == 0) bc[4] = 0.0;
+            return;
+        }
+        // transpose through LDS: lane i needs column i of L for the back substitution
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+            if (mine && j <= lane) Lp[ri + j] = r[j];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < KM; ++p) c[p] = (mine && p > lane && p < k) ? Lp[p * (p + 1) / 2 + lane] : 0.0;
+        di = mine ? Lp[ri + lane] : 1.0;
+    }
+    // y_i = (z_i - sum_{p > i} c_i[p] y_p) / d_i, the chain in ascending p (TSL:630 and the back substitution of TSL:418): one
+    // lane at a time; a finished y_p is broadcast once
+    double yi = 0.0;
+    double yu[KM];
+#pragma unroll
+    for (int i = KM - 1; i >= 0; --i) {
+        if (i < k) {   // uniform
+            double sacc = zi;
+#pragma unroll
+            for (int p = i + 1; p < KM; ++p)
+                if (p < k) sacc = fma(-c[p], yu[p], sacc);   // meaningful in lane i only
+            const double q = sacc / di;
+            yi = (lane == i) ? q : yi;
+            yu[i] = hipk_readlane_d(q, i);
+        }
+    }
+    if (mine) yl[lane] = yi;
+}
+
+// the lower triangle of H^T H (each entry its own fma chain over p = 0..k, the order of hipk_lstsq_normal) and b2 = H[0][:] beta0
+// into LDS, by all threads; then hipk_gm_small_solve_wave0.  Returns false when the factorisation met a non-positive pivot.
 __device__ __forceinline__ bool hipk_gm_lstsq_lds(double *sm, int k, double beta0, int tid) {
     using O = hipk_gm_lds_off;
     const double *Hl = sm + O::hr;
-    double *Lp = sm + O::lp, *yl = sm + O::yl, *zl = sm + O::zl, *bc = sm + O::bc;
+    double *Lp = sm + O::lp, *zl = sm + O::zl, *bc = sm + O::bc;
     const int nent = k * (k + 1) / 2;
     for (int idx = tid; idx < nent; idx += HIPK_THREADS) {
         int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
@@ -1246,109 +1333,12 @@ __device__ __forceinline__ bool hipk_gm_lstsq_lds(double *sm, int k, double beta
     if (tid < k) zl[tid] = Hl[tid] * beta0;   // b2[i] = H[0][i] * beta0
     if (tid == 0) bc[4] = 1.0;
     __syncthreads();
-    if (tid < 64) {
-        const int lane = tid;
-        const int ri = lane * (lane + 1) / 2;   // start of row `lane`
-        bool ok = true;
-        for (int j = 0; j < k; ++j) {
-            const int rj = j * (j + 1) / 2;
-            if (lane == j) {
-                double d = Lp[rj + j];
-                for (int p0 = 0; p0 < j; p0 += 8) {
-                    double l8[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) l8[b] = Lp[rj + ((p0 + b < j) ? p0 + b : 0)];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (p0 + b < j) d = fma(-l8[b], l8[b], d);
-                }
-                if (!(d > 0.0)) bc[4] = 0.0;
-                Lp[rj + j] = sqrt(d);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (bc[4] == 0.0) {
-                ok = false;
-                break;
-            }
-            const double ljj = Lp[rj + j];
-            if (lane > j && lane < k) {
-                double sacc = Lp[ri + j];
-                for (int p0 = 0; p0 < j; p0 += 8) {
-                    double a8[8], b8[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const int pp = (p0 + b < j) ? p0 + b : 0;
-                        a8[b] = Lp[ri + pp];
-                        b8[b] = Lp[rj + pp];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (p0 + b < j) sacc = fma(-a8[b], b8[b], sacc);
-                }
-                Lp[ri + j] = sacc / ljj;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (ok) {
-            // forward: z[i] = (b2[i] - sum_{p<i} L[i][p] z[p]) / L[i][i]; lane i applies the updates in ascending p
-            double si = (lane < k) ? zl[lane] : 0.0;
-            for (int p = 0; p < k; ++p) {
-                if (lane == p) zl[p] = si / Lp[ri + p];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const double zp = zl[p];
-                if (lane > p && lane < k) si = fma(-Lp[ri + p], zp, si);
-            }
-            // backward: y[i] = (z[i] - sum_{p>i} L[p][i] y[p]) / L[i][i], ascending p: one lane at a time
-            for (int i = k - 1; i >= 0; --i) {
-                if (lane == i) {
-                    double sacc = zl[i];
-                    for (int p0 = i + 1; p0 < k; p0 += 8) {
-                        double a8[8], b8[8];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            const int pp = (p0 + b < k) ? p0 + b : k - 1;
-                            a8[b] = Lp[pp * (pp + 1) / 2 + i];
-                            b8[b] = yl[pp];
-                        }
-#pragma unroll
-                        for (int b = 0; b < 8; ++b)
-                            if (p0 + b < k) sacc = fma(-a8[b], b8[b], sacc);
-                    }
-                    yl[i] = sacc / Lp[ri + i];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-    }
+    if (tid < 64) hipk_gm_small_solve_wave0(sm, k, 0);
     __syncthreads();
     return bc[4] != 0.0;
 }
-// 'incremental': y from the triangular system R y = beta_vec (TSL:630), R in the LDS copy; one lane at a time
 __device__ __forceinline__ void hipk_gm_trisolve_lds(double *sm, int k, int tid) {
-    using O = hipk_gm_lds_off;
-    const double *Rl = sm + O::hr, *bv = sm + O::bv;
-    double *yl = sm + O::yl;
-    if (tid < 64) {
-        for (int i = k - 1; i >= 0; --i) {
-            if (tid == i) {
-                double sacc = bv[i];
-                for (int p0 = i + 1; p0 < k; p0 += 8) {
-                    double a8[8], b8[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const int pp = (p0 + b < k) ? p0 + b : k - 1;
-                        a8[b] = Rl[i * HIPK_GM_LDH + pp];
-                        b8[b] = yl[pp];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (p0 + b < k) sacc = fma(-a8[b], b8[b], sacc);
-                }
-                yl[i] = sacc / Rl[i * HIPK_GM_LDH + i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    }
+    if (tid < 64) hipk_gm_small_solve_wave0(sm, k, 1);
     __syncthreads();
 }
 
@@ -1458,7 +1448,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
         return;                                                                \
     }
 #ifdef HIPK_GM_STAMPS
-    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0, t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
 #define HIPK_STAMP(slot)                                              \
     if (stamping) {                                                   \
@@ -1557,7 +1547,9 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                     d1 = hipk_wave_sum(d1);
                     if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
                 }
+                HIPK_STAMP(8)
                 __syncthreads();
+                HIPK_STAMP(9)
                 if (tid == 192) {   // ||rvec|| for the CGS2 decision (TSL:313-326), while the other wavefronts update
                     double rr = 0.0;
                     for (int j0 = 0; j0 <= k; j0 += 8) {
@@ -1592,7 +1584,9 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                     wl[tid] = w_own;
                     if (live) hipk_ho_store<LOCAL>(a.q + row, w_own);
                 }
+                HIPK_STAMP(10)
                 __syncthreads();
+                HIPK_STAMP(11)
                 if (tid < 32) {   // <q,q>: the chain of virtual thread u, then the 32-lane tree
                     double acc = 0.0;
 #pragma unroll
@@ -1628,7 +1622,9 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                     });
                     if (tid == 64) bc[2] = ww;
                 }
+                HIPK_STAMP(12)
                 __syncthreads();
+                HIPK_STAMP(13)
                 if (pass == 1 || bc[0] == 0.0) break;
                 __syncthreads();
             }
@@ -1723,6 +1719,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                 }
                 bc[6] = stp ? 1.0 : 0.0;
             }
+            HIPK_STAMP(14)
             __syncthreads();                         // Vl[k+1], HRl, bc[6]
             HIPK_STAMP(5)
             if (bc[6] != 0.0) {
@@ -1731,6 +1728,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
             }
         }
         // ================ end of the cycle (TSL:754-764) ================
+        HIPK_STAMP(5)
         matvecs += kk;
         if (bc[5] != 0.0) breakdown_any = 1;
         bool solved;
@@ -1740,6 +1738,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
         } else {
             solved = hipk_gm_lstsq_lds(sm, kk, beta0, tid);
         }
+        HIPK_STAMP(6)
         if (!solved) {   // uniform (every workgroup factorises the same bits): the host finishes this cycle
             matvecs -= kk;
             status = 2;
@@ -1825,6 +1824,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
         }
         ++cycles;
         __syncthreads();
+        HIPK_STAMP(7)
         if (!(cycles < a.cycles_left && beta0 > a.atol_eff)) {
             status = 1;
             break;
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
     }
 #ifdef HIPK_GM_STAMPS
     if (stamping)
-        for (int i = 0; i < 8; ++i) a.stamps[i] += t_acc[i];
+        for (int i = 0; i < 16; ++i) a.stamps[i] += t_acc[i];
 #endif
 #undef HIPK_STAMP
 #undef HIPK_HO
@@ -2214,7 +2214,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.bar = &scal->bar;
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
-            if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 64, stream);
+            if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 128, stream);
             if (cyc_lds && cyc_local)
                 hipk_gm_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
             else if (cyc_lds)
@@ -2348,12 +2348,15 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     free(hs);
     if (rc != HIPK_OK) return rc;
     if ((cyc || cyc_lds) && getenv("HIPK_GM_STAMPS")) {  // diagnostic build-in: where workgroup 0 of the cycle kernel spent its shader clocks
-        unsigned long long st8[8];
+        unsigned long long st8[16];
         HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1024, sizeof(st8), hipMemcpyDeviceToHost, stream));
         HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "hipk_gm_cycle_small_kernel stamps (shader clocks, %lld cycles of %d steps): A spmv %llu | multidot %llu | bar1 %llu | "
-                        "B fold+update %llu | bar2 %llu | C decide+normalize %llu | bar3 %llu\n",
-                (long long)cycles, m, st8[0], st8[1], st8[2], st8[3], st8[4], st8[5], st8[6]);
+        fprintf(stderr, "GMRES cycle kernel stamps (shader clocks of workgroup 0, %lld cycles of %d steps): A spmv %llu | multidot %llu | "
+                        "hand-off 1 %llu | B fold+update %llu | hand-off 2 %llu | C decide+normalize %llu | [one workgroup per chunk: "
+                        "barrier 3; LDS kernel: least squares] %llu | [LDS kernel: x update, residual, norm] %llu\n",
+                (long long)cycles, m, st8[0], st8[1], st8[2], st8[3], st8[4], st8[5], st8[6], st8[7]);
+        fprintf(stderr, "  LDS kernel, finer: B loads+fold %llu | wait %llu | update %llu | wait %llu | [<q,q> = B above] ; C folds %llu | wait %llu | "
+                        "[decide = C above] normalise+H column %llu\n", st8[8], st8[9], st8[10], st8[11], st8[12], st8[13], st8[14]);
     }
 
     // TSL:766-773
