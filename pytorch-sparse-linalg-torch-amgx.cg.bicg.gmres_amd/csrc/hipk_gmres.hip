@@ -1171,11 +1171,16 @@ __device__ __forceinline__ void hipk_ho_flag(unsigned long long *p, unsigned lon
 }
 // signal hand-off number `seq` (flag value 2 seq + bit) for this workgroup, then wait until every workgroup has signalled it.
 // Returns the flag word of workgroup 0 (its low bit carries the stop decision), or ~0 when the spin bound was hit.
-template <bool LOCAL>
+struct hipk_no_side_work {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `side`: work of thread 192 (wavefront 3 only waits here) that the consumers of this hand-off need afterwards
+template <bool LOCAL, class F = hipk_no_side_work>
 __device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *flags, int wg, int nwg, unsigned long long seq,
-                                                           unsigned bit, unsigned long long *res_lds) {
+                                                           unsigned bit, unsigned long long *res_lds, F side = F()) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront: its stores have arrived
     __syncthreads();
+    if (threadIdx.x == 192) side();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         if (lane == 0) hipk_ho_flag<LOCAL>(flags + wg, 2 * seq + bit);
@@ -1550,20 +1555,6 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                 HIPK_STAMP(8)
                 __syncthreads();
                 HIPK_STAMP(9)
-                if (tid == 192) {   // ||rvec|| for the CGS2 decision (TSL:313-326), while the other wavefronts update
-                    double rr = 0.0;
-                    for (int j0 = 0; j0 <= k; j0 += 8) {
-                        double r_[8];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) r_[b] = rv[(j0 + b <= k) ? j0 + b : k];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b)
-                            if (j0 + b <= k) rr = fma(r_[b], r_[b], rr);
-                    }
-                    double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
-                    if (!(rnorm > a.eps)) rnorm = 0.0;
-                    bc[3] = rnorm;
-                }
                 // q = w - V h on the own row; published unnormalised for the gathers of the next SpMV
                 {
                     double sacc = 0.0;
@@ -1598,7 +1589,24 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                     if (tid == 0) hipk_ho_store<LOCAL>(&a.part_qq[wg], acc);
                 }
                 HIPK_STAMP(3)
-                HIPK_HO(scal->flag_q)
+                // second hand-off of the pass; meanwhile thread 192 forms ||rvec|| for the CGS2 decision (TSL:313-326)
+                if (hipk_ho_sync<LOCAL>(scal->flag_q, wg, nwg, ++seq, 0u, res_lds, [&]() {
+                        double rr = 0.0;
+                        for (int j0 = 0; j0 <= k; j0 += 8) {
+                            double r_[8];
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) r_[b] = rv[(j0 + b <= k) ? j0 + b : k];
+#pragma unroll
+                            for (int b = 0; b < 8; ++b)
+                                if (j0 + b <= k) rr = fma(r_[b], r_[b], rr);
+                        }
+                        double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                        if (!(rnorm > a.eps)) rnorm = 0.0;
+                        bc[3] = rnorm;
+                    }) == ~0ull) {
+                    if (tid == 0) scal->redo = -1;
+                    return;
+                }
                 HIPK_STAMP(4)
                 // ---------------- C: ||q||^2 (every workgroup, same bits); CGS2 decision after the first pass (TSL:313-326)
                 if (tid < 8) {
