@@ -2168,7 +2168,11 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
     // ... with the basis in LDS and eight workgroups per chunk (hipk_gm_solve_lds_kernel) when m columns of 256 rows fit
     // two workgroups share a compute unit's 160 KB of LDS
-    bool cyc_lds = cyc && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    // ... and 8 g workgroups fit ONE XCD (an eighth of the compute units, two workgroups each); a process whose resident
+    // workgroups once failed to meet (a shared device) does not try again: the wait for that verdict takes seconds
+    static bool lds_cycle_failed = false;
+    bool cyc_lds = cyc && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 && kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 &&
+                   !lds_cycle_failed && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
     if (cyc_lds) {
         static bool attr_done[2] = {false, false};   // the launches ask for more than the default 64 KB of dynamic LDS
         if (!attr_done[sizeof(T) == 8]) {
@@ -2301,10 +2305,12 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             // co-resident): nothing of the cycle is kept -- column 0 is untouched -- and this solve goes on with one launch
             // per kernel
             if (getenv("HIPK_GM_STAMPS")) fprintf(stderr, "hipk_gmres_solve: one-launch cycle abandoned (workgroups not co-resident)\n");
-            if (hs->redo == -2 && cyc_lds && cyc_local)
+            if (hs->redo == -2 && cyc_lds && cyc_local) {
                 cyc_local = false;      // its workgroups were spread over several XCDs: hand-offs at agent scope from now on
-            else
+            } else {
+                if (cyc_lds) lds_cycle_failed = true;
                 cyc = cyc_lds = false;
+            }
             continue;
         }
         if (cyc && cyc_lds) {  // hipk_gm_solve_lds_kernel ran whole cycles, loop test included
