@@ -285,11 +285,13 @@ def main():
         spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles from one word per tile, + fused <p,Ap> chunk partials)",
                      "tile_fast": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, path)
         coded = path in ("coded", "offset_coded")
+        # x, r, p, Ap beyond 384 MiB: the vector kernels' non-temporal instantiation (csrc/hipk_cg.hip)
+        nt_streams = "true" if 4 * n * sv > 384 * 1024 * 1024 else "false"
         legs = [("spmv", 1, spmv_name, fbytes if coded else spmv_bytes,
                  "bytes this format streams: code planes + x + y" if coded else "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
-                ("cg_update", 2, "hipk_cg_update_kernel<double,false> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
+                ("cg_update", 2, f"hipk_cg_update_kernel<double,false,{nt_streams}> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
                  "read Ap, r; write r = 24 n"),
-                ("cg_direction", 3, "hipk_cg_direction_kernel<double,false> (x += alpha p, p = r + beta p)", 5 * n * sv,
+                ("cg_direction", 3, f"hipk_cg_direction_kernel<double,false,{nt_streams}> (x += alpha p, p = r + beta p)", 5 * n * sv,
                  "read r, p, x; write p, x = 40 n")]
         kernels = []
         for key, which, name, nbytes, what in legs:
