@@ -2365,12 +2365,17 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         unsigned long long st8[16];
         HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1024, sizeof(st8), hipMemcpyDeviceToHost, stream));
         HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "GMRES cycle kernel stamps (shader clocks of workgroup 0, %lld cycles of %d steps): A spmv %llu | multidot %llu | "
-                        "hand-off 1 %llu | B fold+update %llu | hand-off 2 %llu | C decide+normalize %llu | [one workgroup per chunk: "
-                        "barrier 3; LDS kernel: least squares] %llu | [LDS kernel: x update, residual, norm] %llu\n",
-                (long long)cycles, m, st8[0], st8[1], st8[2], st8[3], st8[4], st8[5], st8[6], st8[7]);
-        fprintf(stderr, "  LDS kernel, finer: B loads+fold %llu | wait %llu | update %llu | wait %llu | [<q,q> = B above] ; C folds %llu | wait %llu | "
-                        "[decide = C above] normalise+H column %llu\n", st8[8], st8[9], st8[10], st8[11], st8[12], st8[13], st8[14]);
+        if (cyc_lds)
+            fprintf(stderr, "hipk_gm_solve_lds_kernel stamps (shader clocks of workgroup 0, thread 0; %lld cycles of %d steps): A SpMV %llu | "
+                            "multi-dot (+ CGS2 decision of the step before a second pass) %llu | hand-off 1 %llu | B: loads + fold %llu | wait %llu | "
+                            "update %llu | wait %llu | <q,q> %llu | hand-off 2 %llu | C: folds %llu | wait %llu | normalise + H column %llu | "
+                            "wait %llu | end of cycle: least squares %llu | x update, residual, norm %llu\n",
+                    (long long)cycles, m, st8[0], st8[1], st8[2], st8[8], st8[9], st8[10], st8[11], st8[3], st8[4], st8[12], st8[13],
+                    st8[14], st8[5], st8[6], st8[7]);
+        else
+            fprintf(stderr, "hipk_gm_cycle_small_kernel stamps (shader clocks of workgroup 0, thread 0; %lld cycles of %d steps): A SpMV %llu | "
+                            "multi-dot %llu | barrier 1 %llu | B fold + update %llu | barrier 2 %llu | C decide + normalise %llu | barrier 3 %llu\n",
+                    (long long)cycles, m, st8[0], st8[1], st8[2], st8[3], st8[4], st8[5], st8[6]);
     }
 
     // TSL:766-773
