@@ -257,7 +257,11 @@ int hipk_cg_start(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, co
 int hipk_cg_update(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
                    const double *part_pAp, const void *Ap, void *r, double *part_rr_out, int dtype,
                    hipk_stream_t stream);
-/* x += alpha p; p = r + beta p; gamma <- <r,r>; stop test   (the x update rides on the pass over p) */
+/* x += alpha p alone (alpha = gamma / sum(part_pAp), the bits hipk_cg_update / hipk_cg_direction derive): for a caller that
+ * runs it on a side stream while a collective is in flight and then calls hipk_cg_direction with x = NULL */
+int hipk_cg_xupdate(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it, const double *part_pAp,
+                    const void *p, void *x, int dtype, hipk_stream_t stream);
+/* x += alpha p; p = r + beta p; gamma <- <r,r>; stop test   (the x update rides on the pass over p; x = NULL: p only) */
 int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it,
                       int64_t maxiter, const double *part_pAp, const double *part_rr, const void *r, void *p,
                       void *x, int dtype, hipk_stream_t stream);

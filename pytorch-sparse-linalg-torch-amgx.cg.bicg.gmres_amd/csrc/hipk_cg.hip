@@ -122,6 +122,19 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
+    if (x == nullptr) {
+        // row-partitioned solver with the x update on a side stream (hipk_cg_xupdate_kernel, overlapping the collective): p only
+        pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+            constexpr int VEC = hipk_vec<T>::VEC;
+            T pv[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const T m = beta * v[1][k];
+                pv[k] = v[0][k] + m;  // TSL:852
+            }
+            hipk_st<T>(p, i, nv, pv);
+        });
+    } else {
     pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T xv[VEC], pv[VEC];
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
         else hipk_st<T>(x, i, nv, xv);
         hipk_st<T>(p, i, nv, pv);
     });
+    }
     if (c == 0 && threadIdx.x == 0) {
         scal->gamma[(it + 1) & 1] = rr;  // TSL:853
         // TSL:841 for the NEXT pass: stop when k+1 >= maxiter or rs <= atol2.
@@ -146,6 +160,31 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
         if (done) scal->stop_it = it + 1;
         hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
     }
+}
+
+// x += alpha p alone (TSL:847): the row-partitioned solver runs it on a side stream while the <r,r> / halo collective of the
+// iteration is in flight; alpha from the same partials and the same gamma as the update and direction kernels (same bits)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_xupdate_kernel(int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal,
+                                                                       int64_t it, const double *__restrict__ part_pAp,
+                                                                       const T *__restrict__ p, T *__restrict__ x) {
+    const int c = blockIdx.x;
+    hipk_pre<T, 2> pre;
+    pre.issue(n, ch, c, {p, (const T *)x});
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    const double pAp = hipk_reduce_parts(part_pAp, g, sbuf);
+    const T alpha = (T)(scal->gamma[it & 1] / pAp);  // TSL:846
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T xv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * v[0][k];
+            xv[k] = v[1][k] + m0;
+        }
+        hipk_st<T>(x, i, nv, xv);
+    });
 }
 
 // res2 = sum parts0, xx = sum parts1 -> scal
@@ -383,7 +422,7 @@ extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, voi
     hipStream_t stream = (hipStream_t)stream_;
     int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
     if (rc != HIPK_OK) return rc;
-    HIPK_REQUIRE(scal_dev && part_pAp && part_rr && r && p && x, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(scal_dev && part_pAp && part_rr && r && p, HIPK_ERR_ARG, "null argument");   // x == NULL: p only (see hipk_cg_xupdate)
     const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
     if (dtype == HIPK_F64)
         hipk_cg_direction_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
@@ -395,6 +434,23 @@ extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, voi
                                                                             (hipk_cg_scal *)scal_dev, it, maxiter,
                                                                             part_pAp, part_rr, (const float *)r,
                                                                             (float *)p, (float *)x);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+
+extern "C" int hipk_cg_xupdate(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it,
+                               const double *part_pAp, const void *p, void *x, int dtype, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = hipk_step_check(n_local, chunk_rows, g_red, dtype);
+    if (rc != HIPK_OK) return rc;
+    HIPK_REQUIRE(scal_dev && part_pAp && p && x, HIPK_ERR_ARG, "null argument");
+    const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (dtype == HIPK_F64)
+        hipk_cg_xupdate_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (const hipk_cg_scal *)scal_dev, it,
+                                                                          part_pAp, (const double *)p, (double *)x);
+    else
+        hipk_cg_xupdate_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (const hipk_cg_scal *)scal_dev, it,
+                                                                         part_pAp, (const float *)p, (float *)x);
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;
 }

@@ -36,7 +36,7 @@ SYMBOLS = [
     "hipk_gmres_work_bytes", "hipk_gmres_solve",
     # step API (row-partitioned multi-GPU CG)
     "hipk_csr_create_ex", "hipk_spmv_ex", "hipk_dot_parts", "hipk_reduce_parts", "hipk_gather",
-    "hipk_cg_scal_bytes", "hipk_cg_start", "hipk_cg_update", "hipk_cg_direction",
+    "hipk_cg_scal_bytes", "hipk_cg_start", "hipk_cg_update", "hipk_cg_direction", "hipk_cg_xupdate",
     # step API: CG with a callable preconditioner
     "hipk_cgm_start", "hipk_cgm_direction",
     # row-partitioned CG, the loop of one rank in C
@@ -204,6 +204,7 @@ def lib():
     L.hipk_cg_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
     L.hipk_cg_update.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, vp, i32, vp]
     L.hipk_cg_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, i32, vp]
+    L.hipk_cg_xupdate.argtypes = [i64, i32, i32, vp, i64, vp, vp, vp, i32, vp]
     L.hipk_cgm_start.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, vp]
     L.hipk_cgm_direction.argtypes = [i64, i32, i32, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, vp]
     L.hipk_dist_cg_work_bytes.argtypes = [ctypes.POINTER(DistPlan)]

@@ -160,9 +160,11 @@ class MailboxNative(HostStagedProblem):
 
 def main():
     kind, nx, ny, tol, maxiter, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag", "native_p2p")
+    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag", "native_p2p", "native_side")
     mailbox = len(sys.argv) > 7 and sys.argv[7] == "native_p2p"
     native = len(sys.argv) > 7 and sys.argv[7].startswith("native")
+    if len(sys.argv) > 7 and sys.argv[7] == "native_side":
+        os.environ["HIPK_DIST_OVERLAP"] = "1"      # x += alpha p on a side stream beside the second collective
     if len(sys.argv) > 7 and sys.argv[7] == "native_ag":
         os.environ["HIPK_DIST_HALO"] = "allgather"
     dist.init_process_group("gloo")

@@ -82,10 +82,12 @@ def test_dist_cg_hip_kernels_multi_rank_on_one_gpu(world, kind, nx, ny, tmp_path
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,nx,ny,mode", [(2, "poisson", 96, 64, "native"), (2, "random_spd", 80, 77, "native"),
                                                    (2, "random_spd", 80, 77, "native_ag"), (3, "poisson", 96, 64, "native"),
-                                                   (3, "poisson", 96, 64, "native_ag"), (2, "poisson", 4, 8000, "native")])
+                                                   (3, "poisson", 96, 64, "native_ag"), (2, "poisson", 4, 8000, "native"),
+                                                   (2, "random_spd", 80, 77, "native_side"), (3, "poisson", 96, 64, "native_side")])
 def test_dist_cg_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, mode, tmp_path):
     """hipk_dist_cg_solve (the loop of a rank in C: fixed batches, stop word read one batch late, halo by neighbour
-    send/recv pairs or by all-gathered slabs) under a multi-rank partition: ranks share cuda:0, the collective entry points
+    send/recv pairs or by all-gathered slabs; `native_side`: x += alpha p on a side stream beside the second collective,
+    HIPK_DIST_OVERLAP=1) under a multi-rank partition: ranks share cuda:0, the collective entry points
     are host-staged stand-ins (tests/_dist_worker.py).  Bitwise equal to the single-rank oracle solve."""
     r = _run(world, kind, nx, ny, 1e-8, -1, tmp_path, mode=mode)
     assert r["bitwise_equal"], r
