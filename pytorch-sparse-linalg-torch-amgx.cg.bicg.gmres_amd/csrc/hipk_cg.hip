@@ -21,6 +21,7 @@
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
+#include "hipk_handoff.h"
 
 struct hipk_cg_scal {
     double gamma[2];   // <r,r> ping-pong by iteration parity
@@ -30,7 +31,14 @@ struct hipk_cg_scal {
     double xx;         // <x,x>                               (TSL:1013)
     int64_t stop_it;   // iterations >= stop_it are no-ops
     int64_t *host_sig; // pinned host word the direction kernel reports to (hipk_pacer), or null
+    // hipk_cg_solve_lds_kernel (small systems: the whole loop in one launch)
+    int64_t it_done;   // iterations finished when the launch returned
+    int32_t redo;      // < 0: its resident workgroups did not all arrive / were spread over several XCDs (nothing was modified)
+    int32_t bar;       // counter barrier of its placement check
+    unsigned xcc_mask;
+    unsigned pad;
 };
+static_assert(sizeof(hipk_cg_scal) <= 256, "the scalar block is 256 bytes");
 
 // gamma0 = <r0,r0>, bs = <b,b>, atol2; p = r0.
 template <typename T>
@@ -187,6 +195,215 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_xupdate_kernel(int64_t n
     });
 }
 
+// =====================================================================================================================
+// Small systems (<= 8 reduction chunks = n <= 16384, rows of <= 12 entries): THE WHOLE CG LOOP IN ONE LAUNCH.
+// Three launches of >= 4.9 us per iteration for 80 KB vectors leave such systems launch-bound (16 us per iteration at n = 10^4).
+// Here 8 g workgroups stay resident on one XCD and meet at two hand-offs per iteration (csrc/hipk_handoff.h; the scheme of
+// hipk_gm_solve_lds_kernel).  Every thread plays two roles:
+//   * VECTOR role: row (u, e8) of the spec's virtual-thread layout (sub-workgroup s of chunk c owns the virtual threads s + 8u):
+//     x, r, p of that row live in REGISTERS for the whole solve; <r,r> is the chain of its virtual thread + a 32-lane tree, published
+//     as a sub-partial that every consumer folds with the last three levels of the chunk tree -- the bits of the chunk dot;
+//   * SpMV role: row tile*256 + tid of ONE 256-row tile, because <p,Ap> is the TILED dot of the SpMV epilogue (wavefront sums over
+//     64 contiguous rows).  The row's matrix entries and the p values they multiply stay in registers: after the <r,r> hand-off
+//     the thread gathers r at its columns and advances its own copies, p_j = r_j + beta p_j -- the owner's formula on the owner's
+//     operands, the same bits -- so p itself is never exchanged.
+// hand-off 1: tile sums of <p,Ap> + Ap by tile rows;  hand-off 2: sub-partials of <r,r> + r.  Arithmetic per element = the
+// three-kernel loop's (TSL:845-853), bit for bit.
+template <typename T>
+struct hipk_cg_lds_args {
+    int64_t n;
+    int g;
+    const int *crow;
+    const int *col;
+    const T *val;
+    T *x, *r, *p;
+    T *Ap;               // exchange buffer: A p by rows
+    hipk_cg_scal *scal;
+    double *tile_pp;     // [ntiles * 4] wavefront sums of <p,Ap>
+    double *rr_sub;      // [8 g] sub-partials of <r,r>
+    unsigned long long *flag_a, *flag_b;   // [64] each, zeroed before the launch
+    int64_t it0;         // iterations done before this launch
+    int64_t maxiter;
+    int64_t max_its;     // iteration budget of one launch
+};
+static constexpr int kCgRowRegs = 12;
+
+template <typename T, bool LOCAL>
+__global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk_cg_lds_args<T> a) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
+    const int wg = blockIdx.x >> 3;
+    const int c = wg / kGmSub, s = wg % kGmSub;
+    const int g = a.g, nwg = g * kGmSub;
+    if (c >= g) return;
+    hipk_cg_scal *scal = a.scal;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = tid & 31, e8 = tid >> 5;
+    const int64_t n = a.n;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t row = base + (int64_t)VEC * (s + kGmSub * u) + (int64_t)(e8 / VEC) * (VEC * HIPK_THREADS) + (e8 % VEC);
+    const bool live = row < n;
+    const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tile = c * (HIPK_BASE_CHUNK / HIPK_TILE) + s;
+    const int64_t trow = (int64_t)tile * HIPK_TILE + tid;
+    const bool tlive = trow < n;
+
+    __shared__ T wl[HIPK_THREADS];
+    __shared__ double bc[4];
+    __shared__ int fail;
+    __shared__ unsigned long long res_lds;
+    if (tid == 0) fail = 0;
+
+    // vector role
+    T x_own = live ? a.x[row] : (T)0, r_own = live ? a.r[row] : (T)0, p_own = live ? a.p[row] : (T)0;
+    // SpMV role: the tile row's entries, and p at its columns (the launches before this one left p in memory)
+    int lo = 0, len = 0;
+    if (tlive) {
+        lo = a.crow[trow];
+        len = a.crow[trow + 1] - lo;
+    }
+    unsigned cj[kCgRowRegs];
+    T vj[kCgRowRegs], pg[kCgRowRegs];
+#pragma unroll
+    for (int j = 0; j < kCgRowRegs; ++j) {
+        const int cc = (j < len) ? a.col[lo + j] : 0;
+        cj[j] = (unsigned)cc * (unsigned)sizeof(T);
+        vj[j] = (j < len) ? a.val[lo + j] : (T)0;
+        pg[j] = (j < len) ? a.p[cc] : (T)0;
+    }
+    T p_t = tlive ? a.p[trow] : (T)0;
+    int wmax = len < kCgRowRegs ? len : kCgRowRegs;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(wmax, off);
+        wmax = o > wmax ? o : wmax;
+    }
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    double gamma = scal->gamma[a.it0 & 1];
+    const double atol2 = scal->atol2;
+    const int64_t stop0 = scal->stop_it;
+
+    // every workgroup resident (and, LOCAL, on one XCD)?  Nothing has been modified yet: a failure leaves the solve to the launches
+    int epoch = 0;
+    if (LOCAL && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail)) {
+        if (tid == 0) scal->redo = -1;
+        return;
+    }
+    if (LOCAL) {
+        if (tid == 0) {
+            const unsigned mask = __hip_atomic_load(&scal->xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fail = (__builtin_popcount(mask) == 1) ? 0 : 1;
+        }
+        __syncthreads();
+        if (fail) {
+            if (tid == 0) scal->redo = -2;
+            return;
+        }
+    }
+    unsigned long long seq = 0;
+    int64_t it = a.it0;
+    bool done = stop0 <= it;
+    while (!done) {
+        // ---- SpMV role: (A p) of the tile row, wavefront sums of p .* (A p)  (TSL:845-846)
+        T acc_row = (T)0;
+#pragma unroll
+        for (int j = 0; j < kCgRowRegs; ++j)
+            if (j < wmax) {
+                const T pr = vj[j] * pg[j];
+                acc_row = (j < len) ? acc_row + pr : acc_row;
+            }
+        const T Ap_t = tlive ? acc_row : (T)0;
+        double d0 = tlive ? (double)p_t * (double)Ap_t : 0.0;
+        d0 = hipk_wave_sum(d0);
+        if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_pp[(size_t)tile * 4 + wave], d0);
+        if (tlive) hipk_ho_store<LOCAL>(a.Ap + trow, Ap_t);
+        if (hipk_ho_sync<LOCAL>(a.flag_a, wg, nwg, ++seq, 0u, &res_lds) == ~0ull) {
+            if (tid == 0) scal->redo = -3;   // cannot happen once every workgroup has passed the placement check
+            return;
+        }
+        // ---- vector role: alpha, r, x, <r,r> sub-partial  (TSL:846-850)
+        const T Ap_own = live ? hipk_peek_t<T>(a.Ap + row) : (T)0;
+        if (tid < 8) {
+            const double *tp = a.tile_pp;
+            const double pAp = hipk_fold_8x8<T>(tid, g, [&](int ci, int tt) {
+                const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
+                if (tl >= ntiles) return 0.0;
+                const double *w4 = tp + (size_t)tl * 4;
+                const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+                return 0.0 + ((w0 + w1) + (w2 + w3));
+            });
+            if (tid == 0) bc[0] = pAp;
+        }
+        __syncthreads();
+        const T alpha = (T)(gamma / bc[0]);
+        {
+            const T m1 = alpha * Ap_own;
+            r_own = r_own - m1;
+            const T m0 = alpha * p_own;
+            x_own = x_own + m0;
+        }
+        wl[tid] = r_own;
+        if (live) hipk_ho_store<LOCAL>(a.r + row, r_own);
+        __syncthreads();
+        if (tid < 32) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double v = (double)wl[e * 32 + tid];
+                acc = fma(v, v, acc);
+            }
+            acc = hipk_half_sum(acc);
+            if (tid == 0) hipk_ho_store<LOCAL>(&a.rr_sub[wg], acc);
+        }
+        if (hipk_ho_sync<LOCAL>(a.flag_b, wg, nwg, ++seq, 0u, &res_lds) == ~0ull) {
+            if (tid == 0) scal->redo = -3;
+            return;
+        }
+        // ---- beta, p (both roles), stop test  (TSL:851-853, 841)
+        T rg[kCgRowRegs];
+#pragma unroll
+        for (int j = 0; j < kCgRowRegs; ++j)
+            if (j < wmax) rg[j] = hipk_peek_off<T>(a.r, cj[j]);
+        const T r_t = tlive ? hipk_peek_t<T>(a.r + trow) : (T)0;
+        if (tid < 8) {
+            const double rr = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.rr_sub + ci * kGmSub + ss); });
+            if (tid == 0) bc[1] = rr;
+        }
+        __syncthreads();
+        const double rr = bc[1];
+        const T beta = (T)(rr / gamma);
+        {
+            const T m = beta * p_own;
+            p_own = r_own + m;
+            const T mt = beta * p_t;
+            p_t = r_t + mt;
+        }
+#pragma unroll
+        for (int j = 0; j < kCgRowRegs; ++j)
+            if (j < wmax) {
+                const T m = beta * pg[j];
+                pg[j] = rg[j] + m;
+            }
+        gamma = rr;
+        ++it;
+        done = (it >= a.maxiter || rr <= atol2);
+        if (it - a.it0 >= a.max_its) break;
+    }
+    if (live) {
+        a.x[row] = x_own;
+        a.p[row] = p_own;
+    }
+    if (wg == 0 && tid == 0) {
+        scal->gamma[it & 1] = gamma;
+        scal->it_done = it;
+        if (done && it < stop0) scal->stop_it = it;
+    }
+}
+
 // res2 = sum parts0, xx = sum parts1 -> scal
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_scal *__restrict__ scal, int g,
                                                                      const double *__restrict__ part_res,
@@ -280,7 +497,61 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     if (const char *e = getenv("HIPK_CG_STREAMS")) streams = e[0] == '1';
 
     int64_t it = 0, stop = INT64_MAX;
-    for (; it < maxiter; ++it) {
+    // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel), bounded iterations per launch
+    static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
+    bool lds_loop = small && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs && prm->profile == 0 && maxiter > 0 &&
+                    kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 && !lds_loop_failed && !getenv("HIPK_CG_NO_LDS_LOOP");
+    if (lds_loop) {
+        bool local = !getenv("HIPK_CG_LOOP_AGENT");
+        const char *e = getenv("HIPK_CG_LAUNCH_ITS");
+        hipk_cg_lds_args<T> ca;
+        ca.n = n;
+        ca.g = gm.g;
+        ca.crow = A->crow;
+        ca.col = A->col;
+        ca.val = (const T *)A->val;
+        ca.x = x;
+        ca.r = r;
+        ca.p = p;
+        ca.Ap = Ap;
+        ca.scal = scal;
+        ca.tile_pp = A->tile_part;
+        ca.rr_sub = part_b;
+        ca.flag_a = (unsigned long long *)(part_c + 1024);
+        ca.flag_b = ca.flag_a + 64;
+        ca.maxiter = maxiter;
+        ca.max_its = e ? atoll(e) : 16384;
+        if (ca.max_its < 1) ca.max_its = 1;
+        hipk_cg_scal hs0;
+        for (;;) {
+            ca.it0 = it;
+            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 128 * sizeof(unsigned long long), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_cg_scal) - offsetof(hipk_cg_scal, it_done), stream));
+            if (local)
+                hipk_cg_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+            else
+                hipk_cg_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+            HIPK_CHECK_HIP(hipGetLastError());
+            HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+            HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+            if (hs0.redo < 0) {
+                if (hs0.redo == -3) {
+                    hipk_set_error("hipk_cg_solve: a resident workgroup of the one-launch loop stopped arriving");
+                    return HIPK_ERR_HIP;
+                }
+                if (hs0.redo == -2 && local) {   // spread over several XCDs: agent-scope hand-offs
+                    local = false;
+                    continue;
+                }
+                lds_loop_failed = true;          // not co-resident; nothing was modified: the launch sequence below takes over
+                lds_loop = false;
+                break;
+            }
+            it = hs0.it_done;
+            if (hs0.stop_it <= it || it >= maxiter) break;
+        }
+    }
+    for (; !lds_loop && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
         {

@@ -23,6 +23,7 @@
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
+#include "hipk_handoff.h"
 
 #define HIPK_GM_MAXM 31
 #define HIPK_GM_LDH 32
@@ -414,15 +415,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_sc
 //    nothing measurable: MALL-served reads are only ~1.4x faster than HBM reads) and last-arriver folds of the partial sums
 //    inside the kernels (ticket atomics + write-through stores per workgroup: +1.3 ms per cycle).
 // The order of operations per element (columns ascending) is the spec's: same bits as the kernels above.
-__device__ __forceinline__ void hipk_publish(double *p, double v) {
-    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double hipk_peek(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
-
 // NC-column tree of the spec (hipk_block_sum8 for NC <= 8 live columns: no LDS traffic for dead ones)
 template <int NC>
 __device__ __forceinline__ void hipk_block_sumN(double (&v)[NC], double *sbuf) {
@@ -698,18 +690,6 @@ struct hipk_gm_cyc_args {
     unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
 };
 
-template <typename T>
-__device__ __forceinline__ T hipk_peek_t(const T *p);
-template <>
-__device__ __forceinline__ double hipk_peek_t<double>(const double *p) { return hipk_peek(p); }
-template <>
-__device__ __forceinline__ float hipk_peek_t<float>(const float *p) {
-    return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void hipk_publish_t(double *p, double v) { hipk_publish(p, v); }
-__device__ __forceinline__ void hipk_publish_t(float *p, float v) {
-    __hip_atomic_store((unsigned *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // hipk_fold8 on partials another workgroup of THIS launch wrote
 __device__ __forceinline__ double hipk_fold8_sc1(const double *part, int g) {
     double a[8];
@@ -756,27 +736,6 @@ __device__ __forceinline__ double hipk_fold_tiles8_sc1(const double *tp, int nti
     __syncthreads();
     return v;
 }
-// counter barrier of the `nwg` resident workgroups; false when the spin bound was hit (another workgroup never arrived)
-__device__ __forceinline__ bool hipk_gbar(int32_t *ctr, int nwg, int &epoch, int *fail_lds) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront: its (sc1) stores have left
-    __syncthreads();
-    ++epoch;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = epoch * nwg;
-        unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 25)) {  // seconds: a workgroup of this launch is not running
-                *fail_lds = 1;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    return *fail_lds == 0;
-}
-
 template <typename T>
 __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cycle_small_kernel(hipk_gm_cyc_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
@@ -1067,33 +1026,6 @@ __global__ __launch_bounds__(HIPK_BASE_CHUNK / hipk_vec<T>::VEC) void hipk_gm_cy
 //   * <w,w> is the TILED dot of the SpMV epilogue (wavefront sums over 64 CONTIGUOUS rows): sub-workgroup s re-reads tile s
 //     of its chunk (published by the eight owners of those rows) one barrier later and forms the four wavefront sums.
 // Three counter barriers per step as before; 8 g workgroups (<= 64) on one XCD, at most two per compute unit.
-template <typename T, class F>
-__device__ __forceinline__ double hipk_fold_8x8(int i8, int g, F val) {
-    // lanes i8 = 0..7 of an 8-lane group: inner fold of val(i8, 0..7), then the spec's fold of <= 8 chunk partials across
-    // the group (row_shl 4, 2, 1); valid where i8 == 0.  All 8 lanes must be active.
-    double a = 0.0;
-    if (i8 < g) {
-        double p[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) p[s] = val(i8, s);
-        a = 0.0 + (((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7])));
-    } else {
-        a = 0.0 + 0.0;
-    }
-    a = a + hipk_row_shl<4>(a);
-    a = a + hipk_row_shl<2>(a);
-    a = a + hipk_row_shl<1>(a);
-    return a;
-}
-// sum over the 32 lanes of a half wavefront with the strides 16 .. 1 of the spec's tree; valid in lanes 0 and 32
-__device__ __forceinline__ double hipk_half_sum(double d) {
-    d = d + hipk_lane_up16(d);
-    d = d + hipk_row_shl<8>(d);
-    d = d + hipk_row_shl<4>(d);
-    d = d + hipk_row_shl<2>(d);
-    d = d + hipk_row_shl<1>(d);
-    return d;
-}
 // column k of H from rvec and ||q||, breakdown, and for 'incremental' the Givens update + early-exit test (TSL:358-387,
 // 595-623); one thread.  Returns true when the cycle stops after this step.
 __device__ __forceinline__ bool hipk_gm_hcolumn(hipk_gm_scal *scal, int k, const double *rv, double norm1, double *hc) {
@@ -1139,68 +1071,7 @@ __device__ __forceinline__ bool hipk_gm_hcolumn(hipk_gm_scal *scal, int k, const
     return stp;
 }
 
-static constexpr int kGmSub = 8;        // sub-workgroups per reduction chunk
 static constexpr int kGmRowRegs = 12;   // matrix entries of the own row held in registers
-// ---- hand-offs between the workgroups of hipk_gm_solve_lds_kernel
-// LOCAL = true: every workgroup runs on the SAME XCD (verified at kernel start from HW_REG_XCC_ID, else the launch gives up):
-// that XCD's L2 is their coherence point, so payload and flags are PLAIN stores (the lines stay in L2) read with sc1 loads
-// (which only bypass the reader's L1): a hand-off costs L2 round trips.  LOCAL = false: agent-scope (sc1, write-through)
-// stores, valid on any placement, every trip through the fabric.  Each workgroup owns one flag word per hand-off kind and
-// stores the hand-off's sequence number into it after ALL its waves have drained their stores; a consumer polls the
-// <= 64 flags with one wave-wide load.
-template <bool LOCAL>
-__device__ __forceinline__ void hipk_ho_store(double *p, double v) {
-    if (LOCAL)
-        __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    else
-        hipk_publish(p, v);
-}
-template <bool LOCAL>
-__device__ __forceinline__ void hipk_ho_store(float *p, float v) {
-    if (LOCAL)
-        __hip_atomic_store((unsigned *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    else
-        hipk_publish_t(p, v);
-}
-template <bool LOCAL>
-__device__ __forceinline__ void hipk_ho_flag(unsigned long long *p, unsigned long long v) {
-    if (LOCAL)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    else
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// signal hand-off number `seq` (flag value 2 seq + bit) for this workgroup, then wait until every workgroup has signalled it.
-// Returns the flag word of workgroup 0 (its low bit carries the stop decision), or ~0 when the spin bound was hit.
-struct hipk_no_side_work {
-    __device__ __forceinline__ void operator()() const {}
-};
-// `side`: work of thread 192 (wavefront 3 only waits here) that the consumers of this hand-off need afterwards
-template <bool LOCAL, class F = hipk_no_side_work>
-__device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *flags, int wg, int nwg, unsigned long long seq,
-                                                           unsigned bit, unsigned long long *res_lds, F side = F()) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront: its stores have arrived
-    __syncthreads();
-    if (threadIdx.x == 192) side();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        if (lane == 0) hipk_ho_flag<LOCAL>(flags + wg, 2 * seq + bit);
-        unsigned long long f, f0 = ~0ull;
-        unsigned spins = 0;
-        for (;;) {
-            f = (lane < nwg) ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-            if (__all(f >= 2 * seq)) {
-                f0 = __shfl(f, 0);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) break;   // seconds: a workgroup of this launch is not running
-        }
-        if (lane == 0) *res_lds = f0;
-    }
-    __syncthreads();
-    return *res_lds;
-}
-
 // LDS carve of hipk_gm_solve_lds_kernel (doubles after the T arrays)
 struct hipk_gm_lds_off {
     static constexpr int hs = 0;                                   // [32]
@@ -1352,13 +1223,6 @@ __device__ __forceinline__ void hipk_gm_trisolve_lds(double *sm, int k, int tid)
 // least-squares problem itself, from its own LDS copy of H or R), x += V y on the own rows from the LDS basis, the residual
 // b - A x with its tiled norm, the unit residual as column 0, and the loop test (TSL:754-764).  The host reads one small report
 // per launch (a launch is bounded to `max_cycles` cycles).
-// sc1 load of base[byte_off / sizeof(T)]: an SGPR base + 32-bit VGPR offset, so that gathers through several bases (column 0,
-// a.q, x) do not each keep sixteen 64-bit addresses alive
-template <typename T>
-__device__ __forceinline__ T hipk_peek_off(const T *base, unsigned byte_off) {
-    return hipk_peek_t<T>((const T *)((const char *)base + (size_t)byte_off));
-}
-
 template <typename T, bool LOCAL>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk_gm_cyc_args<T> a) {
     using O = hipk_gm_lds_off;

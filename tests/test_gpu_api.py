@@ -498,7 +498,7 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
             create_convdiff_2d_csr(7, 5, device=dev), create_convdiff_2d_csr(128, 128, device=dev),
             create_ldc_pressure_csr(47, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
             _banded_csr(5000, 12, dev, torch.float64), _banded_csr(2049, 9, dev, torch.float64)]
-    restarts = {3: 7, 6: 17, 7: 9}
+    restarts = {2: 31, 3: 7, 4: 1, 6: 17, 7: 9}   # 31: the longest cycle the LDS kernel holds; 1: a cycle of one step
     variants = ({}, {"HIPK_GMRES_NO_LDS_CYCLE": "1"}, {"HIPK_GMRES_NO_CYCLE": "1"}, {"HIPK_GM_LAUNCH_CYCLES": "1"},
                 {"HIPK_GM_CYCLE_AGENT": "1", "HIPK_GM_LAUNCH_CYCLES": "2"})
     for mi, A in enumerate(mats):
@@ -530,6 +530,47 @@ def test_gmres_one_launch_per_cycle_kernel_is_bit_identical(monkeypatch):
     A = torch.eye(5, dtype=torch.float64, device=dev).to_sparse_csr()
     x, info = gmres(A, torch.arange(1.0, 6.0, dtype=torch.float64, device=dev), tol=1e-12, restart=5)
     assert info == 0 and torch.allclose(x, torch.arange(1.0, 6.0, dtype=torch.float64, device=dev))
+
+
+@pytest.mark.gpu
+def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
+    """Small systems with short rows run the whole CG loop in ONE launch (hipk_cg_solve_lds_kernel: x, r, p in registers, eight
+    workgroups per reduction chunk, two hand-offs per iteration, p advanced on the consumer side).  HIPK_CG_NO_LDS_LOOP=1 selects
+    the three-launches-per-iteration loop: same bits, same counts -- ragged tails, one to eight chunks, x0, maxiter cut-offs that
+    fall inside and on the boundary of a launch's iteration budget, agent-scope hand-offs, fp32 storage."""
+    import torch
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import (create_ldc_pressure_csr, create_poisson_2d_csr,
+                                                          create_variable_diffusion_2d_csr)
+    dev = "cuda:0"
+    mats = [create_poisson_2d_csr(100, 100, device=dev), create_poisson_2d_csr(7, 5, device=dev),
+            create_poisson_2d_csr(128, 128, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
+            create_poisson_2d_csr(45, 46, device=dev), create_ldc_pressure_csr(64, device=dev)]
+    variants = ({}, {"HIPK_CG_NO_LDS_LOOP": "1"}, {"HIPK_CG_LAUNCH_ITS": "7"}, {"HIPK_CG_LOOP_AGENT": "1", "HIPK_CG_LAUNCH_ITS": "50"})
+    keys = ("HIPK_CG_NO_LDS_LOOP", "HIPK_CG_LAUNCH_ITS", "HIPK_CG_LOOP_AGENT")
+    for mi, A in enumerate(mats):
+        n = A.shape[0]
+        for dt in (torch.float64, torch.float32):
+            Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(),
+                                                                        A.values().float(), size=A.shape)
+            g = torch.Generator(device=dev).manual_seed(n)
+            b = torch.randn(n, dtype=dt, device=dev, generator=g)
+            x0 = torch.randn(n, dtype=dt, device=dev, generator=g)
+            for kw in (dict(tol=1e-8 if dt == torch.float64 else 1e-4), dict(tol=1e-12, maxiter=21), dict(tol=1e-12, maxiter=7),
+                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0)):
+                out = []
+                for env in variants:
+                    for key in keys:
+                        monkeypatch.delenv(key, raising=False)
+                    for key, v in env.items():
+                        monkeypatch.setenv(key, v)
+                    x, info = cg(Ad, b, **kw)
+                    st = get_last_stats()
+                    out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.recurrence_rs))
+                for o in out[1:]:
+                    assert torch.equal(out[0][0], o[0]) and out[0][1:] == o[1:], (n, dt, kw.keys())
+    for key in keys:
+        monkeypatch.delenv(key, raising=False)
 
 
 @pytest.mark.gpu
