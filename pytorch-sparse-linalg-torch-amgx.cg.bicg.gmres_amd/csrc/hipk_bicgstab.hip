@@ -19,6 +19,7 @@
 #include "hipk_blas1.h"
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
+#include "hipk_handoff.h"
 
 #define HIPK_EPS64 2.220446049250313e-16
 #define HIPK_EPS32 1.1920928955078125e-07
@@ -34,7 +35,14 @@ struct hipk_bi_scal {
     int32_t code;      // 0 / -10 / -11  (TSL:903, 914, 935)
     int32_t extra_mv;  // SpMVs run by an iteration that then broke down
     int64_t *host_sig; // pinned host word the loop reports to (hipk_pacer, hipk_solve.h), or null
+    // hipk_bi_solve_lds_kernel (small systems: the whole loop in one launch)
+    int64_t it_done;   // iterations finished when the launch returned
+    int32_t redo;      // < 0: its resident workgroups did not all arrive / were spread over several XCDs (nothing was modified)
+    int32_t bar;       // counter barrier of its placement check
+    unsigned xcc_mask;
+    unsigned pad;
 };
+static_assert(sizeof(hipk_bi_scal) <= 256, "the scalar block is 256 bytes");
 
 template <typename T>
 struct hipk_eps;
@@ -282,6 +290,366 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
     }
 }
 
+// =====================================================================================================================
+// Small systems (<= 8 reduction chunks, rows of <= 12 entries, M = identity): THE WHOLE BiCGStab LOOP IN ONE LAUNCH -- the scheme
+// of hipk_cg_solve_lds_kernel (csrc/hipk_cg.hip) with three hand-offs per iteration instead of five launches:
+//   K1 (tests, beta, p) | K2 q = A p by TILE rows, wavefront sums of rhat .* q            -> hand-off: tile sums + q
+//   K3 (alpha test, s, <s,s> sub-partial) | K4 t = A s by tile rows, sums of s .* t, t .* t -> hand-off: tile sums + t + <s,s>
+//   K5 (omega tests, x, r, sub-partials of <r,r> and <rhat,r>)                              -> hand-off: those + r
+// The SpMV role keeps p, q, r at the columns of its tile row in registers and advances p = r + beta (p - omega q) and
+// s = r - alpha q itself from the gathered r and q (the owners' formulas on the owners' operands): neither p nor s is exchanged.
+// Arithmetic and every scalar test (TSL:894-936, 961) as in the five kernels above, bit for bit.
+template <typename T>
+struct hipk_bi_lds_args {
+    int64_t n;
+    int g;
+    const int *crow;
+    const int *col;
+    const T *val;
+    T *x, *r, *p, *q, *t;
+    const T *rhat;
+    hipk_bi_scal *scal;
+    double *tsum0, *tsum1, *tsum2;  // [ntiles * 4] wavefront sums of <rhat,q>, <t,t>, <s,t> (three arrays: a fast workgroup writes
+                                    // the sums of the second SpMV while a slow one still folds those of the first)
+    double *part_rr, *part_rhr;     // it = 0: chunk partials of <r0,r0> (twice); afterwards [8 g] sub-partials
+    double *part_ss;                // [8 g] sub-partials of <s,s>
+    unsigned long long *flag_a, *flag_b, *flag_c;   // [64] each, zeroed before the launch
+    int64_t it0, maxiter, max_its;
+};
+static constexpr int kBiRowRegs = 12;
+
+template <typename T, bool LOCAL>
+__global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk_bi_lds_args<T> a) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr double EPS = hipk_eps<T>::v;
+    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
+    const int wg = blockIdx.x >> 3;
+    const int c = wg / kGmSub, s_ = wg % kGmSub;
+    const int g = a.g, nwg = g * kGmSub;
+    if (c >= g) return;
+    hipk_bi_scal *scal = a.scal;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = tid & 31, e8 = tid >> 5;
+    const int64_t n = a.n;
+    const int64_t base = (int64_t)c * HIPK_BASE_CHUNK;
+    const int64_t row = base + (int64_t)VEC * (s_ + kGmSub * u) + (int64_t)(e8 / VEC) * (VEC * HIPK_THREADS) + (e8 % VEC);
+    const bool live = row < n;
+    const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tile = c * (HIPK_BASE_CHUNK / HIPK_TILE) + s_;
+    const int64_t trow = (int64_t)tile * HIPK_TILE + tid;
+    const bool tlive = trow < n;
+
+    __shared__ T wl[HIPK_THREADS], wh[HIPK_THREADS];
+    __shared__ double bc[4];
+    __shared__ int fail;
+    __shared__ unsigned long long res_lds;
+    if (tid == 0) fail = 0;
+
+    // vector role
+    T x_own = live ? a.x[row] : (T)0, r_own = live ? a.r[row] : (T)0, p_own = live ? a.p[row] : (T)0;
+    T q_own = live ? a.q[row] : (T)0;
+    const T h_own = live ? a.rhat[row] : (T)0;
+    wh[tid] = h_own;
+    // SpMV role: the tile row's entries; p and q at its columns (the launches before this one left them in memory)
+    int lo = 0, len = 0;
+    if (tlive) {
+        lo = a.crow[trow];
+        len = a.crow[trow + 1] - lo;
+    }
+    unsigned cj[kBiRowRegs];
+    T vj[kBiRowRegs], pc[kBiRowRegs], qc[kBiRowRegs];
+#pragma unroll
+    for (int j = 0; j < kBiRowRegs; ++j) {
+        const int cc = (j < len) ? a.col[lo + j] : 0;
+        cj[j] = (unsigned)cc * (unsigned)sizeof(T);
+        vj[j] = (j < len) ? a.val[lo + j] : (T)0;
+        pc[j] = (j < len) ? a.p[cc] : (T)0;
+        qc[j] = (j < len) ? a.q[cc] : (T)0;
+    }
+    const T h_t = tlive ? a.rhat[trow] : (T)0;
+    int wmax = len < kBiRowRegs ? len : kBiRowRegs;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(wmax, off);
+        wmax = o > wmax ? o : wmax;
+    }
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    double rho = scal->rho, alpha = scal->alpha, omega = scal->omega;
+    const double atol2 = scal->atol2;
+    const int64_t stop0 = scal->stop_it;
+
+    // every workgroup resident (and, LOCAL, on one XCD)?  Nothing has been modified yet: a failure leaves the solve to the launches
+    int epoch = 0;
+    if (LOCAL && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail)) {
+        if (tid == 0) scal->redo = -1;
+        return;
+    }
+    if (LOCAL) {
+        if (tid == 0) {
+            const unsigned mask = __hip_atomic_load(&scal->xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fail = (__builtin_popcount(mask) == 1) ? 0 : 1;
+        }
+        __syncthreads();
+        if (fail) {
+            if (tid == 0) scal->redo = -2;
+            return;
+        }
+    }
+#define HIPK_BI_HO(flags)                                                      \
+    if (hipk_ho_sync<LOCAL>(flags, wg, nwg, ++seq, 0u, &res_lds) == ~0ull) {   \
+        if (tid == 0) scal->redo = -3;                                         \
+        return;                                                                \
+    }
+    auto fold_tiles = [&](const double *tp, int i8) {
+        return hipk_fold_8x8<T>(i8, g, [&](int ci, int tt) {
+            const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
+            if (tl >= ntiles) return 0.0;
+            const double *w4 = tp + (size_t)tl * 4;
+            const double w0 = hipk_peek(w4), w1 = hipk_peek(w4 + 1), w2 = hipk_peek(w4 + 2), w3 = hipk_peek(w4 + 3);
+            return 0.0 + ((w0 + w1) + (w2 + w3));
+        });
+    };
+    auto fold_subs = [&](const double *sp, int i8) {
+        return hipk_fold_8x8<T>(i8, g, [&](int ci, int ss) { return hipk_peek(sp + ci * kGmSub + ss); });
+    };
+    unsigned long long seq = 0;
+    int64_t it = a.it0, iters = a.it0;
+    int code = 0, extra_mv = 0;
+    double rs_last = scal->rs_last;
+    int64_t stop_it = stop0;
+    bool handed = true;   // the r / <r,r> / <rhat,r> this iteration starts from are visible (a launch or a hand-off before)
+    while (it < stop_it && it - a.it0 < a.max_its) {
+        if (!handed) {
+            HIPK_BI_HO(a.flag_c)
+            handed = true;
+        }
+        // ---- K1: rs = <r,r>, rho' = <rhat,r> -> tests; beta; p = r + beta (p - omega q)   (TSL:893-907)
+        T rc[kBiRowRegs];
+#pragma unroll
+        for (int j = 0; j < kBiRowRegs; ++j)
+            if (j < wmax) rc[j] = hipk_peek_off<T>(a.r, cj[j]);
+        const T r_t = tlive ? hipk_peek_t<T>(a.r + trow) : (T)0;
+        if (tid < 8) {
+            double v;
+            if (it == 0) {   // chunk partials of the tiled dot of r0 = b - A x0 (the launches before this one)
+                double p8 = (tid < g) ? hipk_peek(a.part_rr + tid) : 0.0;
+                p8 = 0.0 + p8;
+                p8 = p8 + hipk_row_shl<4>(p8);
+                p8 = p8 + hipk_row_shl<2>(p8);
+                p8 = p8 + hipk_row_shl<1>(p8);
+                v = p8;
+            } else {
+                v = fold_subs(a.part_rr, tid);
+            }
+            if (tid == 0) bc[0] = v;
+        } else if (tid >= 64 && tid < 72) {
+            const int i8 = tid - 64;
+            double v;
+            if (it == 0) {
+                double p8 = (i8 < g) ? hipk_peek(a.part_rhr + i8) : 0.0;
+                p8 = 0.0 + p8;
+                p8 = p8 + hipk_row_shl<4>(p8);
+                p8 = p8 + hipk_row_shl<2>(p8);
+                p8 = p8 + hipk_row_shl<1>(p8);
+                v = p8;
+            } else {
+                v = fold_subs(a.part_rhr, i8);
+            }
+            if (i8 == 0) bc[1] = v;
+        }
+        __syncthreads();
+        const double rs = bc[0], rho_new = bc[1];
+        rs_last = rs;
+        if (rs <= atol2) {  // TSL:894-896
+            stop_it = it;
+            break;
+        }
+        if (fabs(rho_new) < EPS * fabs(rho)) {  // TSL:902-904
+            stop_it = it;
+            code = -10;
+            break;
+        }
+        const T beta = (T)(rho_new / rho * alpha / omega);  // TSL:906, left to right
+        const T om = (T)omega;
+        {
+            const T t1 = om * q_own;
+            const T t2 = p_own - t1;
+            const T t3 = beta * t2;
+            p_own = r_own + t3;
+        }
+#pragma unroll
+        for (int j = 0; j < kBiRowRegs; ++j)
+            if (j < wmax) {
+                const T t1 = om * qc[j];
+                const T t2 = pc[j] - t1;
+                const T t3 = beta * t2;
+                pc[j] = rc[j] + t3;
+            }
+        // ---- K2 (tile rows): q = A p, wavefront sums of rhat .* q   (TSL:909-910)
+        T q_t;
+        {
+            T acc_row = (T)0;
+#pragma unroll
+            for (int j = 0; j < kBiRowRegs; ++j)
+                if (j < wmax) {
+                    const T pr = vj[j] * pc[j];
+                    acc_row = (j < len) ? acc_row + pr : acc_row;
+                }
+            q_t = tlive ? acc_row : (T)0;
+            double d0 = tlive ? (double)h_t * (double)q_t : 0.0;
+            d0 = hipk_wave_sum(d0);
+            if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tsum0[(size_t)tile * 4 + wave], d0);
+            if (tlive) hipk_ho_store<LOCAL>(a.q + trow, q_t);
+        }
+        HIPK_BI_HO(a.flag_a)
+        // ---- K3: alpha' = rho'/<rhat,q> -> test; s = r - alpha' q; <s,s>   (TSL:910-920)
+        q_own = live ? hipk_peek_t<T>(a.q + row) : (T)0;
+#pragma unroll
+        for (int j = 0; j < kBiRowRegs; ++j)
+            if (j < wmax) qc[j] = hipk_peek_off<T>(a.q, cj[j]);
+        if (tid < 8) {
+            const double v = fold_tiles(a.tsum0, tid);
+            if (tid == 0) bc[2] = v;
+        }
+        __syncthreads();
+        const double rq = bc[2];
+        const double alpha_new = rho_new / rq;  // TSL:910
+        if (fabs(alpha_new) < EPS) {            // TSL:913-915
+            stop_it = it;
+            code = -11;
+            extra_mv = 1;
+            break;
+        }
+        const T al = (T)alpha_new;
+        T s_own;
+        {
+            const T m = al * q_own;
+            s_own = r_own - m;  // TSL:917
+        }
+        wl[tid] = s_own;
+        __syncthreads();
+        if (tid < 32) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double v = (double)wl[e * 32 + tid];
+                acc = fma(v, v, acc);
+            }
+            acc = hipk_half_sum(acc);
+            if (tid == 0) hipk_ho_store<LOCAL>(&a.part_ss[wg], acc);
+        }
+        // ---- K4 (tile rows): t = A s, wavefront sums of s .* t and t .* t   (TSL:923-930)
+        {
+            T acc_row = (T)0;
+#pragma unroll
+            for (int j = 0; j < kBiRowRegs; ++j)
+                if (j < wmax) {
+                    const T m = al * qc[j];
+                    const T sc = rc[j] - m;
+                    const T pr = vj[j] * sc;
+                    acc_row = (j < len) ? acc_row + pr : acc_row;
+                }
+            const T t_t = tlive ? acc_row : (T)0;
+            const T mt = al * q_t;
+            const T s_t = r_t - mt;
+            double d0 = tlive ? (double)s_t * (double)t_t : 0.0;
+            double d1 = tlive ? (double)t_t * (double)t_t : 0.0;
+            d0 = hipk_wave_sum(d0);
+            d1 = hipk_wave_sum(d1);
+            if (lane == 0 && tile < ntiles) {
+                hipk_ho_store<LOCAL>(&a.tsum2[(size_t)tile * 4 + wave], d0);
+                hipk_ho_store<LOCAL>(&a.tsum1[(size_t)tile * 4 + wave], d1);
+            }
+            if (tlive) hipk_ho_store<LOCAL>(a.t + trow, t_t);
+        }
+        HIPK_BI_HO(a.flag_b)
+        // ---- K5: omega' -> tests; x += alpha' p (+ omega' s); r = s (- omega' t); <r,r>, <rhat,r>   (TSL:920-961)
+        const T t_own = live ? hipk_peek_t<T>(a.t + row) : (T)0;
+        if (tid < 8) {
+            const double v = fold_subs(a.part_ss, tid);
+            if (tid == 0) bc[0] = v;
+        } else if (tid >= 64 && tid < 72) {
+            const double v = fold_tiles(a.tsum2, tid - 64);
+            if (tid == 64) bc[1] = v;
+        } else if (tid >= 128 && tid < 136) {
+            const double v = fold_tiles(a.tsum1, tid - 128);
+            if (tid == 128) bc[2] = v;
+        }
+        __syncthreads();
+        const double ss = bc[0], ts = bc[1], tt = bc[2];
+        const bool exit_early = ss < atol2;                                   // TSL:920 (strict)
+        const double omega_new = (fabs(tt) < EPS) ? 0.0 : ts / tt;            // TSL:926-930
+        if (fabs(omega_new) < EPS && !exit_early) {                           // TSL:934-936
+            stop_it = it;
+            code = -11;
+            extra_mv = 2;
+            break;
+        }
+        const T omn = (T)omega_new;
+        if (exit_early) {  // TSL:942-950 with exit_early true
+            const T m0 = al * p_own;
+            x_own = x_own + m0;
+            r_own = s_own;
+        } else {
+            const T m0 = al * p_own;
+            const T m1 = omn * s_own;
+            const T m2 = m0 + m1;
+            x_own = x_own + m2;
+            const T m3 = omn * t_own;
+            r_own = s_own - m3;
+        }
+        __syncthreads();   // bc and wl are free again
+        wl[tid] = r_own;
+        if (live) hipk_ho_store<LOCAL>(a.r + row, r_own);
+        __syncthreads();
+        if (tid < 32) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double rv = (double)wl[e * 32 + tid], hv = (double)wh[e * 32 + tid];
+                acc0 = fma(rv, rv, acc0);
+                acc1 = fma(hv, rv, acc1);
+            }
+            acc0 = hipk_half_sum(acc0);
+            acc1 = hipk_half_sum(acc1);
+            if (tid == 0) {
+                hipk_ho_store<LOCAL>(&a.part_rr[wg], acc0);
+                hipk_ho_store<LOCAL>(&a.part_rhr[wg], acc1);
+            }
+        }
+        rho = rho_new;
+        alpha = alpha_new;
+        omega = omega_new;
+        ++it;
+        iters = it;
+        if (exit_early || it >= a.maxiter) {  // TSL:961, loop bound :892
+            stop_it = it;
+            break;
+        }
+        handed = false;
+    }
+#undef HIPK_BI_HO
+    if (live) {
+        a.x[row] = x_own;
+        a.p[row] = p_own;
+    }
+    if (wg == 0 && tid == 0) {
+        scal->rho = rho;
+        scal->alpha = alpha;
+        scal->omega = omega;
+        scal->rs_last = rs_last;
+        scal->iters = iters;
+        scal->code = code;
+        scal->extra_mv = extra_mv;
+        scal->it_done = it;
+        if (stop_it < stop0) scal->stop_it = stop_it;
+    }
+}
+
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_final_kernel(hipk_bi_scal *__restrict__ scal, int g,
                                                                      const double *__restrict__ part_res,
                                                                      const double *__restrict__ part_xx) {
@@ -387,7 +755,69 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     sq.skip_combine = stt.skip_combine = small ? 1 : 0;
 
     int64_t it = 0, stop = INT64_MAX;
-    for (; it < maxiter; ++it) {
+    // launch-bound systems with short rows, M = identity: the whole loop in one launch (hipk_bi_solve_lds_kernel)
+    static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
+    bool lds_loop = small && !PRE && !ext && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kBiRowRegs && prm->profile == 0 &&
+                    maxiter > 0 && kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 && !lds_loop_failed &&
+                    !getenv("HIPK_BICGSTAB_NO_LDS_LOOP");
+    if (lds_loop) {
+        bool local = !getenv("HIPK_BICGSTAB_LOOP_AGENT");
+        const char *e = getenv("HIPK_BICGSTAB_LAUNCH_ITS");
+        hipk_bi_lds_args<T> ca;
+        ca.n = n;
+        ca.g = gm.g;
+        ca.crow = A->crow;
+        ca.col = A->col;
+        ca.val = (const T *)A->val;
+        ca.x = x;
+        ca.r = r;
+        ca.p = p;
+        ca.q = q;
+        ca.t = t;
+        ca.rhat = rhat;
+        ca.scal = scal;
+        ca.tsum0 = A->tile_part;
+        ca.tsum1 = A->tile_part + 4 * (size_t)nt;
+        ca.tsum2 = part_spare;
+        ca.part_rr = part_rr;
+        ca.part_rhr = part_rhr;
+        ca.part_ss = part_ss;
+        ca.flag_a = (unsigned long long *)(part_spare + 1024);
+        ca.flag_b = ca.flag_a + 64;
+        ca.flag_c = ca.flag_a + 128;
+        ca.maxiter = maxiter;
+        ca.max_its = e ? atoll(e) : 8192;
+        if (ca.max_its < 1) ca.max_its = 1;
+        hipk_bi_scal hs0;
+        for (;;) {
+            ca.it0 = it;
+            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 192 * sizeof(unsigned long long), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
+            if (local)
+                hipk_bi_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+            else
+                hipk_bi_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+            HIPK_CHECK_HIP(hipGetLastError());
+            HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+            HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+            if (hs0.redo < 0) {
+                if (hs0.redo == -3) {
+                    hipk_set_error("hipk_bicgstab_solve: a resident workgroup of the one-launch loop stopped arriving");
+                    return HIPK_ERR_HIP;
+                }
+                if (hs0.redo == -2 && local) {   // spread over several XCDs: agent-scope hand-offs
+                    local = false;
+                    continue;
+                }
+                lds_loop_failed = true;          // not co-resident; nothing was modified: the launch sequence below takes over
+                lds_loop = false;
+                break;
+            }
+            it = hs0.it_done;
+            if (hs0.stop_it <= it || it >= maxiter) break;
+        }
+    }
+    for (; !lds_loop && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
         {

@@ -574,6 +574,51 @@ def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
+    """Small systems with short rows run the whole BiCGStab loop in ONE launch (hipk_bi_solve_lds_kernel: three hand-offs per
+    iteration, p and s advanced on the consumer side); HIPK_BICGSTAB_NO_LDS_LOOP=1 selects the five-launches-per-iteration loop:
+    same bits, same counts and the same breakdown codes -- ragged tails, one to eight chunks, x0, maxiter cut-offs inside and on
+    the boundary of a launch's iteration budget, the early exit, agent-scope hand-offs, fp32 storage."""
+    import torch
+    from pytorch_sparse_solver.module_a import bicgstab, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_ldc_pressure_csr, create_poisson_2d_csr,
+                                                          create_variable_diffusion_2d_csr)
+    dev = "cuda:0"
+    mats = [create_convdiff_2d_csr(100, 100, device=dev), create_convdiff_2d_csr(7, 5, device=dev),
+            create_poisson_2d_csr(128, 128, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
+            create_convdiff_2d_csr(45, 46, device=dev), create_ldc_pressure_csr(64, device=dev),
+            torch.eye(300, dtype=torch.float64, device=dev).to_sparse_csr()]
+    variants = ({}, {"HIPK_BICGSTAB_NO_LDS_LOOP": "1"}, {"HIPK_BICGSTAB_LAUNCH_ITS": "5"},
+                {"HIPK_BICGSTAB_LOOP_AGENT": "1", "HIPK_BICGSTAB_LAUNCH_ITS": "40"})
+    keys = ("HIPK_BICGSTAB_NO_LDS_LOOP", "HIPK_BICGSTAB_LAUNCH_ITS", "HIPK_BICGSTAB_LOOP_AGENT")
+    for mi, A in enumerate(mats):
+        n = A.shape[0]
+        for dt in (torch.float64, torch.float32):
+            Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(),
+                                                                        A.values().float(), size=A.shape)
+            g = torch.Generator(device=dev).manual_seed(n)
+            b = torch.randn(n, dtype=dt, device=dev, generator=g)
+            x0 = torch.randn(n, dtype=dt, device=dev, generator=g)
+            for kw in (dict(tol=1e-8 if dt == torch.float64 else 1e-4), dict(tol=1e-12, maxiter=15), dict(tol=1e-12, maxiter=5),
+                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0)):
+                out = []
+                for env in variants:
+                    for key in keys:
+                        monkeypatch.delenv(key, raising=False)
+                    for key, v in env.items():
+                        monkeypatch.setenv(key, v)
+                    x, info = bicgstab(Ad, b, **kw)
+                    st = get_last_stats()
+                    out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm, st.recurrence_rs, st.breakdown))
+                for o in out[1:]:   # a solve that diverges to NaN must do so in both (the sign bit of a NaN is not specified)
+                    assert torch.equal(torch.isnan(out[0][0]), torch.isnan(o[0])), (n, dt, kw.keys())
+                    assert torch.equal(torch.nan_to_num(out[0][0], nan=0.5), torch.nan_to_num(o[0], nan=0.5)), (n, dt, kw.keys())
+                    assert all(a == b or (a != a and b != b) for a, b in zip(out[0][1:], o[1:])), (n, dt, kw.keys(), out[0][1:], o[1:])
+    for key in keys:
+        monkeypatch.delenv(key, raising=False)
+
+
+@pytest.mark.gpu
 def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypatch):
     """Large systems (more than 8 reduction chunks): the streaming-policy kernels (non-temporal loads of the basis columns
     beyond the resident ones) and the speculative second CGS pass (launched only where predicted; a miss is caught on the
