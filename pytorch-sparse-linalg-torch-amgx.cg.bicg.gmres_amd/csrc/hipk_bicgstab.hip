@@ -315,6 +315,7 @@ struct hipk_bi_lds_args {
     double *part_ss;                // [8 g] sub-partials of <s,s>
     unsigned long long *flag_a, *flag_b, *flag_c;   // [64] each, zeroed before the launch
     int64_t it0, maxiter, max_its;
+    int test_not_resident;   // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the placement check as failed
 };
 static constexpr int kBiRowRegs = 12;
 
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail)) {
+    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
     }
@@ -788,6 +789,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 8192;
         if (ca.max_its < 1) ca.max_its = 1;
+        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
         hipk_bi_scal hs0;
         for (;;) {
             ca.it0 = it;
@@ -809,7 +811,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                     local = false;
                     continue;
                 }
-                lds_loop_failed = true;          // not co-resident; nothing was modified: the launch sequence below takes over
+                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // not co-resident; nothing was modified: the launch sequence below takes over
                 lds_loop = false;
                 break;
             }

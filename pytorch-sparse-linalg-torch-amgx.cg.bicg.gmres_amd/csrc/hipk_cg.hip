@@ -225,6 +225,7 @@ struct hipk_cg_lds_args {
     int64_t it0;         // iterations done before this launch
     int64_t maxiter;
     int64_t max_its;     // iteration budget of one launch
+    int test_not_resident;   // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the placement check as failed
 };
 static constexpr int kCgRowRegs = 12;
 
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail)) {
+    if (!hipk_gbar(&scal->bar, nwg, epoch, &fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
     }
@@ -522,6 +523,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 16384;
         if (ca.max_its < 1) ca.max_its = 1;
+        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
         hipk_cg_scal hs0;
         for (;;) {
             ca.it0 = it;
@@ -543,7 +545,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                     local = false;
                     continue;
                 }
-                lds_loop_failed = true;          // not co-resident; nothing was modified: the launch sequence below takes over
+                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // not co-resident; nothing was modified: the launch sequence below takes over
                 lds_loop = false;
                 break;
             }

@@ -685,6 +685,7 @@ struct hipk_gm_cyc_args {
     double atol_eff;   //   the loop test `res_norm > atol_eff` (TSL:754),
     long long cycles_left;  // cycles the solve may still run (maxiter - cycles so far),
     long long max_cycles;   // and the cycle budget of one launch
+    int test_not_resident;  // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the workgroups as not co-resident
     int32_t *bar;      // barrier counter, zeroed by hipk_gm_cycle_init_kernel
     double eps;
     unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
@@ -1279,6 +1280,10 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     Vl[tid] = live ? a.V[row] : (T)0;                // column 0: written by the launch before this one
     int epoch = 0;
+    if (a.test_not_resident) {   // uniform
+        if (tid == 0) scal->redo = -1;
+        return;
+    }
     if (LOCAL) {
         // all workgroups on one XCD?  (the only exchange of this launch that does not rely on it: agent-scope atomics)
         if (tid == 0) {
@@ -2087,6 +2092,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.atol_eff = atol_eff;
             ca.cycles_left = maxiter - cycles;
             ca.max_cycles = env_int("HIPK_GM_LAUNCH_CYCLES", 64);
+            ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
             ca.bar = &scal->bar;
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
@@ -2172,7 +2178,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             if (hs->redo == -2 && cyc_lds && cyc_local) {
                 cyc_local = false;      // its workgroups were spread over several XCDs: hand-offs at agent scope from now on
             } else {
-                if (cyc_lds) lds_cycle_failed = true;
+                if (cyc_lds && !getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_cycle_failed = true;
                 cyc = cyc_lds = false;
             }
             continue;

@@ -619,6 +619,34 @@ def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_one_launch_kernels_fall_back_when_their_workgroups_are_not_resident(monkeypatch):
+    """The whole-solve kernels of small systems need all their workgroups resident at once; when the placement check fails
+    (a shared device) nothing has been modified and the launch sequences take over.  HIPK_TEST_LDS_NOT_RESIDENT makes the
+    kernels report exactly that: same results as without them."""
+    import torch
+    from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr
+    dev = "cuda:0"
+    for fn, A, kw in ((cg, create_poisson_2d_csr(60, 50, device=dev), dict(tol=1e-9)),
+                      (bicgstab, create_convdiff_2d_csr(60, 50, device=dev), dict(tol=1e-9)),
+                      (gmres, create_convdiff_2d_csr(60, 50, device=dev), dict(tol=1e-9, restart=20, maxiter=30)),
+                      (gmres, create_convdiff_2d_csr(60, 50, device=dev), dict(tol=1e-9, restart=20, maxiter=30, solve_method="incremental"))):
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+        out = []
+        for flag in (None, "1"):
+            if flag:
+                monkeypatch.setenv("HIPK_TEST_LDS_NOT_RESIDENT", flag)
+            else:
+                monkeypatch.delenv("HIPK_TEST_LDS_NOT_RESIDENT", raising=False)
+            x, info = fn(A, b, **kw)
+            st = get_last_stats()
+            out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
+        assert out[0][1] == 0 and torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (fn.__name__, out[0][1:], out[1][1:])
+    monkeypatch.delenv("HIPK_TEST_LDS_NOT_RESIDENT", raising=False)
+
+
+@pytest.mark.gpu
 def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypatch):
     """Large systems (more than 8 reduction chunks): the streaming-policy kernels (non-temporal loads of the basis columns
     beyond the resident ones) and the speculative second CGS pass (launched only where predicted; a miss is caught on the
