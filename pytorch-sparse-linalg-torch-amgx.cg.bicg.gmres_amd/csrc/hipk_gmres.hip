@@ -602,49 +602,61 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
         for (int e = 0; e < VEC; ++e) wv[e] = use ? v[0][e] / nrm : (T)0;
         hipk_st<T>(w, i, nv, wv);
     });
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // column k of H and the scalar bookkeeping of the step, workgroup 0.  The copies run one element per thread and the Givens
+    // chain takes its operands from LDS: as one thread's loop of dependent loads this tail outlasted the kernel's streaming part
+    // (the launch then waits for workgroup 0 alone).
+    if (blockIdx.x == 0) {
         if (!use) norm1 = 0.0;
         double *H = scal->H;
-        for (int j = 0; j <= k; ++j) H[j * HIPK_GM_LDH + k] = scal->rvec[j];
-        H[(k + 1) * HIPK_GM_LDH + k] = norm1;
-        scal->steps_done = k + 1;
-        bool stop = false;
-        if (norm1 == 0.0) {  // TSL:387
-            scal->breakdown = 1;
-            stop = true;
+        const int t = threadIdx.x;
+        __shared__ double hc[HIPK_GM_LDH + 1], gvs[2 * HIPK_GM_LDH];
+        if (t <= k) {
+            const double rj = scal->rvec[t];
+            H[t * HIPK_GM_LDH + k] = rj;
+            hc[t] = rj;
         }
-        if (scal->incremental) {
-            double hc[HIPK_GM_LDH + 1];
-            for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * HIPK_GM_LDH + k];
-            for (int i = 0; i < k; ++i) {
-                const double cs = scal->gv[2 * i], sn = scal->gv[2 * i + 1];
-                const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+        if (t < 2 * k && scal->incremental) gvs[t] = scal->gv[t];
+        __syncthreads();
+        if (t == 0) {
+            H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+            hc[k + 1] = norm1;
+            scal->steps_done = k + 1;
+            bool stop = false;
+            if (norm1 == 0.0) {  // TSL:387
+                scal->breakdown = 1;
+                stop = true;
+            }
+            if (scal->incremental) {
+                for (int i = 0; i < k; ++i) {
+                    const double cs = gvs[2 * i], sn = gvs[2 * i + 1];
+                    const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+                    const double t0 = p0 - p1;
+                    const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
+                    hc[i + 1] = p2 + p3;
+                    hc[i] = t0;
+                }
+                double cs, sn;
+                hipk_givens(hc[k], hc[k + 1], cs, sn);
+                scal->gv[2 * k] = cs;
+                scal->gv[2 * k + 1] = sn;
+                {
+                    const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
+                    hc[k] = p0 - p1;
+                }
+                hc[k + 1] = 0.0;
+                for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
+                double *bv = scal->beta_vec;
+                const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
                 const double t0 = p0 - p1;
-                const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
-                hc[i + 1] = p2 + p3;
-                hc[i] = t0;
+                const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
+                bv[k + 1] = p2 + p3;
+                bv[k] = t0;
+                const double err = fabs(bv[k + 1]);
+                scal->err = err;
+                if (!(err > scal->ptol)) stop = true;  // TSL:591
             }
-            double cs, sn;
-            hipk_givens(hc[k], hc[k + 1], cs, sn);
-            scal->gv[2 * k] = cs;
-            scal->gv[2 * k + 1] = sn;
-            {
-                const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
-                hc[k] = p0 - p1;
-            }
-            hc[k + 1] = 0.0;
-            for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
-            double *bv = scal->beta_vec;
-            const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
-            const double t0 = p0 - p1;
-            const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
-            bv[k + 1] = p2 + p3;
-            bv[k] = t0;
-            const double err = fabs(bv[k + 1]);
-            scal->err = err;
-            if (!(err > scal->ptol)) stop = true;  // TSL:591
+            if (stop) scal->stop_step = k + 1;
         }
-        if (stop) scal->stop_step = k + 1;
     }
 }
 
