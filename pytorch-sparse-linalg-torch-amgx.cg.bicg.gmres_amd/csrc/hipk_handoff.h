@@ -37,7 +37,7 @@ __device__ __forceinline__ bool hipk_gbar(int32_t *ctr, int nwg, int &epoch, int
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 25)) {  // seconds: a workgroup of this launch is not running
+            if (++spins > (1u << 20)) {  // ~a second: a workgroup of this launch is not running
                 *fail_lds = 1;
                 break;
             }
@@ -129,7 +129,7 @@ __device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *f
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) break;   // seconds: a workgroup of this launch is not running
+            if (++spins > (1u << 20)) break;   // ~a second: a workgroup of this launch is not running
         }
         if (lane == 0) *res_lds = f0;
     }
