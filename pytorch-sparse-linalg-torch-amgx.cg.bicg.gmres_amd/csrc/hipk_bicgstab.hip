@@ -316,6 +316,7 @@ struct hipk_bi_lds_args {
     unsigned long long *flag_a, *flag_b, *flag_c;   // [64] each, zeroed before the launch
     int64_t it0, maxiter, max_its;
     int test_not_resident;   // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the placement check as failed
+    int spread;              // more than 64 workgroups: one per block all over the chip (then LOCAL = false)
 };
 static constexpr int kBiRowRegs = 12;
 
@@ -323,8 +324,11 @@ template <typename T, bool LOCAL>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk_bi_lds_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
     constexpr double EPS = hipk_eps<T>::v;
-    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
-    const int wg = blockIdx.x >> 3;
+    int wg = blockIdx.x;                             // spread (more than 64 workgroups): one per block, anywhere on the chip
+    if (!a.spread) {
+        if (blockIdx.x & 7) return;                  // the working blocks share an XCD (dispatch is round-robin over 8)
+        wg = blockIdx.x >> 3;
+    }
     const int c = wg / kGmSub, s_ = wg % kGmSub;
     const int g = a.g, nwg = g * kGmSub;
     if (c >= g) return;
@@ -405,8 +409,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         if (tid == 0) scal->redo = -3;                                         \
         return;                                                                \
     }
-    auto fold_tiles = [&](const double *tp, int i8) {
-        return hipk_fold_8x8<T>(i8, g, [&](int ci, int tt) {
+    auto fold_tiles = [&](const double *tp, int i8) {   // i8 = lane of a whole wavefront
+        return hipk_fold_64x8(i8, g, [&](int ci, int tt) {
             const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
             if (tl >= ntiles) return 0.0;
             const double *w4 = tp + (size_t)tl * 4;
@@ -415,7 +419,12 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         });
     };
     auto fold_subs = [&](const double *sp, int i8) {
-        return hipk_fold_8x8<T>(i8, g, [&](int ci, int ss) { return hipk_peek(sp + ci * kGmSub + ss); });
+        return hipk_fold_64x8(i8, g, [&](int ci, int ss) { return hipk_peek(sp + ci * kGmSub + ss); });
+    };
+    auto fold_chunks = [&](const double *cp, int i8) {   // it = 0: chunk partials of the launches before this one (hipk_reduce_parts)
+        double a8 = (i8 < g) ? hipk_peek(cp + i8) : 0.0;
+        a8 = 0.0 + a8;
+        return hipk_wave_sum(a8);
     };
     unsigned long long seq = 0;
     int64_t it = a.it0, iters = a.it0;
@@ -434,33 +443,12 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         for (int j = 0; j < kBiRowRegs; ++j)
             if (j < wmax) rc[j] = hipk_peek_off<T>(a.r, cj[j]);
         const T r_t = tlive ? hipk_peek_t<T>(a.r + trow) : (T)0;
-        if (tid < 8) {
-            double v;
-            if (it == 0) {   // chunk partials of the tiled dot of r0 = b - A x0 (the launches before this one)
-                double p8 = (tid < g) ? hipk_peek(a.part_rr + tid) : 0.0;
-                p8 = 0.0 + p8;
-                p8 = p8 + hipk_row_shl<4>(p8);
-                p8 = p8 + hipk_row_shl<2>(p8);
-                p8 = p8 + hipk_row_shl<1>(p8);
-                v = p8;
-            } else {
-                v = fold_subs(a.part_rr, tid);
-            }
+        if (tid < 64) {
+            const double v = (it == 0) ? fold_chunks(a.part_rr, tid) : fold_subs(a.part_rr, tid);
             if (tid == 0) bc[0] = v;
-        } else if (tid >= 64 && tid < 72) {
-            const int i8 = tid - 64;
-            double v;
-            if (it == 0) {
-                double p8 = (i8 < g) ? hipk_peek(a.part_rhr + i8) : 0.0;
-                p8 = 0.0 + p8;
-                p8 = p8 + hipk_row_shl<4>(p8);
-                p8 = p8 + hipk_row_shl<2>(p8);
-                p8 = p8 + hipk_row_shl<1>(p8);
-                v = p8;
-            } else {
-                v = fold_subs(a.part_rhr, i8);
-            }
-            if (i8 == 0) bc[1] = v;
+        } else if (tid < 128) {
+            const double v = (it == 0) ? fold_chunks(a.part_rhr, tid - 64) : fold_subs(a.part_rhr, tid - 64);
+            if (tid == 64) bc[1] = v;
         }
         __syncthreads();
         const double rs = bc[0], rho_new = bc[1];
@@ -512,7 +500,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
 #pragma unroll
         for (int j = 0; j < kBiRowRegs; ++j)
             if (j < wmax) qc[j] = hipk_peek_off<T>(a.q, cj[j]);
-        if (tid < 8) {
+        if (tid < 64) {
             const double v = fold_tiles(a.tsum0, tid);
             if (tid == 0) bc[2] = v;
         }
@@ -570,13 +558,13 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         HIPK_BI_HO(a.flag_b)
         // ---- K5: omega' -> tests; x += alpha' p (+ omega' s); r = s (- omega' t); <r,r>, <rhat,r>   (TSL:920-961)
         const T t_own = live ? hipk_peek_t<T>(a.t + row) : (T)0;
-        if (tid < 8) {
+        if (tid < 64) {
             const double v = fold_subs(a.part_ss, tid);
             if (tid == 0) bc[0] = v;
-        } else if (tid >= 64 && tid < 72) {
+        } else if (tid < 128) {
             const double v = fold_tiles(a.tsum2, tid - 64);
             if (tid == 64) bc[1] = v;
-        } else if (tid >= 128 && tid < 136) {
+        } else if (tid < 192) {
             const double v = fold_tiles(a.tsum1, tid - 128);
             if (tid == 128) bc[2] = v;
         }
@@ -758,11 +746,14 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     int64_t it = 0, stop = INT64_MAX;
     // launch-bound systems with short rows, M = identity: the whole loop in one launch (hipk_bi_solve_lds_kernel)
     static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
-    bool lds_loop = small && !PRE && !ext && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kBiRowRegs && prm->profile == 0 &&
-                    maxiter > 0 && kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 && !lds_loop_failed &&
-                    !getenv("HIPK_BICGSTAB_NO_LDS_LOOP");
+    // up to 64 workgroups (8 chunks) on ONE XCD; up to 32 chunks (n <= 65536) spread over the chip, two workgroups per compute unit
+    const bool lds_spread = kGmSub * gm.g > 64;
+    bool lds_loop = gm.g <= 32 && !getenv("HIPK_BICGSTAB_NO_SMALL") && !PRE && !ext && gm.ch == HIPK_BASE_CHUNK &&
+                    A->max_row_len <= kBiRowRegs && prm->profile == 0 && maxiter > 0 &&
+                    kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_loop_failed &&
+                    !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
     if (lds_loop) {
-        bool local = !getenv("HIPK_BICGSTAB_LOOP_AGENT");
+        bool local = !lds_spread && !getenv("HIPK_BICGSTAB_LOOP_AGENT");
         const char *e = getenv("HIPK_BICGSTAB_LAUNCH_ITS");
         hipk_bi_lds_args<T> ca;
         ca.n = n;
@@ -779,13 +770,15 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         ca.scal = scal;
         ca.tsum0 = A->tile_part;
         ca.tsum1 = A->tile_part + 4 * (size_t)nt;
-        ca.tsum2 = part_spare;
+        ca.tsum2 = part_ts;   // (the launch sequence's chunk-partial slots of <t,s>, <t,t> are free here)
         ca.part_rr = part_rr;
         ca.part_rhr = part_rhr;
         ca.part_ss = part_ss;
-        ca.flag_a = (unsigned long long *)(part_spare + 1024);
-        ca.flag_b = ca.flag_a + 64;
-        ca.flag_c = ca.flag_a + 128;
+        ca.flag_a = (unsigned long long *)part_tt;   // 3 x 512 words
+        ca.flag_b = ca.flag_a + kHoMaxWg;
+        ca.flag_c = ca.flag_a + 2 * kHoMaxWg;
+        ca.spread = lds_spread ? 1 : 0;
+        const int lgrid = lds_spread ? kGmSub * gm.g : 8 * kGmSub * gm.g;
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 8192;
         if (ca.max_its < 1) ca.max_its = 1;
@@ -793,12 +786,12 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         hipk_bi_scal hs0;
         for (;;) {
             ca.it0 = it;
-            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 192 * sizeof(unsigned long long), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 3 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
             if (local)
-                hipk_bi_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_bi_solve_lds_kernel<T, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             else
-                hipk_bi_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_bi_solve_lds_kernel<T, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             HIPK_CHECK_HIP(hipGetLastError());
             HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
             HIPK_CHECK_HIP(hipStreamSynchronize(stream));

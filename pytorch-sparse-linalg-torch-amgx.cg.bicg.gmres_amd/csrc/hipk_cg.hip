@@ -226,14 +226,18 @@ struct hipk_cg_lds_args {
     int64_t maxiter;
     int64_t max_its;     // iteration budget of one launch
     int test_not_resident;   // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the placement check as failed
+    int spread;              // more than 64 workgroups: one per block all over the chip (then LOCAL = false)
 };
 static constexpr int kCgRowRegs = 12;
 
 template <typename T, bool LOCAL>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk_cg_lds_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
-    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
-    const int wg = blockIdx.x >> 3;
+    int wg = blockIdx.x;                             // spread (more than 64 workgroups): one per block, anywhere on the chip
+    if (!a.spread) {
+        if (blockIdx.x & 7) return;                  // the working blocks share an XCD (dispatch is round-robin over 8)
+        wg = blockIdx.x >> 3;
+    }
     const int c = wg / kGmSub, s = wg % kGmSub;
     const int g = a.g, nwg = g * kGmSub;
     if (c >= g) return;
@@ -328,9 +332,9 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         }
         // ---- vector role: alpha, r, x, <r,r> sub-partial  (TSL:846-850)
         const T Ap_own = live ? hipk_peek_t<T>(a.Ap + row) : (T)0;
-        if (tid < 8) {
+        if (tid < 64) {
             const double *tp = a.tile_pp;
-            const double pAp = hipk_fold_8x8<T>(tid, g, [&](int ci, int tt) {
+            const double pAp = hipk_fold_64x8(tid, g, [&](int ci, int tt) {
                 const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
                 if (tl >= ntiles) return 0.0;
                 const double *w4 = tp + (size_t)tl * 4;
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         for (int j = 0; j < kCgRowRegs; ++j)
             if (j < wmax) rg[j] = hipk_peek_off<T>(a.r, cj[j]);
         const T r_t = tlive ? hipk_peek_t<T>(a.r + trow) : (T)0;
-        if (tid < 8) {
-            const double rr = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.rr_sub + ci * kGmSub + ss); });
+        if (tid < 64) {
+            const double rr = hipk_fold_64x8(tid, g, [&](int ci, int ss) { return hipk_peek(a.rr_sub + ci * kGmSub + ss); });
             if (tid == 0) bc[1] = rr;
         }
         __syncthreads();
@@ -500,10 +504,15 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     int64_t it = 0, stop = INT64_MAX;
     // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel), bounded iterations per launch
     static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
-    bool lds_loop = small && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs && prm->profile == 0 && maxiter > 0 &&
-                    kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 && !lds_loop_failed && !getenv("HIPK_CG_NO_LDS_LOOP");
+    // up to 64 workgroups (8 chunks) on ONE XCD, up to 512 (64 chunks, n <= 131072) spread over the chip, two per compute unit
+    const bool lds_spread = kGmSub * gm.g > 64;
+    // (measured per iteration, one launch vs three launches: 5.5 vs 16 us at 8 chunks, 10.6 vs 19.9 at 16, 12.3 vs 16.6 at 32,
+    // 18.3 vs 18.3 at 64: the agent-scope hand-offs grow with the workgroup count -- taken up to 32 chunks, n <= 65536)
+    bool lds_loop = gm.g <= 32 && !getenv("HIPK_CG_NO_SMALL") && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs &&
+                    prm->profile == 0 && maxiter > 0 && kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) &&
+                    !lds_loop_failed && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
     if (lds_loop) {
-        bool local = !getenv("HIPK_CG_LOOP_AGENT");
+        bool local = !lds_spread && !getenv("HIPK_CG_LOOP_AGENT");
         const char *e = getenv("HIPK_CG_LAUNCH_ITS");
         hipk_cg_lds_args<T> ca;
         ca.n = n;
@@ -518,8 +527,10 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         ca.scal = scal;
         ca.tile_pp = A->tile_part;
         ca.rr_sub = part_b;
-        ca.flag_a = (unsigned long long *)(part_c + 1024);
-        ca.flag_b = ca.flag_a + 64;
+        ca.flag_a = (unsigned long long *)(part_c + 1024);   // 2 x 512 words
+        ca.flag_b = ca.flag_a + kHoMaxWg;
+        ca.spread = lds_spread ? 1 : 0;
+        const int lgrid = lds_spread ? kGmSub * gm.g : 8 * kGmSub * gm.g;
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 16384;
         if (ca.max_its < 1) ca.max_its = 1;
@@ -527,12 +538,12 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         hipk_cg_scal hs0;
         for (;;) {
             ca.it0 = it;
-            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 128 * sizeof(unsigned long long), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_cg_scal) - offsetof(hipk_cg_scal, it_done), stream));
             if (local)
-                hipk_cg_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_cg_solve_lds_kernel<T, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             else
-                hipk_cg_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_cg_solve_lds_kernel<T, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             HIPK_CHECK_HIP(hipGetLastError());
             HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
             HIPK_CHECK_HIP(hipStreamSynchronize(stream));

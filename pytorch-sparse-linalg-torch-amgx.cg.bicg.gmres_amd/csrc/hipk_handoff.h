@@ -65,6 +65,24 @@ __device__ __forceinline__ double hipk_fold_8x8(int i8, int g, F val) {
     a = a + hipk_row_shl<1>(a);
     return a;
 }
+// The same for up to 64 chunks, one LANE per chunk (a whole wavefront must call): inner fold of val(lane, 0..7), then the spec's
+// fold of the chunk results -- thread t takes partial t (g <= 256: one each), tree v[t] += v[t+s], of which the strides 32 .. 1
+// reach the <= 64 non-zero slots.  For g <= 8 the additions (and bits) are those of hipk_fold_8x8.  Valid in lane 0.
+template <class F>
+__device__ __forceinline__ double hipk_fold_64x8(int lane, int g, F val) {
+    double a = 0.0;
+    if (lane < g) {
+        double p[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) p[s] = val(lane, s);
+        a = 0.0 + (((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7])));
+    } else {
+        a = 0.0 + 0.0;
+    }
+    return hipk_wave_sum(a);
+}
+static constexpr int kHoMaxChunks = 64;    // chunks (lanes of the fold above) the one-launch kernels handle: n <= 131072
+static constexpr int kHoMaxWg = 8 * kHoMaxChunks;
 // sum over the 32 lanes of a half wavefront with the strides 16 .. 1 of the spec's tree; valid in lanes 0 and 32
 __device__ __forceinline__ double hipk_half_sum(double d) {
     d = d + hipk_lane_up16(d);
@@ -83,7 +101,8 @@ static constexpr int kGmSub = 8;        // sub-workgroups per reduction chunk
 // (which only bypass the reader's L1): a hand-off costs L2 round trips.  LOCAL = false: agent-scope (sc1, write-through)
 // stores, valid on any placement, every trip through the fabric.  Each workgroup owns one flag word per hand-off kind and
 // stores the hand-off's sequence number into it after ALL its waves have drained their stores; a consumer polls the
-// <= 64 flags with one wave-wide load.
+// flags with one wave-wide load per 64 workgroups.  Up to 64 workgroups (n <= 16384) run on ONE XCD; larger systems spread over the
+// chip (one workgroup per block, agent-scope hand-offs only).
 template <bool LOCAL>
 __device__ __forceinline__ void hipk_ho_store(double *p, double v) {
     if (LOCAL)
@@ -120,12 +139,18 @@ __device__ __forceinline__ unsigned long long hipk_ho_sync(unsigned long long *f
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         if (lane == 0) hipk_ho_flag<LOCAL>(flags + wg, 2 * seq + bit);
-        unsigned long long f, f0 = ~0ull;
+        unsigned long long f0 = ~0ull;
         unsigned spins = 0;
-        for (;;) {
-            f = (lane < nwg) ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-            if (__all(f >= 2 * seq)) {
-                f0 = __shfl(f, 0);
+        for (;;) {   // <= 512 flags: one wave-wide load per 64
+            bool all = true;
+            unsigned long long first = 0;
+            for (int j0 = 0; j0 < nwg; j0 += 64) {
+                const unsigned long long f = (j0 + lane < nwg) ? __hip_atomic_load(flags + j0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                all = all && __all(f >= 2 * seq);
+                if (j0 == 0) first = __shfl(f, 0);
+            }
+            if (all) {
+                f0 = first;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

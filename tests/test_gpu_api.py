@@ -545,7 +545,10 @@ def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
     dev = "cuda:0"
     mats = [create_poisson_2d_csr(100, 100, device=dev), create_poisson_2d_csr(7, 5, device=dev),
             create_poisson_2d_csr(128, 128, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
-            create_poisson_2d_csr(45, 46, device=dev), create_ldc_pressure_csr(64, device=dev)]
+            create_poisson_2d_csr(45, 46, device=dev), create_ldc_pressure_csr(64, device=dev),
+            # more than 8 chunks: up to 512 workgroups spread over the chip (agent-scope hand-offs, one lane per chunk in the folds)
+            create_poisson_2d_csr(181, 181, device=dev), create_poisson_2d_csr(300, 200, device=dev),
+            create_poisson_2d_csr(256, 256, device=dev), create_variable_diffusion_2d_csr(129, 128, device=dev)]
     variants = ({}, {"HIPK_CG_NO_LDS_LOOP": "1"}, {"HIPK_CG_LAUNCH_ITS": "7"}, {"HIPK_CG_LOOP_AGENT": "1", "HIPK_CG_LAUNCH_ITS": "50"})
     keys = ("HIPK_CG_NO_LDS_LOOP", "HIPK_CG_LAUNCH_ITS", "HIPK_CG_LOOP_AGENT")
     for mi, A in enumerate(mats):
@@ -587,7 +590,10 @@ def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
     mats = [create_convdiff_2d_csr(100, 100, device=dev), create_convdiff_2d_csr(7, 5, device=dev),
             create_poisson_2d_csr(128, 128, device=dev), create_variable_diffusion_2d_csr(90, 70, device=dev),
             create_convdiff_2d_csr(45, 46, device=dev), create_ldc_pressure_csr(64, device=dev),
-            torch.eye(300, dtype=torch.float64, device=dev).to_sparse_csr()]
+            torch.eye(300, dtype=torch.float64, device=dev).to_sparse_csr(),
+            # more than 8 chunks: workgroups spread over the chip (agent-scope hand-offs, one lane per chunk in the folds)
+            create_convdiff_2d_csr(181, 181, device=dev), create_convdiff_2d_csr(300, 200, device=dev),
+            create_convdiff_2d_csr(256, 256, device=dev)]
     variants = ({}, {"HIPK_BICGSTAB_NO_LDS_LOOP": "1"}, {"HIPK_BICGSTAB_LAUNCH_ITS": "5"},
                 {"HIPK_BICGSTAB_LOOP_AGENT": "1", "HIPK_BICGSTAB_LAUNCH_ITS": "40"})
     keys = ("HIPK_BICGSTAB_NO_LDS_LOOP", "HIPK_BICGSTAB_LAUNCH_ITS", "HIPK_BICGSTAB_LOOP_AGENT")
