@@ -698,6 +698,8 @@ struct hipk_gm_cyc_args {
     long long cycles_left;  // cycles the solve may still run (maxiter - cycles so far),
     long long max_cycles;   // and the cycle budget of one launch
     int test_not_resident;  // tests (HIPK_TEST_LDS_NOT_RESIDENT): report the workgroups as not co-resident
+    int spread;             // more than 64 workgroups: one per block all over the chip (then LOCAL = false)
+    unsigned long long *flag_a, *flag_b;   // [512] each: per-workgroup hand-off flags, zeroed before the launch
     int32_t *bar;      // barrier counter, zeroed by hipk_gm_cycle_init_kernel
     double eps;
     unsigned long long *stamps;  // diagnostic (HIPK_GM_STAMPS=1): per-phase shader-clock totals of workgroup 0, else null
@@ -1240,8 +1242,11 @@ template <typename T, bool LOCAL>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk_gm_cyc_args<T> a) {
     using O = hipk_gm_lds_off;
     constexpr int VEC = hipk_vec<T>::VEC;
-    if (blockIdx.x & 7) return;                      // the working blocks share an XCD (dispatch is round-robin over 8)
-    const int wg = blockIdx.x >> 3;
+    int wg = blockIdx.x;                             // spread (more than 64 workgroups): one per block, anywhere on the chip
+    if (!a.spread) {
+        if (blockIdx.x & 7) return;                  // the working blocks share an XCD (dispatch is round-robin over 8)
+        wg = blockIdx.x >> 3;
+    }
     const int c = wg / kGmSub, s = wg % kGmSub;
     const int g = a.g, nwg = g * kGmSub;
     if (c >= g) return;
@@ -1292,21 +1297,18 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     Vl[tid] = live ? a.V[row] : (T)0;                // column 0: written by the launch before this one
     int epoch = 0;
-    if (a.test_not_resident) {   // uniform
+    // every workgroup resident -- and, LOCAL, all on one XCD?  (the only exchange of this launch that does not rely on the
+    // placement: agent-scope atomics.)  Nothing has been modified yet: a failure leaves the solve to the launch sequences.
+    if (LOCAL && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!hipk_gbar(a.bar, nwg, epoch, fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
     }
     if (LOCAL) {
-        // all workgroups on one XCD?  (the only exchange of this launch that does not rely on it: agent-scope atomics)
-        if (tid == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            __hip_atomic_fetch_or(&scal->xcc_mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!hipk_gbar(a.bar, nwg, epoch, fail)) {
-            if (tid == 0) scal->redo = -1;
-            return;
-        }
         if (tid == 0) {
             const unsigned mask = __hip_atomic_load(&scal->xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *fail = (__builtin_popcount(mask) == 1) ? 0 : 1;
@@ -1316,8 +1318,6 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
             if (tid == 0) scal->redo = -2;
             return;
         }
-    } else {
-        __syncthreads();
     }
     unsigned long long seq = 0;                      // hand-offs so far (uniform over the launch)
     // the vector the next SpMV gathers: column 0 as the launch before left it (first cycle), afterwards the UNNORMALISED q or
@@ -1411,12 +1411,12 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                     }
                 }
                 HIPK_STAMP(1)
-                HIPK_HO(scal->flag_md)
+                HIPK_HO(a.flag_a)
                 HIPK_STAMP(2)
                 // ---------------- B: h = fold of the sub-partials (thread (j, chunk i8): 8 loads, register folds)
                 T wt = (T)0;
                 if (pass == 0 && trow < n) wt = hipk_peek_t<T>(wcol + trow);     // tile sums of <w,w>: in flight with the fold
-                {
+                if (g <= 8) {
                     const int j = tid >> 3, i8 = tid & 7;
                     const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
                     double hj = 0.0;
@@ -1426,6 +1426,18 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                         hj = (j <= k) ? hj : 0.0;
                         hs[j] = hj;
                         rv[j] = ((pass == 0) ? 0.0 : rv[j]) + hj;   // rvec += h (TSL:305), kept by every workgroup
+                    }
+                } else {   // more than 8 chunks: a wavefront per column, a lane per chunk
+                    for (int j = wave; j < HIPK_GM_LDH; j += HIPK_THREADS / 64) {
+                        double hj = 0.0;
+                        if (j <= k) {   // uniform per wavefront
+                            const double *pj = a.part_md + (size_t)j * HIPK_MAX_PARTS;
+                            hj = hipk_fold_64x8(lane, g, [&](int ci, int ss) { return hipk_peek(pj + ci * kGmSub + ss); });
+                        }
+                        if (lane == 0) {
+                            hs[j] = hj;
+                            rv[j] = ((pass == 0) ? 0.0 : rv[j]) + hj;
+                        }
                     }
                 }
                 if (pass == 0) {
@@ -1471,7 +1483,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                 }
                 HIPK_STAMP(3)
                 // second hand-off of the pass; meanwhile thread 192 forms ||rvec|| for the CGS2 decision (TSL:313-326)
-                if (hipk_ho_sync<LOCAL>(scal->flag_q, wg, nwg, ++seq, 0u, res_lds, [&]() {
+                if (hipk_ho_sync<LOCAL>(a.flag_b, wg, nwg, ++seq, 0u, res_lds, [&]() {
                         double rr = 0.0;
                         for (int j0 = 0; j0 <= k; j0 += 8) {
                             double r_[8];
@@ -1490,8 +1502,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                 }
                 HIPK_STAMP(4)
                 // ---------------- C: ||q||^2 (every workgroup, same bits); CGS2 decision after the first pass (TSL:313-326)
-                if (tid < 8) {
-                    const double qq = hipk_fold_8x8<T>(tid, g, [&](int ci, int ss) { return hipk_peek(a.part_qq + ci * kGmSub + ss); });
+                if (tid < 64) {
+                    const double qq = hipk_fold_64x8(tid, g, [&](int ci, int ss) { return hipk_peek(a.part_qq + ci * kGmSub + ss); });
                     if (tid == 0) {
                         bc[1] = qq;
                         double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
@@ -1499,10 +1511,10 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
                         const double rnorm = bc[3];
                         bc[0] = (rnorm < qnorm * HIPK_INV_SQRT2) ? 1.0 : 0.0;
                     }
-                } else if (tid >= 64 && tid < 72 && pass == 0) {
+                } else if (tid < 128 && pass == 0) {
                     // ||A v||^2 from the tile sums (hipk_fold_tiles8: per chunk the fold of its <= 8 tiles, then the chunks)
                     const double *tp = a.tile_ww;
-                    const double ww = hipk_fold_8x8<T>(tid - 64, g, [&](int ci, int tt) {
+                    const double ww = hipk_fold_64x8(tid - 64, g, [&](int ci, int tt) {
                         const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
                         if (tl >= ntiles) return 0.0;
                         const double *w4 = tp + (size_t)tl * 4;
@@ -1652,7 +1664,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
             x_own = (T)((double)x_own + sacc);
             if (live) hipk_ho_store<LOCAL>(a.x + row, x_own);
         }
-        HIPK_HO(scal->flag_md)
+        HIPK_HO(a.flag_a)
         // r = (M)(b - A x) on the own row (TSL:791), unnormalised into a.q
         T r_own;
         {
@@ -1677,7 +1689,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
             if (live) hipk_ho_store<LOCAL>(a.q + row, r_own);
         }
         matvecs += 1;
-        HIPK_HO(scal->flag_q)
+        HIPK_HO(a.flag_b)
         {   // wavefront sums of <r,r> over the own tile
             T rt = (T)0;
             if (trow < n) rt = hipk_peek_t<T>(a.q + trow);
@@ -1685,10 +1697,10 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_gm_solve_lds_kernel(hipk
             d1 = hipk_wave_sum(d1);
             if (lane == 0 && tile < ntiles) hipk_ho_store<LOCAL>(&a.tile_ww[(size_t)tile * 4 + wave], d1);
         }
-        HIPK_HO(scal->flag_md)
-        if (tid < 8) {
+        HIPK_HO(a.flag_a)
+        if (tid < 64) {
             const double *tp = a.tile_ww;
-            const double r2 = hipk_fold_8x8<T>(tid, g, [&](int ci, int tt) {
+            const double r2 = hipk_fold_64x8(tid, g, [&](int ci, int tt) {
                 const int tl = ci * (HIPK_BASE_CHUNK / HIPK_TILE) + tt;
                 if (tl >= ntiles) return 0.0;
                 const double *w4 = tp + (size_t)tl * 4;
@@ -1750,7 +1762,6 @@ __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int i
         scal->R[i] = ((i / HIPK_GM_LDH) == (i % HIPK_GM_LDH)) ? 1.0 : 0.0;  // TSL:581
     for (int i = t; i < HIPK_GM_LDH * 2; i += blockDim.x) scal->gv[i] = 0.0;
     for (int i = t; i <= HIPK_GM_LDH; i += blockDim.x) scal->beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
-    for (int i = t; i < 64; i += blockDim.x) scal->flag_md[i] = scal->flag_q[i] = 0ull;
     if (t == 0) {
         scal->bar = 0;
         scal->xcc_mask = 0;
@@ -2052,8 +2063,12 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     // ... and 8 g workgroups fit ONE XCD (an eighth of the compute units, two workgroups each); a process whose resident
     // workgroups once failed to meet (a shared device) does not try again: the wait for that verdict takes seconds
     static bool lds_cycle_failed = false;
-    bool cyc_lds = cyc && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 && kGmSub * gm.g <= 2 * (A->n_cu / 8) && kGmSub * gm.g <= 64 &&
-                   !lds_cycle_failed && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    // 9 .. 32 chunks (n <= 65536): the same kernel with its workgroups spread over the chip (agent-scope hand-offs)
+    const bool lds_spread = gm.g > 8 && gm.g <= 32 && gm.ch == HIPK_BASE_CHUNK && !ext && A->max_row_len <= HIPK_LONG_ROW &&
+                            !getenv("HIPK_GMRES_NO_SMALL") && !getenv("HIPK_GMRES_NO_CYCLE") && !getenv("HIPK_NO_LDS_SPREAD");
+    bool cyc_lds = (cyc || lds_spread) && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 &&
+                   kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_cycle_failed && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
+    if (lds_spread) cyc = cyc_lds;   // beyond 8 chunks there is no one-workgroup-per-chunk kernel to fall back to
     if (cyc_lds) {
         static bool attr_done[2] = {false, false};   // the launches ask for more than the default 64 KB of dynamic LDS
         if (!attr_done[sizeof(T) == 8]) {
@@ -2063,7 +2078,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         }
     }
     // its hand-offs through the shared L2 of ONE XCD (plain stores; placement verified by the kernel), else agent-scope stores
-    bool cyc_local = !getenv("HIPK_GM_CYCLE_AGENT");
+    bool cyc_local = !lds_spread && !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     const bool stream_k = !small && !getenv("HIPK_GMRES_NO_STREAM");  // large systems: hipk_gm_*_stream_kernel
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
@@ -2107,12 +2122,17 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
             ca.bar = &scal->bar;
             ca.eps = eps_t;
-            ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1024) : nullptr;
+            ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1600) : nullptr;
             if (ca.stamps && cycles == 0) (void)hipMemsetAsync(ca.stamps, 0, 128, stream);
+            ca.spread = lds_spread ? 1 : 0;
+            ca.flag_a = (unsigned long long *)(part_spare + 512);   // 2 x 512 words
+            ca.flag_b = ca.flag_a + kHoMaxWg;
+            if (cyc_lds) (void)hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream);
+            const int lgrid = lds_spread ? kGmSub * gm.g : 8 * kGmSub * gm.g;
             if (cyc_lds && cyc_local)
-                hipk_gm_solve_lds_kernel<T, true><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
+                hipk_gm_solve_lds_kernel<T, true><<<lgrid, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
             else if (cyc_lds)
-                hipk_gm_solve_lds_kernel<T, false><<<8 * kGmSub * gm.g, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
+                hipk_gm_solve_lds_kernel<T, false><<<lgrid, HIPK_THREADS, hipk_gm_solve_lds_bytes<T>(m), stream>>>(ca);
             else
                 hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
@@ -2245,7 +2265,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     if (rc != HIPK_OK) return rc;
     if ((cyc || cyc_lds) && getenv("HIPK_GM_STAMPS")) {  // diagnostic build-in: where workgroup 0 of the cycle kernel spent its shader clocks
         unsigned long long st8[16];
-        HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1024, sizeof(st8), hipMemcpyDeviceToHost, stream));
+        HIPK_CHECK_HIP(hipMemcpyAsync(st8, part_spare + 1600, sizeof(st8), hipMemcpyDeviceToHost, stream));
         HIPK_CHECK_HIP(hipStreamSynchronize(stream));
         if (cyc_lds)
             fprintf(stderr, "hipk_gm_solve_lds_kernel stamps (shader clocks of workgroup 0, thread 0; %lld cycles of %d steps): A SpMV %llu | "
