@@ -23,6 +23,15 @@
 #include "hipk_spmv.h"
 #include "hipk_handoff.h"
 
+// progress / placement block of the one-launch loops (hipk_cg_solve_lds_kernel), zeroed before each launch
+struct hipk_lds_ctl {
+    double rs_last;    // <r,r> of the last finished iteration
+    int64_t it_done;   // iterations finished when the launch returned
+    int32_t redo;      // < 0: its resident workgroups did not all arrive / were spread over several XCDs (nothing was modified)
+    int32_t bar;       // counter barrier of its placement check
+    unsigned xcc_mask;
+    unsigned pad;
+};
 struct hipk_cg_scal {
     double gamma[2];   // <r,r> ping-pong by iteration parity
     double atol2;      // max(tol^2 <b,b>, atol^2)            (TSL:815-817)
@@ -31,12 +40,7 @@ struct hipk_cg_scal {
     double xx;         // <x,x>                               (TSL:1013)
     int64_t stop_it;   // iterations >= stop_it are no-ops
     int64_t *host_sig; // pinned host word the direction kernel reports to (hipk_pacer), or null
-    // hipk_cg_solve_lds_kernel (small systems: the whole loop in one launch)
-    int64_t it_done;   // iterations finished when the launch returned
-    int32_t redo;      // < 0: its resident workgroups did not all arrive / were spread over several XCDs (nothing was modified)
-    int32_t bar;       // counter barrier of its placement check
-    unsigned xcc_mask;
-    unsigned pad;
+    hipk_lds_ctl ctl;  // hipk_cg_solve_lds_kernel (small systems: the whole loop in one launch)
 };
 static_assert(sizeof(hipk_cg_scal) <= 256, "the scalar block is 256 bytes");
 
@@ -218,9 +222,15 @@ struct hipk_cg_lds_args {
     const T *val;
     T *x, *r, *p;
     T *Ap;               // exchange buffer: A p by rows
-    hipk_cg_scal *scal;
+    hipk_lds_ctl *ctl;          // progress of the launch
+    double *gamma;              // [2] by iteration parity; in: gamma of iteration it0 (it0 > 0 or M = identity), out: of the last one
+    const double *atol2;        // device scalars of the solve's header block
+    int64_t *stop_it;
+    const T *dinv;              // PRE: the Jacobi preconditioner's diagonal (M = diag(dinv), TSL:849)
+    const double *rz0_parts;    // PRE, it0 = 0: chunk partials of gamma0 = <r0, M r0> (hipk_pcg_start_kernel)
     double *tile_pp;     // [ntiles * 4] wavefront sums of <p,Ap>
     double *rr_sub;      // [8 g] sub-partials of <r,r>
+    double *rz_sub;      // PRE: [8 g] sub-partials of <r, M r>
     unsigned long long *flag_a, *flag_b;   // [64] each, zeroed before the launch
     int64_t it0;         // iterations done before this launch
     int64_t maxiter;
@@ -230,7 +240,7 @@ struct hipk_cg_lds_args {
 };
 static constexpr int kCgRowRegs = 12;
 
-template <typename T, bool LOCAL>
+template <typename T, bool LOCAL, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk_cg_lds_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
     int wg = blockIdx.x;                             // spread (more than 64 workgroups): one per block, anywhere on the chip
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
     const int c = wg / kGmSub, s = wg % kGmSub;
     const int g = a.g, nwg = g * kGmSub;
     if (c >= g) return;
-    hipk_cg_scal *scal = a.scal;
+    hipk_lds_ctl *scal = a.ctl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = tid & 31, e8 = tid >> 5;
     const int64_t n = a.n;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
     const int64_t trow = (int64_t)tile * HIPK_TILE + tid;
     const bool tlive = trow < n;
 
-    __shared__ T wl[HIPK_THREADS];
+    __shared__ T wl[HIPK_THREADS], wz[HIPK_THREADS];
     __shared__ double bc[4];
     __shared__ int fail;
     __shared__ unsigned long long res_lds;
@@ -277,15 +287,26 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         pg[j] = (j < len) ? a.p[cc] : (T)0;
     }
     T p_t = tlive ? a.p[trow] : (T)0;
+    // PRE: the diagonal of M at the own row, at the tile row and at the tile row's columns
+    T d_own = (T)1, d_t = (T)1, dc[kCgRowRegs];
+#pragma unroll
+    for (int j = 0; j < kCgRowRegs; ++j) dc[j] = (T)1;
+    if (PRE) {
+        d_own = live ? a.dinv[row] : (T)0;
+        d_t = tlive ? a.dinv[trow] : (T)0;
+#pragma unroll
+        for (int j = 0; j < kCgRowRegs; ++j) dc[j] = (j < len) ? a.dinv[a.col[lo + j]] : (T)0;
+    }
     int wmax = len < kCgRowRegs ? len : kCgRowRegs;
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(wmax, off);
         wmax = o > wmax ? o : wmax;
     }
     wmax = __builtin_amdgcn_readfirstlane(wmax);
-    double gamma = scal->gamma[a.it0 & 1];
-    const double atol2 = scal->atol2;
-    const int64_t stop0 = scal->stop_it;
+    double gamma = a.gamma[a.it0 & 1];
+    const double atol2 = *a.atol2;
+    const int64_t stop0 = *a.stop_it;
+    double rs_last = scal->rs_last;
 
     // every workgroup resident (and, LOCAL, on one XCD)?  Nothing has been modified yet: a failure leaves the solve to the launches
     int epoch = 0;
@@ -308,6 +329,16 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
             if (tid == 0) scal->redo = -2;
             return;
         }
+    }
+    if (PRE && a.it0 == 0) {   // gamma0 = <r0, M r0>: chunk partials of the launch before this one (hipk_reduce_parts)
+        if (tid < 64) {
+            double a8 = (tid < g) ? a.rz0_parts[tid] : 0.0;
+            a8 = 0.0 + a8;
+            a8 = hipk_wave_sum(a8);
+            if (tid == 0) bc[2] = a8;
+        }
+        __syncthreads();
+        gamma = bc[2];
     }
     unsigned long long seq = 0;
     int64_t it = a.it0;
@@ -352,17 +383,23 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
             x_own = x_own + m0;
         }
         wl[tid] = r_own;
+        if (PRE) wz[tid] = d_own * r_own;   // z = M r (TSL:849), never stored to memory
         if (live) hipk_ho_store<LOCAL>(a.r + row, r_own);
         __syncthreads();
         if (tid < 32) {
-            double acc = 0.0;
+            double acc = 0.0, acc1 = 0.0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const double v = (double)wl[e * 32 + tid];
                 acc = fma(v, v, acc);
+                if (PRE) acc1 = fma(v, (double)wz[e * 32 + tid], acc1);   // TSL:850
             }
             acc = hipk_half_sum(acc);
-            if (tid == 0) hipk_ho_store<LOCAL>(&a.rr_sub[wg], acc);
+            if (PRE) acc1 = hipk_half_sum(acc1);
+            if (tid == 0) {
+                hipk_ho_store<LOCAL>(&a.rr_sub[wg], acc);
+                if (PRE) hipk_ho_store<LOCAL>(&a.rz_sub[wg], acc1);
+            }
         }
         if (hipk_ho_sync<LOCAL>(a.flag_b, wg, nwg, ++seq, 0u, &res_lds) == ~0ull) {
             if (tid == 0) scal->redo = -3;
@@ -377,23 +414,31 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         if (tid < 64) {
             const double rr = hipk_fold_64x8(tid, g, [&](int ci, int ss) { return hipk_peek(a.rr_sub + ci * kGmSub + ss); });
             if (tid == 0) bc[1] = rr;
+        } else if (PRE && tid < 128) {
+            const double rz = hipk_fold_64x8(tid - 64, g, [&](int ci, int ss) { return hipk_peek(a.rz_sub + ci * kGmSub + ss); });
+            if (tid == 64) bc[3] = rz;
         }
         __syncthreads();
         const double rr = bc[1];
-        const T beta = (T)(rr / gamma);
+        const double gamma_new = PRE ? bc[3] : rr;   // <r,z> steers alpha and beta, <r,r> the stop test (TSL:835-841)
+        const T beta = (T)(gamma_new / gamma);
         {
+            const T z_own = PRE ? d_own * r_own : r_own;
             const T m = beta * p_own;
-            p_own = r_own + m;
+            p_own = z_own + m;
+            const T z_t = PRE ? d_t * r_t : r_t;
             const T mt = beta * p_t;
-            p_t = r_t + mt;
+            p_t = z_t + mt;
         }
 #pragma unroll
         for (int j = 0; j < kCgRowRegs; ++j)
             if (j < wmax) {
+                const T zj = PRE ? dc[j] * rg[j] : rg[j];
                 const T m = beta * pg[j];
-                pg[j] = rg[j] + m;
+                pg[j] = zj + m;
             }
-        gamma = rr;
+        gamma = gamma_new;
+        rs_last = rr;
         ++it;
         done = (it >= a.maxiter || rr <= atol2);
         if (it - a.it0 >= a.max_its) break;
@@ -403,9 +448,10 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_cg_solve_lds_kernel(hipk
         a.p[row] = p_own;
     }
     if (wg == 0 && tid == 0) {
-        scal->gamma[it & 1] = gamma;
+        a.gamma[it & 1] = gamma;
+        scal->rs_last = rs_last;
         scal->it_done = it;
-        if (done && it < stop0) scal->stop_it = it;
+        if (done && it < stop0) *a.stop_it = it;
     }
 }
 
@@ -524,7 +570,13 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         ca.r = r;
         ca.p = p;
         ca.Ap = Ap;
-        ca.scal = scal;
+        ca.ctl = &scal->ctl;
+        ca.gamma = scal->gamma;
+        ca.atol2 = &scal->atol2;
+        ca.stop_it = &scal->stop_it;
+        ca.dinv = nullptr;
+        ca.rz0_parts = nullptr;
+        ca.rz_sub = nullptr;
         ca.tile_pp = A->tile_part;
         ca.rr_sub = part_b;
         ca.flag_a = (unsigned long long *)(part_c + 1024);   // 2 x 512 words
@@ -539,20 +591,20 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         for (;;) {
             ca.it0 = it;
             HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream));
-            HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_cg_scal) - offsetof(hipk_cg_scal, it_done), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
             if (local)
-                hipk_cg_solve_lds_kernel<T, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_cg_solve_lds_kernel<T, true, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             else
-                hipk_cg_solve_lds_kernel<T, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_cg_solve_lds_kernel<T, false, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             HIPK_CHECK_HIP(hipGetLastError());
             HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
             HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-            if (hs0.redo < 0) {
-                if (hs0.redo == -3) {
+            if (hs0.ctl.redo < 0) {
+                if (hs0.ctl.redo == -3) {
                     hipk_set_error("hipk_cg_solve: a resident workgroup of the one-launch loop stopped arriving");
                     return HIPK_ERR_HIP;
                 }
-                if (hs0.redo == -2 && local) {   // spread over several XCDs: agent-scope hand-offs
+                if (hs0.ctl.redo == -2 && local) {   // spread over several XCDs: agent-scope hand-offs
                     local = false;
                     continue;
                 }
@@ -560,7 +612,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                 lds_loop = false;
                 break;
             }
-            it = hs0.it_done;
+            it = hs0.ctl.it_done;
             if (hs0.stop_it <= it || it >= maxiter) break;
         }
     }
@@ -861,7 +913,10 @@ struct hipk_pcg_scal {
     int64_t stop_it;
     int64_t *host_sig;  // as in hipk_cg_scal
     int64_t pad;
+    double gamma[2];    // hipk_cg_solve_lds_kernel<.., PRE>: <r,z> by iteration parity (the launch sequence keeps it as partials)
+    hipk_lds_ctl ctl;
 };
+static_assert(sizeof(hipk_pcg_scal) <= 256, "the scalar block is 256 bytes");
 
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_pcg_start_kernel(
@@ -1080,7 +1135,72 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     sa.stop_it = &scal->stop_it;
 
     int64_t it = 0, stop = INT64_MAX;
-    for (; it < maxiter; ++it) {
+    // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel<.., PRE = true>)
+    static bool lds_loop_failed = false;
+    const bool lds_spread = kGmSub * gm.g > 64;
+    bool lds_loop = gm.g <= 32 && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs && prm->profile == 0 && maxiter > 0 &&
+                    kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_loop_failed &&
+                    !getenv("HIPK_CG_NO_SMALL") && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
+    if (lds_loop) {
+        bool local = !lds_spread && !getenv("HIPK_CG_LOOP_AGENT");
+        const char *e = getenv("HIPK_CG_LAUNCH_ITS");
+        hipk_cg_lds_args<T> ca;
+        ca.n = n;
+        ca.g = gm.g;
+        ca.crow = A->crow;
+        ca.col = A->col;
+        ca.val = (const T *)A->val;
+        ca.x = x;
+        ca.r = r;
+        ca.p = p;
+        ca.Ap = Ap;
+        ca.ctl = &scal->ctl;
+        ca.gamma = scal->gamma;
+        ca.atol2 = &scal->atol2;
+        ca.stop_it = &scal->stop_it;
+        ca.dinv = dinv;
+        ca.rz0_parts = part_z[0];
+        ca.rz_sub = part_z[1];
+        ca.tile_pp = A->tile_part;
+        ca.rr_sub = part_b;
+        ca.flag_a = (unsigned long long *)(part_c + 1024);   // 2 x 512 words
+        ca.flag_b = ca.flag_a + kHoMaxWg;
+        ca.spread = lds_spread ? 1 : 0;
+        ca.maxiter = maxiter;
+        ca.max_its = e ? atoll(e) : 16384;
+        if (ca.max_its < 1) ca.max_its = 1;
+        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
+        const int lgrid = lds_spread ? kGmSub * gm.g : 8 * kGmSub * gm.g;
+        hipk_pcg_scal hs0;
+        for (;;) {
+            ca.it0 = it;
+            HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream));
+            HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
+            if (local)
+                hipk_cg_solve_lds_kernel<T, true, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+            else
+                hipk_cg_solve_lds_kernel<T, false, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+            HIPK_CHECK_HIP(hipGetLastError());
+            HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+            HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+            if (hs0.ctl.redo < 0) {
+                if (hs0.ctl.redo == -3) {
+                    hipk_set_error("hipk_pcg_solve: a resident workgroup of the one-launch loop stopped arriving");
+                    return HIPK_ERR_HIP;
+                }
+                if (hs0.ctl.redo == -2 && local) {   // spread over several XCDs: agent-scope hand-offs
+                    local = false;
+                    continue;
+                }
+                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // nothing was modified: the launch sequence below takes over
+                lds_loop = false;
+                break;
+            }
+            it = hs0.ctl.it_done;
+            if (hs0.stop_it <= it || it >= maxiter) break;
+        }
+    }
+    for (; !lds_loop && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
         {
@@ -1119,7 +1239,7 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     const int64_t iterations = (hs.stop_it < it) ? hs.stop_it : it;
     matvecs += iterations;
     hipk_finish_isolve_stats(st, prm, hs.bs, hs.res2, hs.xx, iterations, matvecs);
-    st->recurrence_rs = hs.rs_last;
+    st->recurrence_rs = (lds_loop && iterations > 0) ? hs.ctl.rs_last : hs.rs_last;
     st->breakdown = 0;
     float ms = 0.f;
     HIPK_CHECK_HIP(hipEventElapsedTime(&ms, whole.a, whole.b));

@@ -542,7 +542,7 @@ def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
     the three-launches-per-iteration loop: same bits, same counts -- ragged tails, one to eight chunks, x0, maxiter cut-offs that
     fall inside and on the boundary of a launch's iteration budget, agent-scope hand-offs, fp32 storage."""
     import torch
-    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, cg, get_last_stats
     from pytorch_sparse_solver.utils.matrix_utils import (create_ldc_pressure_csr, create_poisson_2d_csr,
                                                           create_variable_diffusion_2d_csr)
     dev = "cuda:0"
@@ -562,8 +562,10 @@ def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
             g = torch.Generator(device=dev).manual_seed(n)
             b = torch.randn(n, dtype=dt, device=dev, generator=g)
             x0 = torch.randn(n, dtype=dt, device=dev, generator=g)
+            jac = JacobiPreconditioner(Ad)   # the same loop with M = diag(A)^-1 (hipk_cg_solve_lds_kernel<.., PRE>)
             for kw in (dict(tol=1e-8 if dt == torch.float64 else 1e-4), dict(tol=1e-12, maxiter=21), dict(tol=1e-12, maxiter=7),
-                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0)):
+                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0), dict(tol=1e-8 if dt == torch.float64 else 1e-4, M=jac),
+                       dict(tol=1e-12, maxiter=7, M=jac), dict(tol=1e-6, x0=x0, M=jac)):
                 out = []
                 for env in variants:
                     for key in keys:
