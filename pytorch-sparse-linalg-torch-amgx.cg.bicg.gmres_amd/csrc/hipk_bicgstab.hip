@@ -291,7 +291,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_xupdate_kernel(
 }
 
 // =====================================================================================================================
-// Small systems (<= 8 reduction chunks, rows of <= 12 entries, M = identity): THE WHOLE BiCGStab LOOP IN ONE LAUNCH -- the scheme
+// Small systems (<= 32 reduction chunks, rows of <= 12 entries; M = identity or Jacobi): THE WHOLE BiCGStab LOOP IN ONE LAUNCH -- the scheme
 // of hipk_cg_solve_lds_kernel (csrc/hipk_cg.hip) with three hand-offs per iteration instead of five launches:
 //   K1 (tests, beta, p) | K2 q = A p by TILE rows, wavefront sums of rhat .* q            -> hand-off: tile sums + q
 //   K3 (alpha test, s, <s,s> sub-partial) | K4 t = A s by tile rows, sums of s .* t, t .* t -> hand-off: tile sums + t + <s,s>
@@ -308,6 +308,7 @@ struct hipk_bi_lds_args {
     const T *val;
     T *x, *r, *p, *q, *t;
     const T *rhat;
+    const T *dinv;                  // PRE: Jacobi preconditioning, M = diag(dinv) applied BEFORE A (TSL:908, 922)
     hipk_bi_scal *scal;
     double *tsum0, *tsum1, *tsum2;  // [ntiles * 4] wavefront sums of <rhat,q>, <t,t>, <s,t> (three arrays: a fast workgroup writes
                                     // the sums of the second SpMV while a slow one still folds those of the first)
@@ -320,7 +321,7 @@ struct hipk_bi_lds_args {
 };
 static constexpr int kBiRowRegs = 12;
 
-template <typename T, bool LOCAL>
+template <typename T, bool LOCAL, bool PRE>
 __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk_bi_lds_args<T> a) {
     constexpr int VEC = hipk_vec<T>::VEC;
     constexpr double EPS = hipk_eps<T>::v;
@@ -372,6 +373,14 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
         qc[j] = (j < len) ? a.q[cc] : (T)0;
     }
     const T h_t = tlive ? a.rhat[trow] : (T)0;
+    T d_own = (T)1, dc[kBiRowRegs];   // PRE: the diagonal of M at the own row and at the tile row's columns
+#pragma unroll
+    for (int j = 0; j < kBiRowRegs; ++j) dc[j] = (T)1;
+    if (PRE) {
+        d_own = live ? a.dinv[row] : (T)0;
+#pragma unroll
+        for (int j = 0; j < kBiRowRegs; ++j) dc[j] = (j < len) ? a.dinv[a.col[lo + j]] : (T)0;
+    }
     int wmax = len < kBiRowRegs ? len : kBiRowRegs;
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(wmax, off);
@@ -485,7 +494,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
 #pragma unroll
             for (int j = 0; j < kBiRowRegs; ++j)
                 if (j < wmax) {
-                    const T pr = vj[j] * pc[j];
+                    const T pin = PRE ? dc[j] * pc[j] : pc[j];   // phat = M p (TSL:908)
+                    const T pr = vj[j] * pin;
                     acc_row = (j < len) ? acc_row + pr : acc_row;
                 }
             q_t = tlive ? acc_row : (T)0;
@@ -539,7 +549,8 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
                 if (j < wmax) {
                     const T m = al * qc[j];
                     const T sc = rc[j] - m;
-                    const T pr = vj[j] * sc;
+                    const T sin = PRE ? dc[j] * sc : sc;         // shat = M s (TSL:922)
+                    const T pr = vj[j] * sin;
                     acc_row = (j < len) ? acc_row + pr : acc_row;
                 }
             const T t_t = tlive ? acc_row : (T)0;
@@ -579,13 +590,14 @@ __global__ __launch_bounds__(HIPK_THREADS, 2) void hipk_bi_solve_lds_kernel(hipk
             break;
         }
         const T omn = (T)omega_new;
+        const T ph_own = PRE ? d_own * p_own : p_own, sh_own = PRE ? d_own * s_own : s_own;   // x advances with phat, shat (TSL:942)
         if (exit_early) {  // TSL:942-950 with exit_early true
-            const T m0 = al * p_own;
+            const T m0 = al * ph_own;
             x_own = x_own + m0;
             r_own = s_own;
         } else {
-            const T m0 = al * p_own;
-            const T m1 = omn * s_own;
+            const T m0 = al * ph_own;
+            const T m1 = omn * sh_own;
             const T m2 = m0 + m1;
             x_own = x_own + m2;
             const T m3 = omn * t_own;
@@ -748,7 +760,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
     // up to 64 workgroups (8 chunks) on ONE XCD; up to 32 chunks (n <= 65536) spread over the chip, two workgroups per compute unit
     const bool lds_spread = kGmSub * gm.g > 64;
-    bool lds_loop = gm.g <= 32 && !getenv("HIPK_BICGSTAB_NO_SMALL") && !PRE && !ext && gm.ch == HIPK_BASE_CHUNK &&
+    bool lds_loop = gm.g <= 32 && !getenv("HIPK_BICGSTAB_NO_SMALL") && !ext && gm.ch == HIPK_BASE_CHUNK &&
                     A->max_row_len <= kBiRowRegs && prm->profile == 0 && maxiter > 0 &&
                     kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_loop_failed &&
                     !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
@@ -767,6 +779,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         ca.q = q;
         ca.t = t;
         ca.rhat = rhat;
+        ca.dinv = dinv;
         ca.scal = scal;
         ca.tsum0 = A->tile_part;
         ca.tsum1 = A->tile_part + 4 * (size_t)nt;
@@ -789,9 +802,9 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 3 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
             if (local)
-                hipk_bi_solve_lds_kernel<T, true><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_bi_solve_lds_kernel<T, true, PRE><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             else
-                hipk_bi_solve_lds_kernel<T, false><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
+                hipk_bi_solve_lds_kernel<T, false, PRE><<<lgrid, HIPK_THREADS, 0, stream>>>(ca);
             HIPK_CHECK_HIP(hipGetLastError());
             HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
             HIPK_CHECK_HIP(hipStreamSynchronize(stream));

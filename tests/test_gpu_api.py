@@ -588,7 +588,7 @@ def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
     same bits, same counts and the same breakdown codes -- ragged tails, one to eight chunks, x0, maxiter cut-offs inside and on
     the boundary of a launch's iteration budget, the early exit, agent-scope hand-offs, fp32 storage."""
     import torch
-    from pytorch_sparse_solver.module_a import bicgstab, get_last_stats
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, get_last_stats
     from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_ldc_pressure_csr, create_poisson_2d_csr,
                                                           create_variable_diffusion_2d_csr)
     dev = "cuda:0"
@@ -610,8 +610,10 @@ def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
             g = torch.Generator(device=dev).manual_seed(n)
             b = torch.randn(n, dtype=dt, device=dev, generator=g)
             x0 = torch.randn(n, dtype=dt, device=dev, generator=g)
+            jac = JacobiPreconditioner(Ad)   # M = diag(A)^-1 before A (TSL:908, 922): hipk_bi_solve_lds_kernel<.., PRE>
             for kw in (dict(tol=1e-8 if dt == torch.float64 else 1e-4), dict(tol=1e-12, maxiter=15), dict(tol=1e-12, maxiter=5),
-                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0)):
+                       dict(tol=1e-6, x0=x0), dict(tol=1e-30, maxiter=0), dict(tol=1e-8 if dt == torch.float64 else 1e-4, M=jac),
+                       dict(tol=1e-12, maxiter=5, M=jac), dict(tol=1e-6, x0=x0, M=jac)):
                 out = []
                 for env in variants:
                     for key in keys:
