@@ -112,7 +112,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_kernel(
     if (threadIdx.x == 0) part_rr[c] = acc;
 }
 
-template <typename T, bool SMALL = false, bool NT = false>
+// NOX: p only -- the row-partitioned solver with the x update on a side stream (hipk_cg_xupdate_kernel).  A compile-time switch:
+// as a run-time branch it cost the hot instantiation its 8 workgroups per CU (74 VGPRs: 22.6 -> 25.4 us at N = 4 M).
+template <typename T, bool SMALL = false, bool NT = false, bool NOX = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     int64_t n, int ch, int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
     const double *__restrict__ part_pAp, const double *__restrict__ part_rr, const T *__restrict__ r,
@@ -134,8 +136,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
-    if (x == nullptr) {
-        // row-partitioned solver with the x update on a side stream (hipk_cg_xupdate_kernel, overlapping the collective): p only
+    if (NOX) {
         pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
             constexpr int VEC = hipk_vec<T>::VEC;
             T pv[VEC];
@@ -760,16 +761,22 @@ extern "C" int hipk_cg_direction(int64_t n_local, int chunk_rows, int g_red, voi
     if (rc != HIPK_OK) return rc;
     HIPK_REQUIRE(scal_dev && part_pAp && part_rr && r && p, HIPK_ERR_ARG, "null argument");   // x == NULL: p only (see hipk_cg_xupdate)
     const int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
-    if (dtype == HIPK_F64)
+    if (dtype == HIPK_F64 && x)
         hipk_cg_direction_kernel<double><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
                                                                              (hipk_cg_scal *)scal_dev, it, maxiter,
                                                                              part_pAp, part_rr, (const double *)r,
                                                                              (double *)p, (double *)x);
-    else
+    else if (dtype == HIPK_F64)
+        hipk_cg_direction_kernel<double, false, false, true><<<grid, HIPK_THREADS, 0, stream>>>(
+            n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev, it, maxiter, part_pAp, part_rr, (const double *)r, (double *)p, nullptr);
+    else if (x)
         hipk_cg_direction_kernel<float><<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red,
                                                                             (hipk_cg_scal *)scal_dev, it, maxiter,
                                                                             part_pAp, part_rr, (const float *)r,
                                                                             (float *)p, (float *)x);
+    else
+        hipk_cg_direction_kernel<float, false, false, true><<<grid, HIPK_THREADS, 0, stream>>>(
+            n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev, it, maxiter, part_pAp, part_rr, (const float *)r, (float *)p, nullptr);
     HIPK_CHECK_HIP(hipGetLastError());
     return HIPK_OK;
 }
