@@ -291,7 +291,7 @@ def main():
                  "bytes this format streams: code planes + x + y" if coded else "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
                 ("cg_update", 2, f"hipk_cg_update_kernel<double,false,{nt_streams}> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
                  "read Ap, r; write r = 24 n"),
-                ("cg_direction", 3, f"hipk_cg_direction_kernel<double,false,{nt_streams}> (x += alpha p, p = r + beta p)", 5 * n * sv,
+                ("cg_direction", 3, f"hipk_cg_direction_kernel<double,false,{nt_streams},false> (x += alpha p, p = r + beta p)", 5 * n * sv,
                  "read r, p, x; write p, x = 40 n")]
         kernels = []
         for key, which, name, nbytes, what in legs:
