@@ -325,6 +325,14 @@ int hipk_dist_cg_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const hip
                        void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
                        hipk_stream_t stream);
 
+/* Row-partitioned BiCGStab (TSL:859-964 via `_isolve`): the same conventions and the same plan / collective structs; x_ext carries
+ * x0 / the solution in its first n_local entries.  Bit for bit the iterates, counts and breakdown codes of hipk_bicgstab_solve on
+ * the whole system.  Five collective launches per iteration (the all-gathers of the six dots' partials, the halos of p and s). */
+size_t hipk_dist_bicgstab_work_bytes(const hipk_dist_plan *plan);
+int hipk_dist_bicgstab_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const hipk_rccl *coll, const void *b_local,
+                             void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
+                             hipk_stream_t stream);
+
 /* ---- EXPERIMENTAL peer-to-peer exchange provider for the loop above (csrc/hipk_p2p.hip) ---------------------------------
  * Each rank owns a device mailbox that every peer maps through HIP IPC; an all-gather is ONE small kernel per rank (publish
  * blocks store into the peers' mailboxes, collect blocks wait on per-source sequence flags).  No reference counterpart.

@@ -442,7 +442,7 @@ def native_loop_ok(prob: DistProblem) -> bool:
             and part.per * (part.world - 1) < part.g and part.n_local > 0)
 
 
-def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every):
+def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every, solver: str = "cg"):
     """One call into libhipk.so runs the whole loop of this rank (csrc/hipk_dist.hip): the host enqueues fixed batches
     of iterations and reads the device stop word one batch late -- no Python between the kernels."""
     import os
@@ -471,7 +471,9 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     x = prob.ops.zeros(n_ext)
     if x0_local is not None:
         x[:n] = x0_local
-    wb = int(L.hipk_dist_cg_work_bytes(ctypes.byref(plan)))
+    work_bytes_fn, solve_fn = {"cg": (L.hipk_dist_cg_work_bytes, L.hipk_dist_cg_solve),
+                               "bicgstab": (L.hipk_dist_bicgstab_work_bytes, L.hipk_dist_bicgstab_solve)}[solver]
+    wb = int(work_bytes_fn(ctypes.byref(plan)))
     work = torch.empty(wb, dtype=torch.uint8, device=dev)
     prm = _hipk.Params()
     prm.tol, prm.atol = float(tol), float(atol)
@@ -479,14 +481,24 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     prm.check_every = int(check_every)
     st = _hipk.Stats()
     with torch.cuda.device(dev):
-        rcode = L.hipk_dist_cg_solve(prob.A["h"], ctypes.byref(plan), ctypes.byref(coll), prob.b.data_ptr(), x.data_ptr(),
-                                     work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st),
-                                     torch.cuda.current_stream(dev).cuda_stream)
-    _hipk._check(rcode, "hipk_dist_cg_solve")
+        rcode = solve_fn(prob.A["h"], ctypes.byref(plan), ctypes.byref(coll), prob.b.data_ptr(), x.data_ptr(),
+                         work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st),
+                         torch.cuda.current_stream(dev).cuda_stream)
+    _hipk._check(rcode, f"hipk_dist_{solver}_solve")
     if getattr(prob, "p2p", None) is not None and prob.p2p.failed():
         raise RuntimeError("hipk_p2p: a rank never published its part of an exchange (wait bound hit); results discarded")
     return x[:n], int(st.info), DistStats(int(st.iterations), int(st.matvecs), int(st.info), st.b_norm, st.residual_norm,
                                           st.x_norm, st.threshold)
+
+
+def dist_bicgstab(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,
+                  maxiter: Optional[int] = None, check_every: int = 16):
+    """Row-partitioned BiCGStab (`hipk_dist_bicgstab_solve`): returns (x_local, info, DistStats); bit for bit the iterates of the
+    single-device `bicgstab`.  Only the C-driven loop exists (HIP kernels + a collective struct: direct RCCL, the mailboxes, or a
+    test's stand-ins) -- there is no backend-agnostic Python form of this solver."""
+    if not native_loop_ok(prob):
+        raise RuntimeError("dist_bicgstab needs the C-driven loop: HIP kernels, a collective provider and rows on every rank")
+    return _dist_cg_native(prob, x0_local, tol, atol, maxiter, check_every, solver="bicgstab")
 
 
 def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,

@@ -12,12 +12,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-sparse-linalg-torch-amgx.cg.bi
 
 from dist_cpu_ops import OracleOps  # noqa: E402
 from oracle import oracle as O  # noqa: E402
-from pytorch_sparse_solver.distributed import DistProblem, RowPartition, dist_cg  # noqa: E402
-from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr  # noqa: E402
+from pytorch_sparse_solver.distributed import DistProblem, RowPartition, dist_bicgstab, dist_cg  # noqa: E402
+from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr  # noqa: E402
 
 
 def build_global(kind, nx, ny):
-    A = create_poisson_2d_csr(nx, ny)
+    A = create_convdiff_2d_csr(nx, ny) if kind == "convdiff" else create_poisson_2d_csr(nx, ny)
     n = nx * ny
     if kind == "random_spd":
         # add symmetric long-range couplings (ghosts from several owners), keep diagonal dominance
@@ -202,12 +202,15 @@ def main():
     if native:
         from pytorch_sparse_solver.distributed import native_loop_ok
         assert native_loop_ok(prob), "the C-driven loop was expected to run"
-    x_loc, info, st = dist_cg(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
+    solver = sys.argv[8] if len(sys.argv) > 8 else "cg"
+    solve = dist_bicgstab if solver == "bicgstab" else dist_cg
+    x_loc, info, st = solve(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
     pieces = [None] * world
     dist.all_gather_object(pieces, (part.row0, x_loc.cpu().numpy().copy(), info, st.iterations, st.residual_norm))
     if rank == 0:
         x = np.concatenate([p[1] for p in sorted(pieces, key=lambda q: q[0])])
-        ref = O.cg(crow.numpy(), col.numpy(), val.numpy(), b.numpy(), tol=tol, maxiter=None if maxiter < 0 else maxiter)
+        ref = (O.bicgstab if solver == "bicgstab" else O.cg)(crow.numpy(), col.numpy(), val.numpy(), b.numpy(), tol=tol,
+                                                              maxiter=None if maxiter < 0 else maxiter)
         res = {"bitwise_equal": bool(np.array_equal(x, ref.x)), "info": [p[2] for p in pieces], "ref_info": ref.info,
                "iterations": [p[3] for p in pieces], "ref_iterations": ref.iterations,
                "residual_norm": [p[4] for p in pieces], "ref_residual_norm": ref.residual_norm,

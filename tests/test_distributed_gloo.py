@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu"):
+def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu", solver="cg"):
     out = str(tmp_path / f"res_{world}_{kind}.json")
     port = _free_port()
     procs = []
@@ -27,7 +27,7 @@ def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu"):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), kind, str(nx), str(ny),
-                                       str(tol), str(maxiter), out, mode], env=env, stdout=subprocess.PIPE,
+                                       str(tol), str(maxiter), out, mode, solver], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -109,6 +109,22 @@ def test_dist_cg_c_driven_loop_device_mailboxes(world, kind, nx, ny, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny,mode,maxiter", [(2, "convdiff", 96, 64, "native", -1), (3, "convdiff", 96, 64, "native_ag", -1),
+                                                           (2, "random_spd", 80, 77, "native", -1), (2, "convdiff", 4, 8000, "native", -1),
+                                                           (2, "convdiff", 96, 64, "native_p2p", -1), (2, "convdiff", 96, 64, "native", 9)])
+def test_dist_bicgstab_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, mode, maxiter, tmp_path):
+    """hipk_dist_bicgstab_solve (row-partitioned BiCGStab, the loop of a rank in C: five collective launches per iteration) under a
+    multi-rank partition sharing cuda:0 -- host-staged stand-ins for the collectives (both halo forms) or the device mailboxes.
+    Bitwise equal to the single-rank oracle solve: x, iteration count, info, true residual."""
+    r = _run(world, kind, nx, ny, 1e-8, maxiter, tmp_path, mode=mode, solver="bicgstab")
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {r["ref_info"]} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+    if maxiter > 0:
+        assert set(r["iterations"]) == {maxiter}
+
+
+@pytest.mark.gpu
 def test_dist_cg_c_driven_loop_maxiter_cutoff(tmp_path):
     r = _run(2, "poisson", 96, 64, 1e-12, 9, tmp_path, mode="native")
     assert r["bitwise_equal"] and set(r["iterations"]) == {9} and set(r["info"]) == {-1} and r["ref_info"] == -1
@@ -121,8 +137,8 @@ def test_dist_cg_nccl_world1_equals_single_gpu(tmp_path):
     code = r'''
 import os, sys, json, torch, torch.distributed as dist
 sys.path[:0] = [%r, %r]
-from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
-from pytorch_sparse_solver.module_a import cg, get_last_stats
+from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_bicgstab, dist_cg
+from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 prob = DistPoissonProblem(nx_per_rank=96, ny=64, rank=0, world=1, device=torch.device("cuda", 0))
@@ -136,8 +152,12 @@ x, info, st = dist_cg(prob, tol=1e-8)
 A = create_poisson_2d_csr(96, 64, device="cuda:0")
 xr, info_r = cg(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8)
 s = get_last_stats()
+xb, info_b, stb = dist_bicgstab(prob, tol=1e-8)          # the row-partitioned BiCGStab through real RCCL calls
+xbr, info_br = bicgstab(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8)
+sb = get_last_stats()
 print(json.dumps({"equal": bool(torch.equal(x, xr)), "info": info, "info_r": info_r, "it": st.iterations, "it_r": s.iterations,
-                  "res": st.residual_norm, "res_r": s.residual_norm}))
+                  "res": st.residual_norm, "res_r": s.residual_norm,
+                  "bi_equal": bool(torch.equal(xb, xbr)), "bi_info": [info_b, info_br], "bi_it": [stb.iterations, sb.iterations]}))
 dist.destroy_process_group()
 ''' % (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
@@ -145,3 +165,4 @@ dist.destroy_process_group()
     assert p.returncode == 0, p.stdout + p.stderr
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["equal"] and r["info"] == r["info_r"] == 0 and r["it"] == r["it_r"] and r["res"] == r["res_r"], r
+    assert r["bi_equal"] and r["bi_info"] == [0, 0] and r["bi_it"][0] == r["bi_it"][1], r
