@@ -333,6 +333,14 @@ int hipk_dist_bicgstab_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, con
                              void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
                              hipk_stream_t stream);
 
+/* Row-partitioned GMRES (TSL:641-803; params.restart <= 31, params.gmres_method, params.gpu_tolerances as hipk_gmres_solve): the
+ * kernels of the large-system path with in-place all-gathers of their chunk partials and the halo of v_k before each SpMV; bit for
+ * bit the iterates, cycle and operator-application counts of hipk_gmres_solve on the whole system.  per * world <= 2048. */
+size_t hipk_dist_gmres_work_bytes(const hipk_dist_plan *plan, int restart);
+int hipk_dist_gmres_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const hipk_rccl *coll, const void *b_local,
+                          void *x_ext, void *work, size_t work_bytes, const hipk_params *prm, hipk_stats *st,
+                          hipk_stream_t stream);
+
 /* ---- EXPERIMENTAL peer-to-peer exchange provider for the loop above (csrc/hipk_p2p.hip) ---------------------------------
  * Each rank owns a device mailbox that every peer maps through HIP IPC; an all-gather is ONE small kernel per rank (publish
  * blocks store into the peers' mailboxes, collect blocks wait on per-source sequence flags).  No reference counterpart.

@@ -2374,3 +2374,240 @@ extern "C" int hipk_pgmres_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user,
     return hipk_gmres_solve_t<float>(A, nullptr, (const float *)b, (float *)x, (char *)work, prm, st, (hipStream_t)stream, M,
                                      user);
 }
+
+
+// =====================================================================================================================
+// Row-partitioned GMRES, the loop of one rank in C (new against the reference, which is single-device).  The algorithm is `gmres`
+// (TSL:641-803: `_gmres_batched` / `_gmres_incremental`) on the kernels of the large-system path above; each of them folds the
+// chunk partials of ALL ranks, so the iterates, H, the cycle and operator-application counts are bitwise those of the single-GPU
+// solve for any rank count.  A rank's kernels write their chunk partials at the rank's position of the GLOBAL partial arrays and
+// the ranks complete them with in-place all-gathers; per Arnoldi step on the solver's stream:
+//   halo of v_k | SpMV, all-gather ||w||^2 | multi-dot, all-gather of its k+1 columns (one group) | h-reduce | update, all-gather ||q||^2
+//   | [CGS2 decision, second pass: the same three again -- device no-ops when not wanted, the collectives still pair up] | normalise
+// The cycle's small least-squares problem is solved by every rank's host from its own (identical) copy of H.
+// Conventions of hipk_dist_cg_solve (csrc/hipk_dist.hip): same plan / collective structs, fp64, M = identity.
+static size_t hipk_dgm_vec_bytes(const hipk_dist_plan *pl) {
+    return hipk_align_up((size_t)(pl->n_ext > 0 ? pl->n_ext : 1) * sizeof(double), 256);
+}
+extern "C" size_t hipk_dist_gmres_work_bytes(const hipk_dist_plan *plan, int restart) {
+    if (!plan || plan->world < 1 || plan->per < 1) return 0;
+    const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM ? HIPK_GM_MAXM : restart);
+    const size_t slab = (size_t)(plan->slab > 0 ? plan->slab : 1);
+    return kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) + (size_t)(m + 2) * hipk_dgm_vec_bytes(plan) +
+           hipk_align_up((size_t)(plan->n_send > 0 ? plan->n_send : 1) * 8, 256) + hipk_align_up(slab * 8, 256) +
+           hipk_align_up(slab * (size_t)plan->world * 8, 256);
+}
+
+extern "C" int hipk_dist_gmres_solve(hipk_csr_t A, const hipk_dist_plan *pl, const hipk_rccl *cc, const void *b_local, void *x_ext,
+                                     void *work_, size_t work_bytes, const hipk_params *prm, hipk_stats *st, hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(A && pl && cc && b_local && x_ext && work_ && prm && st, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(A->dtype == HIPK_F64, HIPK_ERR_UNSUPPORTED, "the row-partitioned solver is fp64");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_ARG, "restart must be in [1, 31]");
+    HIPK_REQUIRE(pl->world >= 1 && pl->rank >= 0 && pl->rank < pl->world, HIPK_ERR_ARG, "rank / world");
+    HIPK_REQUIRE(pl->n_local > 0 && pl->n_local == A->n_rows && pl->n_ext >= pl->n_local, HIPK_ERR_ARG,
+                 "every rank must own rows (n_local > 0) and n_ext >= n_local");
+    HIPK_REQUIRE(pl->per >= 1 && (int64_t)pl->per * pl->world >= pl->g_red && pl->g_red >= 1 && pl->g_red <= HIPK_MAX_PARTS &&
+                     (int64_t)pl->per * pl->world <= HIPK_MAX_PARTS,
+                 HIPK_ERR_ARG, "partial-sum geometry (per * world must not exceed 2048)");
+    HIPK_REQUIRE((pl->n_local + pl->chunk_rows - 1) / pl->chunk_rows <= pl->per, HIPK_ERR_ARG, "more local chunks than `per`");
+    HIPK_REQUIRE(cc->all_gather && cc->group_start && cc->group_end && (pl->world == 1 || pl->halo_mode == 0 || (cc->send && cc->recv)),
+                 HIPK_ERR_ARG, "missing collective entry points");
+    HIPK_REQUIRE((((uintptr_t)work_) & 255u) == 0 && hipk_aligned16(x_ext) && hipk_aligned16(b_local), HIPK_ERR_ALIGN,
+                 "work must be 256-byte, x / b 16-byte aligned");
+    HIPK_REQUIRE(work_bytes >= hipk_dist_gmres_work_bytes(pl, prm->restart), HIPK_ERR_WORKSPACE, "work too small");
+    memset(st, 0, sizeof(*st));
+    typedef double T;
+    char *work = (char *)work_;
+    const int64_t n = pl->n_local, n_ext = pl->n_ext;
+    const int ch = pl->chunk_rows, G = pl->g_red, per = pl->per, W = pl->world;
+    const int gl = (int)((n + ch - 1) / ch);             // local chunks = grid of the vector kernels
+    const int c0 = pl->rank * per;                       // this rank's position in the global partial arrays
+    const int m = prm->restart;
+    const size_t vec = hipk_dgm_vec_bytes(pl);
+    const int64_t ldv = (int64_t)(vec / sizeof(T));
+    hipk_gm_scal *scal = (hipk_gm_scal *)work;
+    double *parts = (double *)(work + kGmHeader);
+    double *part_ww = parts, *part_qq = parts + HIPK_MAX_PARTS, *part_res = parts + 2 * HIPK_MAX_PARTS;
+    double *part_bb = parts + 3 * HIPK_MAX_PARTS, *part_xx = parts + 4 * HIPK_MAX_PARTS;
+    double *part_spare = parts + 5 * HIPK_MAX_PARTS;
+    double *part_md = parts + (size_t)kGmSlots * HIPK_MAX_PARTS;
+    char *vbase = work + kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double);
+    T *V = (T *)vbase;
+    T *tmp = (T *)(vbase + (size_t)(m + 1) * vec);
+    char *cbase = vbase + (size_t)(m + 2) * vec;
+    double *send_buf = (double *)cbase;
+    double *slab_loc = (double *)(cbase + hipk_align_up((size_t)(pl->n_send > 0 ? pl->n_send : 1) * 8, 256));
+    double *slab_all = (double *)((char *)slab_loc + hipk_align_up((size_t)(pl->slab > 0 ? pl->slab : 1) * 8, 256));
+    T *x = (T *)x_ext;
+    const T *b = (const T *)b_local;
+    const int incremental = (prm->gmres_method == HIPK_GMRES_INCREMENTAL) ? 1 : 0;
+    const double eps_t = HIPK_EPS64;
+    const int64_t maxiter = (prm->maxiter < 0) ? 10 * pl->n_global : prm->maxiter;  // TSL:719-721
+    const int NCCL_F64 = 8;
+    enum { MODE_DOT_YY = 2, MODE_RESID = 4 };
+
+#define HIPK_DGM_NCCL(expr, what)                                                       \
+    do {                                                                                \
+        const int _r = (expr);                                                          \
+        if (_r != 0) {                                                                  \
+            hipk_set_error("hipk_dist_gmres_solve: %s failed (ncclResult %d)", what, _r); \
+            return HIPK_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+#define HIPK_DGM_TRY(expr)              \
+    do {                                \
+        const int _rc = (expr);         \
+        if (_rc != HIPK_OK) return _rc; \
+    } while (0)
+
+    hipk_event_pair whole;
+    HIPK_CHECK_HIP(whole.create());
+    HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
+    HIPK_CHECK_HIP(hipMemsetAsync(work, 0, hipk_dist_gmres_work_bytes(pl, m), stream));
+    if (n_ext > n) HIPK_CHECK_HIP(hipMemsetAsync(x + n, 0, (size_t)(n_ext - n) * 8, stream));
+
+    // in-place all-gather of a global partial array: every rank wrote its `per` entries at arr + c0
+    auto complete = [&](double *arr) -> int {
+        HIPK_DGM_NCCL(cc->all_gather(arr + c0, arr, (size_t)per, NCCL_F64, cc->comm, stream), "all_gather(partials)");
+        return HIPK_OK;
+    };
+    bool need_pack = false;
+    for (int peer = 0; peer < W; ++peer)
+        if (pl->send_counts[peer] > 0 && !(pl->send_first && pl->send_first[peer] >= 0)) need_pack = true;
+    auto halo = [&](double *v) -> int {   // the peers' entries this rank's rows reference -> v[n .. n_ext)
+        if (W == 1 || (pl->n_send == 0 && pl->n_ghost == 0 && pl->halo_mode == 1)) return HIPK_OK;
+        if (pl->halo_mode == 1) {
+            if (pl->n_send && need_pack) HIPK_DGM_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, send_buf, HIPK_F64, stream));
+            HIPK_DGM_NCCL(cc->group_start(), "group_start");
+            size_t so = 0, ro = 0;
+            for (int peer = 0; peer < W; ++peer) {
+                const size_t ns = (size_t)pl->send_counts[peer], nr = (size_t)pl->recv_counts[peer];
+                const bool direct = pl->send_first && pl->send_first[peer] >= 0;
+                if (ns) HIPK_DGM_NCCL(cc->send(direct ? v + pl->send_first[peer] : send_buf + so, ns, NCCL_F64, peer, cc->comm, stream), "send(halo)");
+                if (nr) HIPK_DGM_NCCL(cc->recv(v + n + ro, nr, NCCL_F64, peer, cc->comm, stream), "recv(halo)");
+                so += ns;
+                ro += nr;
+            }
+            HIPK_DGM_NCCL(cc->group_end(), "group_end");
+        } else {
+            if (pl->n_send) HIPK_DGM_TRY(hipk_gather(pl->n_send, pl->send_idx_dev, v, slab_loc, HIPK_F64, stream));
+            HIPK_DGM_NCCL(cc->all_gather(slab_loc, slab_all, (size_t)pl->slab, NCCL_F64, cc->comm, stream), "all_gather(halo slabs)");
+            if (pl->n_ghost) HIPK_DGM_TRY(hipk_gather(pl->n_ghost, pl->ghost_src_dev, slab_all, v + n, HIPK_F64, stream));
+        }
+        return HIPK_OK;
+    };
+
+    // residual = b - A x0 into column 0, unit residual + norm (TSL:791-792); <b,b>
+    auto residual = [&]() -> int {
+        HIPK_DGM_TRY(halo(x));
+        HIPK_DGM_TRY(hipk_spmv_ex(A, x, V, MODE_RESID | MODE_DOT_YY, nullptr, b, part_spare + c0, part_res + c0, nullptr, 0, stream));
+        HIPK_DGM_TRY(complete(part_res));
+        hipk_gm_resnorm_kernel<T><<<gl, HIPK_THREADS, 0, stream>>>(n, ch, G, scal, V, part_res, part_bb, eps_t);
+        return hipGetLastError() == hipSuccess ? HIPK_OK : HIPK_ERR_HIP;
+    };
+    HIPK_DGM_TRY(hipk_dot_parts(n, ch, b, b, HIPK_F64, part_bb + c0, stream));
+    HIPK_DGM_TRY(complete(part_bb));
+    HIPK_DGM_TRY(residual());
+    int64_t matvecs = 1;
+    double head[2];
+    HIPK_CHECK_HIP(hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+    double res_norm = head[0];
+    const double bs = head[1];
+    const double b_norm = hipk_norm_from_sq(bs);
+    // TSL:735-753 on the GLOBAL size
+    const double eps = HIPK_EPS64;
+    const double ng = (double)pl->n_global;
+    const double cand = (prm->gpu_tolerances ? 1e-12 : 1e-14) * sqrt(ng);
+    const double adaptive = (cand > prm->tol) ? cand : (double)(float)prm->tol;
+    const double base_atol = (double)(float)(eps * (prm->gpu_tolerances ? 1000 : 100) * ng);
+    const double atol_eff = hipk_tmax(adaptive * b_norm, hipk_tmax((double)(float)prm->atol, base_atol));
+    const double ptol = b_norm * hipk_tmin(1.0, atol_eff / b_norm);
+
+    std::vector<unsigned char> hs_store(sizeof(hipk_gm_scal));
+    hipk_gm_scal *hs = (hipk_gm_scal *)hs_store.data();
+    const int nres = 5;
+    int64_t cycles = 0;
+    int happy = 0;
+    while (cycles < maxiter && res_norm > atol_eff) {
+        hipk_gm_cycle_init_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, incremental, ptol);
+        for (int k = 0; k < m; ++k) {
+            T *vk = V + (int64_t)k * ldv, *w = V + (int64_t)(k + 1) * ldv;
+            HIPK_DGM_TRY(halo(vk));
+            HIPK_DGM_TRY(hipk_spmv_ex(A, vk, w, MODE_DOT_YY, nullptr, nullptr, part_spare + c0, part_ww + c0, &scal->stop_step, k, stream));
+            HIPK_DGM_TRY(complete(part_ww));
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, G, part_qq, eps_t);
+                const int mg = gl * (k / 8 + 1);
+                hipk_gm_multidot_stream_kernel<T, 8><<<mg, HIPK_THREADS, 0, stream>>>(n, ch, scal, k, pass, V, ldv, w, part_md + c0, gl, nres);
+                if (W > 1) HIPK_DGM_NCCL(cc->group_start(), "group_start");
+                for (int j = 0; j <= k; ++j) HIPK_DGM_TRY(complete(part_md + (size_t)j * HIPK_MAX_PARTS));
+                if (W > 1) HIPK_DGM_NCCL(cc->group_end(), "group_end");
+                hipk_gm_hreduce_kernel<<<k + 1, HIPK_THREADS, 0, stream>>>(scal, k, pass, G, part_md);
+                hipk_gm_update_stream_kernel<T, HIPK_GM_LDH><<<gl, HIPK_THREADS, 0, stream>>>(n, ch, scal, k, pass, V, ldv, w, part_qq + c0, nres);
+                HIPK_DGM_TRY(complete(part_qq));
+            }
+            hipk_gm_normalize_kernel<T><<<gl, HIPK_THREADS, 0, stream>>>(n, ch, G, scal, k, w, part_qq, part_ww, eps_t, 0, 0);
+        }
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            hipk_set_error("hipk_dist_gmres_solve: HIP failure inside a restart cycle");
+            return HIPK_ERR_HIP;
+        }
+        const int k = (int)hs->steps_done;
+        matvecs += k;
+        if (hs->breakdown) happy = 1;
+        hipk_gm_y yy;
+        memset(&yy, 0, sizeof(yy));
+        if (k > 0) {
+            if (!incremental) {
+                hipk_lstsq_normal(hs->H, HIPK_GM_LDH, k, res_norm, yy.y);
+            } else {
+                for (int i = k - 1; i >= 0; --i) {  // solve_triangular, TSL:630
+                    double sacc = hs->beta_vec[i];
+                    for (int p = i + 1; p < k; ++p) sacc = fma(-hs->R[i * HIPK_GM_LDH + p], yy.y[p], sacc);
+                    yy.y[i] = sacc / hs->R[i * HIPK_GM_LDH + i];
+                }
+            }
+            hipk_gm_xupdate_kernel<T><<<gl, HIPK_THREADS, 0, stream>>>(n, ch, k, V, ldv, x, yy);
+        }
+        HIPK_DGM_TRY(residual());
+        ++matvecs;
+        if (hipMemcpyAsync(head, scal, sizeof(head), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            hipk_set_error("hipk_dist_gmres_solve: HIP failure at the end of a restart cycle");
+            return HIPK_ERR_HIP;
+        }
+        res_norm = head[0];
+        ++cycles;
+    }
+
+    // TSL:766-773
+    HIPK_DGM_TRY(halo(x));
+    HIPK_DGM_TRY(hipk_spmv_ex(A, x, tmp, MODE_RESID | MODE_DOT_YY, nullptr, b, part_spare + c0, part_res + c0, nullptr, 0, stream));
+    HIPK_DGM_TRY(complete(part_res));
+    ++matvecs;
+    HIPK_DGM_TRY(hipk_dot_parts(n, ch, x, x, HIPK_F64, part_xx + c0, stream));
+    HIPK_DGM_TRY(complete(part_xx));
+    hipk_gm_final_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, G, part_res, part_xx);
+    HIPK_CHECK_HIP(hipGetLastError());
+    double fin[4];
+    HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
+    HIPK_CHECK_HIP(hipMemcpyAsync(fin, scal, sizeof(fin), hipMemcpyDeviceToHost, stream));
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+    st->iterations = cycles;
+    st->matvecs = matvecs;
+    st->b_norm = b_norm;
+    st->residual_norm = hipk_norm_from_sq(fin[2]);
+    st->x_norm = hipk_norm_from_sq(fin[3]);
+    st->threshold = atol_eff * 10;  // TSL:769
+    st->info = (isnan(st->x_norm) || st->residual_norm > st->threshold) ? -1 : 0;
+    st->breakdown = happy;
+    st->recurrence_rs = res_norm;
+    float ms = 0.f;
+    HIPK_CHECK_HIP(hipEventElapsedTime(&ms, whole.a, whole.b));
+    st->solve_ms = ms;
+#undef HIPK_DGM_NCCL
+#undef HIPK_DGM_TRY
+    return HIPK_OK;
+}

@@ -41,6 +41,7 @@ SYMBOLS = [
     "hipk_cgm_start", "hipk_cgm_direction",
     # row-partitioned CG, the loop of one rank in C
     "hipk_dist_cg_work_bytes", "hipk_dist_cg_solve", "hipk_dist_bicgstab_work_bytes", "hipk_dist_bicgstab_solve",
+    "hipk_dist_gmres_work_bytes", "hipk_dist_gmres_solve",
     # experimental mailbox exchange provider for that loop
     "hipk_p2p_create", "hipk_p2p_export", "hipk_p2p_connect", "hipk_p2p_destroy", "hipk_p2p_error",
     "hipk_p2p_group_start", "hipk_p2p_group_end", "hipk_p2p_all_gather",
@@ -215,6 +216,10 @@ def lib():
     L.hipk_dist_bicgstab_work_bytes.restype = ctypes.c_size_t
     L.hipk_dist_bicgstab_solve.argtypes = [vp, ctypes.POINTER(DistPlan), ctypes.POINTER(Rccl), vp, vp, vp, ctypes.c_size_t,
                                            ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
+    L.hipk_dist_gmres_work_bytes.argtypes = [ctypes.POINTER(DistPlan), i32]
+    L.hipk_dist_gmres_work_bytes.restype = ctypes.c_size_t
+    L.hipk_dist_gmres_solve.argtypes = [vp, ctypes.POINTER(DistPlan), ctypes.POINTER(Rccl), vp, vp, vp, ctypes.c_size_t,
+                                        ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     L.hipk_p2p_create.argtypes = [ctypes.POINTER(vp), i32, i32, ctypes.c_size_t]
     L.hipk_p2p_export.argtypes = [vp, ctypes.c_char_p]
     L.hipk_p2p_connect.argtypes = [vp, ctypes.c_char_p]

@@ -442,7 +442,8 @@ def native_loop_ok(prob: DistProblem) -> bool:
             and part.per * (part.world - 1) < part.g and part.n_local > 0)
 
 
-def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every, solver: str = "cg"):
+def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every, solver: str = "cg", restart: int = 0,
+                    solve_method: str = "batched"):
     """One call into libhipk.so runs the whole loop of this rank (csrc/hipk_dist.hip): the host enqueues fixed batches
     of iterations and reads the device stop word one batch late -- no Python between the kernels."""
     import os
@@ -471,14 +472,22 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     x = prob.ops.zeros(n_ext)
     if x0_local is not None:
         x[:n] = x0_local
-    work_bytes_fn, solve_fn = {"cg": (L.hipk_dist_cg_work_bytes, L.hipk_dist_cg_solve),
-                               "bicgstab": (L.hipk_dist_bicgstab_work_bytes, L.hipk_dist_bicgstab_solve)}[solver]
-    wb = int(work_bytes_fn(ctypes.byref(plan)))
+    if solver == "gmres":
+        solve_fn = L.hipk_dist_gmres_solve
+        wb = int(L.hipk_dist_gmres_work_bytes(ctypes.byref(plan), int(restart)))
+    else:
+        work_bytes_fn, solve_fn = {"cg": (L.hipk_dist_cg_work_bytes, L.hipk_dist_cg_solve),
+                                   "bicgstab": (L.hipk_dist_bicgstab_work_bytes, L.hipk_dist_bicgstab_solve)}[solver]
+        wb = int(work_bytes_fn(ctypes.byref(plan)))
     work = torch.empty(wb, dtype=torch.uint8, device=dev)
     prm = _hipk.Params()
     prm.tol, prm.atol = float(tol), float(atol)
     prm.maxiter = -1 if maxiter is None else int(maxiter)
     prm.check_every = int(check_every)
+    if solver == "gmres":
+        prm.restart = int(restart)
+        prm.gmres_method = {"batched": 0, "incremental": 1}[solve_method]
+        prm.gpu_tolerances = 1          # the reference's `device.type == 'cuda'` tolerance branch (TSL:737-740)
     st = _hipk.Stats()
     with torch.cuda.device(dev):
         rcode = solve_fn(prob.A["h"], ctypes.byref(plan), ctypes.byref(coll), prob.b.data_ptr(), x.data_ptr(),
@@ -499,6 +508,19 @@ def dist_bicgstab(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *,
     if not native_loop_ok(prob):
         raise RuntimeError("dist_bicgstab needs the C-driven loop: HIP kernels, a collective provider and rows on every rank")
     return _dist_cg_native(prob, x0_local, tol, atol, maxiter, check_every, solver="bicgstab")
+
+
+def dist_gmres(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,
+               restart: int = 20, maxiter: Optional[int] = None, solve_method: str = "batched"):
+    """Row-partitioned GMRES (`hipk_dist_gmres_solve`): returns (x_local, info, DistStats with iterations = restart cycles); bit
+    for bit the iterates of the single-device `gmres` on a CUDA tensor.  C-driven loop only, restart <= 31."""
+    if not native_loop_ok(prob):
+        raise RuntimeError("dist_gmres needs the C-driven loop: HIP kernels, a collective provider and rows on every rank")
+    if solve_method not in ("batched", "incremental"):
+        raise ValueError(f"invalid solve_method {solve_method}, must be either 'batched' or 'incremental'")
+    if not 1 <= int(restart) <= 31:
+        raise ValueError("dist_gmres: restart must be in [1, 31]")
+    return _dist_cg_native(prob, x0_local, tol, atol, maxiter, 0, solver="gmres", restart=restart, solve_method=solve_method)
 
 
 def dist_cg(prob: DistProblem, x0_local: Optional[torch.Tensor] = None, *, tol: float = 1e-5, atol: float = 0.0,

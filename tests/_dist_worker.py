@@ -12,7 +12,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-sparse-linalg-torch-amgx.cg.bi
 
 from dist_cpu_ops import OracleOps  # noqa: E402
 from oracle import oracle as O  # noqa: E402
-from pytorch_sparse_solver.distributed import DistProblem, RowPartition, dist_bicgstab, dist_cg  # noqa: E402
+from pytorch_sparse_solver.distributed import DistProblem, RowPartition, dist_bicgstab, dist_cg, dist_gmres  # noqa: E402
 from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr  # noqa: E402
 
 
@@ -203,14 +203,22 @@ def main():
         from pytorch_sparse_solver.distributed import native_loop_ok
         assert native_loop_ok(prob), "the C-driven loop was expected to run"
     solver = sys.argv[8] if len(sys.argv) > 8 else "cg"
-    solve = dist_bicgstab if solver == "bicgstab" else dist_cg
-    x_loc, info, st = solve(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
+    if solver.startswith("gmres"):     # "gmres" / "gmres_incremental": restart 12, cycles capped by maxiter
+        method = "incremental" if solver.endswith("incremental") else "batched"
+        x_loc, info, st = dist_gmres(prob, tol=tol, restart=12, maxiter=None if maxiter < 0 else maxiter, solve_method=method)
+    else:
+        solve = dist_bicgstab if solver == "bicgstab" else dist_cg
+        x_loc, info, st = solve(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
     pieces = [None] * world
     dist.all_gather_object(pieces, (part.row0, x_loc.cpu().numpy().copy(), info, st.iterations, st.residual_norm))
     if rank == 0:
         x = np.concatenate([p[1] for p in sorted(pieces, key=lambda q: q[0])])
-        ref = (O.bicgstab if solver == "bicgstab" else O.cg)(crow.numpy(), col.numpy(), val.numpy(), b.numpy(), tol=tol,
-                                                              maxiter=None if maxiter < 0 else maxiter)
+        if solver.startswith("gmres"):
+            ref = O.gmres(crow.numpy(), col.numpy(), val.numpy(), b.numpy(), tol=tol, restart=12, maxiter=None if maxiter < 0 else maxiter,
+                          solve_method="incremental" if solver.endswith("incremental") else "batched", gpu_tolerances=True)
+        else:
+            ref = (O.bicgstab if solver == "bicgstab" else O.cg)(crow.numpy(), col.numpy(), val.numpy(), b.numpy(), tol=tol,
+                                                                  maxiter=None if maxiter < 0 else maxiter)
         res = {"bitwise_equal": bool(np.array_equal(x, ref.x)), "info": [p[2] for p in pieces], "ref_info": ref.info,
                "iterations": [p[3] for p in pieces], "ref_iterations": ref.iterations,
                "residual_norm": [p[4] for p in pieces], "ref_residual_norm": ref.residual_norm,

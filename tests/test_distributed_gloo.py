@@ -125,6 +125,21 @@ def test_dist_bicgstab_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny,mode,solver,maxiter", [
+    (2, "convdiff", 96, 64, "native", "gmres", -1), (3, "convdiff", 96, 64, "native_ag", "gmres", -1),
+    (2, "random_spd", 80, 77, "native", "gmres_incremental", -1), (2, "convdiff", 4, 8000, "native", "gmres", 3),
+    (2, "convdiff", 96, 64, "native_p2p", "gmres_incremental", -1)])
+def test_dist_gmres_c_driven_loop_multi_rank_on_one_gpu(world, kind, nx, ny, mode, solver, maxiter, tmp_path):
+    """hipk_dist_gmres_solve (row-partitioned GMRES(12): the large-system kernels with in-place all-gathers of their chunk partials
+    and the halo of v_k before each SpMV) under a multi-rank partition sharing cuda:0.  Bitwise equal to the single-rank oracle
+    solve: x, restart-cycle count, info, true residual."""
+    r = _run(world, kind, nx, ny, 1e-8, maxiter, tmp_path, mode=mode, solver=solver)
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {r["ref_info"]} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+
+
+@pytest.mark.gpu
 def test_dist_cg_c_driven_loop_maxiter_cutoff(tmp_path):
     r = _run(2, "poisson", 96, 64, 1e-12, 9, tmp_path, mode="native")
     assert r["bitwise_equal"] and set(r["iterations"]) == {9} and set(r["info"]) == {-1} and r["ref_info"] == -1
@@ -137,8 +152,8 @@ def test_dist_cg_nccl_world1_equals_single_gpu(tmp_path):
     code = r'''
 import os, sys, json, torch, torch.distributed as dist
 sys.path[:0] = [%r, %r]
-from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_bicgstab, dist_cg
-from pytorch_sparse_solver.module_a import bicgstab, cg, get_last_stats
+from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_bicgstab, dist_cg, dist_gmres
+from pytorch_sparse_solver.module_a import bicgstab, cg, gmres, get_last_stats
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 prob = DistPoissonProblem(nx_per_rank=96, ny=64, rank=0, world=1, device=torch.device("cuda", 0))
@@ -155,7 +170,11 @@ s = get_last_stats()
 xb, info_b, stb = dist_bicgstab(prob, tol=1e-8)          # the row-partitioned BiCGStab through real RCCL calls
 xbr, info_br = bicgstab(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8)
 sb = get_last_stats()
-print(json.dumps({"equal": bool(torch.equal(x, xr)), "info": info, "info_r": info_r, "it": st.iterations, "it_r": s.iterations,
+xg, info_g, stg = dist_gmres(prob, tol=1e-8, restart=15)   # and the row-partitioned GMRES
+xgr, info_gr = gmres(A, torch.ones(96 * 64, dtype=torch.float64, device="cuda:0"), tol=1e-8, restart=15)
+sg = get_last_stats()
+print(json.dumps({"gm_equal": bool(torch.equal(xg, xgr)), "gm_info": [info_g, info_gr], "gm_it": [stg.iterations, sg.iterations],
+                  "equal": bool(torch.equal(x, xr)), "info": info, "info_r": info_r, "it": st.iterations, "it_r": s.iterations,
                   "res": st.residual_norm, "res_r": s.residual_norm,
                   "bi_equal": bool(torch.equal(xb, xbr)), "bi_info": [info_b, info_br], "bi_it": [stb.iterations, sb.iterations]}))
 dist.destroy_process_group()
@@ -166,3 +185,4 @@ dist.destroy_process_group()
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["equal"] and r["info"] == r["info_r"] == 0 and r["it"] == r["it_r"] and r["res"] == r["res_r"], r
     assert r["bi_equal"] and r["bi_info"] == [0, 0] and r["bi_it"][0] == r["bi_it"][1], r
+    assert r["gm_equal"] and r["gm_info"][0] == r["gm_info"][1] and r["gm_it"][0] == r["gm_it"][1], r
