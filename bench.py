@@ -281,9 +281,11 @@ def main():
         path = h.path()
         fbytes = h.format_bytes()
         # the chunk-per-workgroup pair form needs chunks of <= 64 tiles; larger chunks take the persistent loop kernel
-        spmv_kernel = "hipk_spmv_sell_pair_kernel<double,5,true,1>" if nx == NX else "hipk_spmv_sell_loop_kernel<double,5,false,false,true>"
-        spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles from one word per tile, + fused <p,Ap> chunk partials)",
-                     "tile_fast": "hipk_spmv_kernel<double,1280,true> (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, path)
+        # the instantiation the CG loop's SpMV launches select (the library reports it: hipk_last_spmv_kernel)
+        in_loop(1)
+        spmv_kernel = h.last_spmv_kernel()
+        spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles two rows per lane from one word per tile, + fused <p,Ap> chunk partials)",
+                     "tile_fast": f"{spmv_kernel} (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, f"{spmv_kernel} ({path})")
         coded = path in ("coded", "offset_coded")
         # x, r, p, Ap beyond 384 MiB: the vector kernels' non-temporal instantiation (csrc/hipk_cg.hip)
         nt_streams = "true" if 4 * n * sv > 384 * 1024 * 1024 else "false"
@@ -351,7 +353,7 @@ def main():
                 _, _, pst2 = one_solve()
                 torch.cuda.synchronize()
                 pdt = time.perf_counter() - t1
-                pname = "hipk_spmv_kernel<double,1280,true>"
+                pname = h.last_spmv_kernel()
                 spmv_report["plain_csr_kernels_same_matrix"] = {
                     "path": h.path(), "kernel": pname, "in_loop_us": pus, "algorithmic_bytes_per_launch": spmv_bytes,
                     "GBps": spmv_bytes / pus / 1e3,

@@ -120,6 +120,10 @@ int64_t hipk_csr_spmv_bytes(hipk_csr_t h);
 enum hipk_spmv_path { HIPK_PATH_TILE_FAST = 0, HIPK_PATH_TILE = 1, HIPK_PATH_ROWWAVE = 2, HIPK_PATH_CODED = 3,
                       HIPK_PATH_OFFSET_CODED = 4 };
 int hipk_csr_spmv_path(hipk_csr_t h);
+/* Name of the kernel instantiation the calling thread's most recent SpMV launch selected (stand-alone or inside a solver),
+ * as the profiler prints it, e.g. "hipk_spmv_sell_wide_kernel<5,1>"; "" before the first launch.  Measurement scripts label
+ * their per-kernel figures with it instead of guessing the dispatch. */
+const char *hipk_last_spmv_kernel(void);
 /* mode 0: automatic (default); 1: never use the coded forms (A/B measurements, parity tests).
  * Environment: HIPK_SPMV_CODED=0 at creation time skips building the coded forms altogether,
  * HIPK_SPMV_OFFSET_CODED=0 only the offset-coded one. */

@@ -21,6 +21,9 @@ void hipk_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *hipk_last_error(void) { return g_err; }
+static thread_local char g_spmv_kernel[96] = "";
+extern "C" const char *hipk_last_spmv_kernel(void) { return g_spmv_kernel; }
+#define HIPK_NOTE_KERNEL(...) snprintf(g_spmv_kernel, sizeof(g_spmv_kernel), __VA_ARGS__)
 extern "C" int hipk_version(void) { return HIPK_VERSION; }
 
 extern "C" int hipk_device_count(void) {
@@ -499,6 +502,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             hipk_spmv_rowwave_kernel<float><<<hgrid, HIPK_THREADS, 0, stream>>>(ah);
     }
     if (rowwave) {
+        HIPK_NOTE_KERNEL("hipk_spmv_rowwave_kernel<%s>", h->dtype == HIPK_F64 ? "double" : "float");
         const int rgrid = (int)((a.n + 3) / 4);
         if (prof) prof->before(stream);
         if (h->dtype == HIPK_F64)
@@ -546,6 +550,10 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
 #define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
 #define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
             kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
+            const char *tname = h->dtype == HIPK_F64 ? "double" : "float";
+            const int uw = (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8) ? h->sell_w : 0;
+            const char *uni = h->tile_ucode ? "true" : "false", *vls = h->coded_layout == 3 ? "true" : "false";
+            HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,false,%s,%s>", tname, uw, vls, uni);
             int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
             const int slots = h->n_cu * occ;
@@ -556,6 +564,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (chunked) {
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
                 lgrid = hipk_xcd_grid(a.g);
+                HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>", tname, uw, vls, uni);
+                char pname[96];
                 // pair codes with an exact tile size: two tiles per loop trip (hipk_spmv_sell_pair_kernel)
                 static const bool no_pair = getenv("HIPK_SPMV_SELL_NO_PAIR") != nullptr;
                 if (!no_pair && h->coded_layout == 2 && (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8)) {
@@ -563,8 +573,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
 #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
                     void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+                    int pmode = -1;
                     // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
                     static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
+                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && (a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode)
+                        pmode = a.mode;
                     if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !no_mode)
                         pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
@@ -572,10 +585,25 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_YY && !no_mode)
                         pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
+                    snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
+                    // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel): fp64, most tiles uniform
+                    static const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;
+                    if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles) {
+#define HIPK_PICK_WIDE(M) \
+    (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M> : hipk_spmv_sell_wide_kernel<4, M>)
+                        pk = HIPK_PICK_WIDE(-1);
+                        if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
+                        if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
+                        snprintf(pname, sizeof(pname), "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
+                                 ((a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode) ? a.mode : -1);
+#undef HIPK_PICK_WIDE
+                    }
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
-                        (pocc * h->n_cu >= a.g || pocc >= occ))
+                        (pocc * h->n_cu >= a.g || pocc >= occ)) {
                         kern = pk;
+                        HIPK_NOTE_KERNEL("%s", pname);
+                    }
 #undef HIPK_PICK_PAIR
 #undef HIPK_PICK_PAIR_U
                 }
@@ -599,6 +627,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             return HIPK_OK;
         }
         if (prof) prof->before(stream);
+        HIPK_NOTE_KERNEL("hipk_spmv_coded_kernel<%s,1>", h->dtype == HIPK_F64 ? "double" : "float");
 #define HIPK_LAUNCH_CODED(T, RR) hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a)
         if (h->dtype == HIPK_F64)
             HIPK_LAUNCH_CODED(double, 1);
@@ -615,6 +644,12 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         return HIPK_OK;
     }
     if (prof) prof->before(stream);
+    {
+        const bool f64 = h->dtype == HIPK_F64, shortrows = h->max_row_len <= HIPK_LONG_ROW;
+        const int cap = (f64 && h->max_tile_nnz <= 1280 && shortrows) ? 1280 : (h->max_tile_nnz <= 2048 && shortrows) ? 2048 : f64 ? 1280 : 2048;
+        HIPK_NOTE_KERNEL("hipk_spmv_kernel<%s,%d,%s>", f64 ? "double" : "float", cap,
+                         (h->max_tile_nnz <= cap && shortrows) ? "true" : "false");
+    }
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)
             hipk_spmv_kernel<double, 1280, true><<<grid, HIPK_THREADS, 0, stream>>>(a);

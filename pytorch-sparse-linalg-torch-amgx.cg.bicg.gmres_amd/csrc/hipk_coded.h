@@ -873,4 +873,240 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_
         }
     }
 }
+// ------------------------------------------------------------------ uniform tiles TWO ROWS PER LANE (16-byte accesses)
+// tools/ubench/stencil_probe.hip took the kernels above apart on the N = 4 M 5-point matrix: a stencil kernel with NO per-lane
+// decode at all (offsets and values in scalar registers, ~40 vector instructions per tile) runs no faster than the coded kernel
+// (18.0 vs 18.4 us), the number of tiles in flight per trip does not matter (1, 2, 4, 8: 17.6-18.3 us), but every 8-byte-per-lane
+// load instruction costs: 1 / 3 / 5 / 6 loads per row = 12.3 / 13.6 / 15.3 / 18.0 us, while the same five loads as 16-byte
+// accesses (two adjacent rows per lane) cost 12.3 us -- what a plain copy of x to y costs in this launch shape.  The bound is the
+// count of vector-memory instructions, not bytes, latency or vector ALU work.
+// So: a UNIFORM tile (all 256 rows carry the same codes, `tile_ucode`) is taken by two wavefronts, each lane forming rows 2l and
+// 2l + 1 of its wavefront's 128 rows from 16-byte loads at `x + offset_k` (the offset and value of code k live in scalar registers,
+// fetched once per change of `ucode`); the other tiles (grid-line ends: about one in eight) take the per-lane path above, whole
+// workgroup, first.  Wavefront pair p walks the uniform tiles of parity p of the chunk.  Same products, same additions in the same
+// order per row; the fused dots' 64-row sums follow the spec's tree with the rows laid out two per lane (strides 32 ... 2 are lane
+// shifts by 16 ... 1 on both components, stride 1 is x + y): same bits.  fp64, pair codes, chunk per workgroup.
+__device__ __forceinline__ double hipk_half_tree2(double2 d) {  // sums of rows 0..63 / 64..127 of a wavefront: lanes 0 / 32
+    d.x = d.x + hipk_lane_up16(d.x);
+    d.y = d.y + hipk_lane_up16(d.y);
+    d.x = d.x + hipk_row_shl<8>(d.x);
+    d.y = d.y + hipk_row_shl<8>(d.y);
+    d.x = d.x + hipk_row_shl<4>(d.x);
+    d.y = d.y + hipk_row_shl<4>(d.y);
+    d.x = d.x + hipk_row_shl<2>(d.x);
+    d.y = d.y + hipk_row_shl<2>(d.y);
+    d.x = d.x + hipk_row_shl<1>(d.x);
+    d.y = d.y + hipk_row_shl<1>(d.y);
+    return d.x + d.y;
+}
+
+template <int UNITS, int MODE = -1>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
+    typedef double T;
+    constexpr int G0 = (UNITS + 3) / 4;
+    constexpr int NE = UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8);
+    static_assert(UNITS == 4 || UNITS == 5 || UNITS == 8, "exact tile sizes only");
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tpc = a.ch / HIPK_TILE;
+    const int chunk = hipk_xcd_chunk(blockIdx.x, a.g);
+    if (chunk < 0) return;
+    const int t_first = chunk * tpc;
+    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;
+    __shared__ double wsum0[HIPK_SELL_MAX_TPC * 4];
+    __shared__ double wsum1[HIPK_SELL_MAX_TPC * 4];
+    __shared__ T dval[HIPK_CODED_MAX];
+    __shared__ int doff[HIPK_CODED_MAX];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned char *__restrict__ code = a.code;
+    const char *__restrict__ xb = (const char *)a.x;
+    T *__restrict__ y = (T *)a.y;
+    const int mode = MODE >= 0 ? MODE : a.mode;
+    const int n32 = (int)a.n;
+    const unsigned long long *__restrict__ ucode = a.tile_ucode;
+    const int *__restrict__ g_doff = a.dict_off;
+    const T *__restrict__ g_dval = (const T *)a.dict_val;
+
+    unsigned long long uc_mine = 0ull;  // requested first: complete before the dictionary reaches LDS (loads return in order)
+    if (lane < t_end - t_first) uc_mine = ucode[t_first + lane];
+    T dv = (T)0;
+    int dofs = 0;
+    if (t < a.n_codes) {
+        dv = g_dval[t];
+        dofs = g_doff[t];
+    }
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
+    doff[t] = dofs;
+    __syncthreads();
+
+    // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's, a tile's word is read into scalar registers
+    // with v_readlane (no memory round trip per tile)
+    auto tile_ucode_of = [&](int tl) -> unsigned long long {
+        const int i = tl - t_first;
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)uc_mine, i) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(uc_mine >> 32), i) << 32);
+    };
+
+    // ---- the tiles whose rows differ: one row per lane, codes from the planes (as hipk_spmv_sell_pair_kernel, one tile per trip)
+    for (int tl = t_first; tl < t_end; ++tl) {
+        if (tile_ucode_of(tl) != 0ull) continue;
+        unsigned c[G0];
+        {
+            const unsigned char *tp = code + (size_t)tl * (UNITS * HIPK_TILE);
+            constexpr int D = UNITS >> 2, Bp = UNITS & 3;
+#pragma unroll
+            for (int g = 0; g < G0; ++g) {
+                unsigned wv = 0xFFFFFFFFu;
+                if (g < D) {
+                    wv = ((const unsigned *)tp)[g * HIPK_TILE + t];
+                } else {
+                    const unsigned char *bp = tp + (size_t)D * 1024 + t;
+                    if (Bp >= 1) wv = (wv & 0xFFFFFF00u) | bp[0];
+                    if (Bp >= 2) wv = (wv & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
+                }
+                c[g] = wv;
+            }
+        }
+        const int row = tl * HIPK_TILE + t;
+        const int rowx = row < n32 ? row : n32 - 1;
+        T xv[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const unsigned bo = (unsigned)(rowx + doff[ck]) * (unsigned)sizeof(T);
+            xv[k] = *(const T *)(xb + bo);
+        }
+        T ow = (T)0, ob = (T)0, od = (T)0;
+        if (row < n32) {
+            if (mode & HIPK_SPMV_DOT_W) ow = ((const T *)a.w)[row];
+            if (mode & HIPK_SPMV_RESID) ob = ((const T *)a.bsub)[row];
+            if (mode & HIPK_SPMV_SCALE) od = ((const T *)a.dscale)[row];
+        }
+        T s = (T)0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (c[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const T p = dval[ck] * xv[k];
+            const T s1 = s + p;
+            s = (ck != HIPK_SELL_PAD) ? s1 : s;
+        }
+        double d0 = 0.0, d1 = 0.0;
+        if (row < n32) {
+            T out = s;
+            if (mode & HIPK_SPMV_RESID) out = ob - out;
+            if (mode & HIPK_SPMV_SCALE) out = od * out;
+            y[row] = out;
+            if (mode & HIPK_SPMV_DOT_W) d0 = (double)ow * (double)out;
+            if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+        }
+        const int slot = (tl - t_first) * 4 + wave;
+        if (mode & HIPK_SPMV_DOT_W) {
+            d0 = hipk_wave_sum(d0);
+            if (lane == 0) wsum0[slot] = d0;
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+            d1 = hipk_wave_sum(d1);
+            if (lane == 0) wsum1[slot] = d1;
+        }
+    }
+
+    // ---- the uniform tiles of this wavefront pair's parity: two rows per lane
+    {
+        const int wp = wave >> 1, wh = wave & 1;
+        unsigned long long cur = 0ull;
+        const bool w_is_x = (mode & HIPK_SPMV_DOT_W) && a.w == a.x;  // <x, A x> (the CG loop): w is the diagonal entry's operand
+        int kc = -1;        // entry with offset 0, if any
+        long long sbo[NE];  // byte offset of entry k (scalar)
+        T sv[NE];           // its value (scalar)
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            sbo[k] = 0;
+            sv[k] = (T)0;
+        }
+        for (int tl = t_first + wp; tl < t_end; tl += 2) {
+            const unsigned long long uc = tile_ucode_of(tl);
+            if (uc == 0ull) continue;
+            if (uc != cur) {
+                cur = uc;
+                kc = -1;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+                    const int ci = ck == HIPK_SELL_PAD ? 0 : (int)ck;
+                    sbo[k] = (long long)__builtin_amdgcn_readfirstlane(doff[ci]) * (long long)sizeof(T);
+                    if (ck != HIPK_SELL_PAD && sbo[k] == 0) kc = k;
+                    const double v = dval[ci];
+                    sv[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
+                }
+            }
+            const int r0 = tl * HIPK_TILE + wh * 128 + 2 * lane;
+            const unsigned vo = (unsigned)r0 * (unsigned)sizeof(T);
+            double2 xv[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+                if (ck != HIPK_SELL_PAD) xv[k] = *(const double2 *)(xb + sbo[k] + vo);
+            }
+            double2 ow = {0.0, 0.0}, ob = {0.0, 0.0}, od = {0.0, 0.0};
+            if (mode & HIPK_SPMV_DOT_W) {
+                if (w_is_x && kc >= 0) {
+#pragma unroll
+                    for (int k = 0; k < NE; ++k)
+                        if (k == kc) ow = xv[k];
+                } else {
+                    ow = *(const double2 *)((const char *)a.w + vo);
+                }
+            }
+            if (mode & HIPK_SPMV_RESID) ob = *(const double2 *)((const char *)a.bsub + vo);
+            if (mode & HIPK_SPMV_SCALE) od = *(const double2 *)((const char *)a.dscale + vo);
+            double2 s = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+                if (ck != HIPK_SELL_PAD) {
+                    const double px = sv[k] * xv[k].x, py = sv[k] * xv[k].y;
+                    s.x = s.x + px;
+                    s.y = s.y + py;
+                }
+            }
+            double2 out = s;
+            if (mode & HIPK_SPMV_RESID) {
+                out.x = ob.x - out.x;
+                out.y = ob.y - out.y;
+            }
+            if (mode & HIPK_SPMV_SCALE) {
+                out.x = od.x * out.x;
+                out.y = od.y * out.y;
+            }
+            *(double2 *)((char *)y + vo) = out;
+            const int slot = (tl - t_first) * 4 + 2 * wh + (lane >> 5);
+            if (mode & HIPK_SPMV_DOT_W) {
+                double2 d = {ow.x * out.x, ow.y * out.y};
+                const double r = hipk_half_tree2(d);
+                if ((lane & 31) == 0) wsum0[slot] = r;
+            }
+            if (mode & HIPK_SPMV_DOT_YY) {
+                double2 d = {out.x * out.x, out.y * out.y};
+                const double r = hipk_half_tree2(d);
+                if ((lane & 31) == 0) wsum1[slot] = r;
+            }
+        }
+    }
+    if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+        __syncthreads();
+        if (wave == 0) {
+            const int cnt = t_end - t_first;
+            if (mode & HIPK_SPMV_DOT_W) {
+                const double r = hipk_wave_fold(wsum0, cnt, lane);
+                if (lane == 0) a.part0[chunk] = r;
+            }
+            if (mode & HIPK_SPMV_DOT_YY) {
+                const double r = hipk_wave_fold(wsum1, cnt, lane);
+                if (lane == 0) a.part1[chunk] = r;
+            }
+        }
+    }
+}
 #endif

@@ -27,7 +27,7 @@ GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
 SYMBOLS = [
     "hipk_version", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
-    "hipk_csr_spmv_path", "hipk_csr_set_path", "hipk_csr_format_bytes",
+    "hipk_csr_spmv_path", "hipk_last_spmv_kernel", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
     "hipk_chunk_size", "hipk_chunk_count", "hipk_scratch_bytes",
     "hipk_spmv", "hipk_spmv_dot", "hipk_dot", "hipk_axpy", "hipk_xpby", "hipk_block_jacobi_apply",
@@ -156,6 +156,7 @@ def lib():
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
     L.hipk_version.restype = i32
     L.hipk_last_error.restype = ctypes.c_char_p
+    L.hipk_last_spmv_kernel.restype = ctypes.c_char_p
     L.hipk_device_count.restype = i32
     L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]
     L.hipk_csr_destroy.argtypes = [vp]
@@ -317,6 +318,11 @@ class CsrHandle:
     def path(self) -> str:
         """SpMV kernel family selected by the structure analysis (include/hipk.h, hipk_spmv_path)."""
         return self.PATHS[int(lib().hipk_csr_spmv_path(self._h))]
+
+    @staticmethod
+    def last_spmv_kernel() -> str:
+        """Kernel instantiation this thread's most recent SpMV launch selected (hipk_last_spmv_kernel)."""
+        return lib().hipk_last_spmv_kernel().decode()
 
     def set_path(self, plain_only: bool) -> None:
         """plain_only=True: never use the coded form (A/B measurements, parity tests)."""

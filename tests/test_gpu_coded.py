@@ -265,6 +265,75 @@ def test_chunked_form_with_a_ragged_last_chunk_and_larger_chunks(hipk, oracle):
     assert np.array_equal(coded[0], b.cpu().numpy() - oracle.spmv(crow, col, val, x.cpu().numpy()))
 
 
+def _spmv_ex_mode(hipk, h, mode, x, w, b):
+    L = hipk.lib()
+    G = int(L.hipk_chunk_count(x.numel()))
+    y = torch.empty_like(x)
+    p0 = torch.zeros(G, dtype=torch.float64, device=DEV)
+    p1 = torch.zeros(G, dtype=torch.float64, device=DEV)
+    hipk._check(L.hipk_spmv_ex(h._h, x.data_ptr(), y.data_ptr(), mode, w.data_ptr(), b.data_ptr(), p0.data_ptr(),
+                               p1.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream), "hipk_spmv_ex")
+    return y.cpu().numpy(), p0.cpu().numpy(), p1.cpu().numpy()
+
+
+@pytest.mark.parametrize("offsets", [[-1, 0, 1], [-1500, -1, 0, 1], [-1500, -1, 0, 1, 1500], [-1500, -1, 1, 1500],
+                                     [-9000, -1500, -1, 0, 1, 1500, 9000], [-9000, -1500, -2, -1, 0, 1, 1500, 9000]])
+def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets):
+    """hipk_spmv_sell_wide_kernel (chunk-per-workgroup sizes, fp64, most tiles uniform): uniform tiles from 16-byte accesses, two
+    rows per lane, the fused dots' 64-row sums on that layout; tile widths 3-4, 5 and 7-8, a partial last tile, uniform tiles
+    with padding (the first and last rows of the band lack entries), an offset list without a diagonal.  Every mode the solvers
+    use -- compiled-in <w, y> with w == x (the CG loop: w taken from the diagonal entry's load) and w != x, ||y||^2, the
+    residual form with both dots -- against the plain CSR kernels bit for bit, y against the oracle."""
+    n = 2_200_077
+    crow, col, val = banded(n, offsets, lambda r, k: 1.5 + 0.25 * k)
+    h = make_handle(hipk, crow, col, val, n)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x, w, b = (torch.randn(n, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
+    assert h.path() == "coded"
+    runs = [(0, x, w), (1, x, x), (1, x, w), (2, x, w), (7, x, w), (6, x, w), (3, x, w)]
+    coded = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
+    assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_sell_wide_kernel"), hipk.CsrHandle.last_spmv_kernel()
+    h.set_path(plain_only=True)
+    plain = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
+    assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_kernel")
+    h.set_path(plain_only=False)
+    for (m, _, _), cr, pr in zip(runs, coded, plain):
+        assert np.array_equal(cr[0], pr[0]), m
+        if m & 1:
+            assert np.array_equal(cr[1], pr[1]), m
+        if m & 2:
+            assert np.array_equal(cr[2], pr[2]), m
+    assert np.array_equal(coded[0][0], oracle.spmv(crow, col, val, x.cpu().numpy()))
+
+
+@pytest.mark.parametrize("solver", ["pbicgstab", "pgmres", "bicgstab", "gmres"])
+def test_two_rows_per_lane_inside_the_solvers(hipk, solver):
+    """The solvers' SpMV forms on the two-rows-per-lane kernel at a size that takes it (N = 2.25 M): a few iterations of
+    BiCGStab / GMRES, plain and Jacobi-preconditioned (the epilogue's row scaling), identical to the plain CSR kernels."""
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
+    A = create_convdiff_2d_csr(1500, 1500, device=DEV)
+    h = hipk.handle_for(A)
+    n = A.shape[0]
+    assert h.path() == "coded"
+    b = torch.randn(n, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    dinv = 1.0 / torch.linspace(3.0, 5.0, n, dtype=torch.float64, device=DEV)
+    res = {}
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        x = torch.zeros_like(b)
+        if solver == "pbicgstab":
+            st = hipk.solve_pcg(h, dinv, b, x, tol=1e-10, atol=0.0, maxiter=12, method="bicgstab")
+        elif solver == "pgmres":
+            st = hipk.solve_pgmres(h, dinv, b, x, tol=1e-10, atol=0.0, maxiter=2, restart=6)
+        else:
+            st = hipk.solve(solver, h, b, x, tol=1e-10, atol=0.0, maxiter=12 if solver == "bicgstab" else 2, restart=6)
+        res[plain] = (x.cpu().numpy(), st.iterations, st.info, st.residual_norm)
+        if not plain:
+            assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_sell_wide_kernel"), hipk.CsrHandle.last_spmv_kernel()
+    h.set_path(plain_only=False)
+    assert np.array_equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
+
+
 # ------------------------------------------------------------------ offset-coded layout (variable coefficients)
 @pytest.mark.parametrize("chunked", ["1", "0"])
 @pytest.mark.parametrize("offsets", [[-300, -1, 0, 1, 300], [-1, 0, 1], [-40, -7, -1, 0, 1, 7, 40], [0, 5, 9, 11, 50, 51],

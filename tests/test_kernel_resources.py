@@ -44,7 +44,8 @@ HOT = {
     "hipk_gmres.hip": ["void hipk_gm_multidot_stream_kernel<double, 8>", "void hipk_gm_update_stream_kernel<double, 8>",
                        "void hipk_gm_normalize_kernel<double>"],
     "hipk_api.hip": ["void hipk_spmv_kernel<double, 1280, true>", "void hipk_spmv_sell_pair_kernel<double, 5, true, 1>",
-                     "void hipk_spmv_sell_pair_kernel<double, 5, true, 2>", "void hipk_spmv_sell_pair_kernel<double, 5, true, -1>"],
+                     "void hipk_spmv_sell_pair_kernel<double, 5, true, 2>", "void hipk_spmv_sell_pair_kernel<double, 5, true, -1>",
+                     "void hipk_spmv_sell_wide_kernel<5, 1>", "void hipk_spmv_sell_wide_kernel<5, 2>", "void hipk_spmv_sell_wide_kernel<5, -1>"],
 }
 
 
