@@ -149,6 +149,20 @@ def cpu_baseline(nx, iters):
                                     f"{it_gen} iterations in {dt_gen:.2f} s"}
 
 
+def _loop_spmv_kernel(h, v):
+    """Name of the kernel instantiation the CG loop's SpMV (y = A p with the fused <p, y> partials) selects for this handle:
+    one such launch through the C ABI, then the library's own record of what it dispatched (hipk_last_spmv_kernel)."""
+    import torch
+    from pytorch_sparse_solver import _hipk
+    L = _hipk.lib()
+    y = torch.empty_like(v)
+    part = torch.zeros(int(L.hipk_chunk_count(v.numel())), dtype=torch.float64, device=v.device)
+    _hipk._check(L.hipk_spmv_ex(h._h, v.data_ptr(), y.data_ptr(), 1, v.data_ptr(), None, part.data_ptr(), None, None, 0,
+                                torch.cuda.current_stream().cuda_stream), "hipk_spmv_ex")
+    torch.cuda.synchronize()
+    return h.last_spmv_kernel()
+
+
 def load_pmc():
     for name in PMC_FILES:
         try:
@@ -282,8 +296,7 @@ def main():
         fbytes = h.format_bytes()
         # the chunk-per-workgroup pair form needs chunks of <= 64 tiles; larger chunks take the persistent loop kernel
         # the instantiation the CG loop's SpMV launches select (the library reports it: hipk_last_spmv_kernel)
-        in_loop(1)
-        spmv_kernel = h.last_spmv_kernel()
+        spmv_kernel = _loop_spmv_kernel(h, b)
         spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles two rows per lane from one word per tile, + fused <p,Ap> chunk partials)",
                      "tile_fast": f"{spmv_kernel} (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, f"{spmv_kernel} ({path})")
         coded = path in ("coded", "offset_coded")
@@ -353,7 +366,7 @@ def main():
                 _, _, pst2 = one_solve()
                 torch.cuda.synchronize()
                 pdt = time.perf_counter() - t1
-                pname = h.last_spmv_kernel()
+                pname = _loop_spmv_kernel(h, b)
                 spmv_report["plain_csr_kernels_same_matrix"] = {
                     "path": h.path(), "kernel": pname, "in_loop_us": pus, "algorithmic_bytes_per_launch": spmv_bytes,
                     "GBps": spmv_bytes / pus / 1e3,

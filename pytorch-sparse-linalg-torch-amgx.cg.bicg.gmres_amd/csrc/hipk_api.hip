@@ -558,8 +558,13 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
             const int slots = h->n_cu * occ;
             // one workgroup per reduction chunk when the chunks about fill the machine in one round
-            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots &&
-                                 h->sell_chunked * a.g >= slots;  // default: the chunks fill at least half of the slots
+            // (default: the chunks fill at least half of the slots; a quarter where the two-rows-per-lane kernel applies --
+            // N = 1.96 M Poisson: 28.2 -> 30.2 k CG it/s, no gain below a quarter)
+            static const bool chunked_env = getenv("HIPK_SPMV_SELL_CHUNKED") != nullptr;
+            const bool wide_ok = h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles && h->coded_layout == 2 &&
+                                 (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8);
+            const int cfac = (!chunked_env && wide_ok && h->sell_chunked == 2) ? 4 : h->sell_chunked;
+            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && cfac * a.g >= slots;
             int lgrid;
             if (chunked) {
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
@@ -587,7 +592,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
                     snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
                     // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel): fp64, most tiles uniform
-                    static const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;
+                    const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;  // read per launch: in-process A/B (tools/gmres_variants.py)
                     if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles) {
 #define HIPK_PICK_WIDE(M) \
     (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M> : hipk_spmv_sell_wide_kernel<4, M>)

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // CHUNKED = true (large systems: about as many reduction chunks as resident workgroups): one workgroup per
 //   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
 //   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
-#define HIPK_SELL_MAX_TPC 64  // tiles per chunk the chunked form holds in LDS (chunks up to 16384 rows)
+#define HIPK_SELL_MAX_TPC 128  // tiles per chunk the chunked form holds in LDS (chunks up to 32768 rows: N = 64 M)
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
 //   row pointers, for stencils with variable coefficients.
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
 // tiles in PAIRS: both tiles' gathers (2 x NE loads per thread) are in flight together, their row sums and wavefront
 // sums are independent instruction streams the scheduler interleaves (no idle hazard slots), and the loop is unrolled over
 // two pairs so that the prefetched requests change roles instead of being copied.  Same arithmetic per row, same tile /
-// chunk folds: same bits.  Pair codes only (VALS = false), exact tile sizes (UNITS = 4, 5, 8), chunks of <= 64 tiles.
+// chunk folds: same bits.  Pair codes only (VALS = false), exact tile sizes (UNITS = 4, 5, 8), chunks of <= HIPK_SELL_MAX_TPC tiles.
 // MODE >= 0: the mode bits as a compile-time constant (the solver loops' hot forms: no per-tile scalar branches on the mode)
 template <typename T, int UNITS, bool UNI, int MODE = -1>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_pair_kernel(hipk_spmv_args a) {
@@ -927,8 +927,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     const int *__restrict__ g_doff = a.dict_off;
     const T *__restrict__ g_dval = (const T *)a.dict_val;
 
-    unsigned long long uc_mine = 0ull;  // requested first: complete before the dictionary reaches LDS (loads return in order)
-    if (lane < t_end - t_first) uc_mine = ucode[t_first + lane];
+    unsigned long long uc_mine = 0ull, uc_more = 0ull;  // requested first: complete before the dictionary reaches LDS (loads
+    if (lane < t_end - t_first) uc_mine = ucode[t_first + lane];                                     // return in order)
+    if (tpc > 64 && lane + 64 < t_end - t_first) uc_more = ucode[t_first + 64 + lane];
     T dv = (T)0;
     int dofs = 0;
     if (t < a.n_codes) {
@@ -940,12 +941,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     doff[t] = dofs;
     __syncthreads();
 
-    // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's, a tile's word is read into scalar registers
-    // with v_readlane (no memory round trip per tile)
+    // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's (and t_first + 64 + i's for chunks of more
+    // than 64 tiles), a tile's word is read into scalar registers with v_readlane (no memory round trip per tile)
     auto tile_ucode_of = [&](int tl) -> unsigned long long {
         const int i = tl - t_first;
-        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)uc_mine, i) |
-               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(uc_mine >> 32), i) << 32);
+        const unsigned long long src = (i & 64) ? uc_more : uc_mine;
+        return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)src, i & 63) |
+               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(src >> 32), i & 63) << 32);
     };
 
     // ---- the tiles whose rows differ: one row per lane, codes from the planes (as hipk_spmv_sell_pair_kernel, one tile per trip)

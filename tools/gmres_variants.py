@@ -10,7 +10,7 @@ from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 A = create_convdiff_2d_csr(nx, nx, device="cuda:0")
 b = torch.ones(nx * nx, dtype=torch.float64, device="cuda:0")
-KEYS = ("HIPK_GMRES_NO_SWEEP", "HIPK_GM_MAP", "HIPK_GM_FOLD", "HIPK_GM_NRES", "HIPK_GM_SPEC", "HIPK_GMRES_NO_STREAM", "HIPK_GM_SWEEP3")
+KEYS = ("HIPK_GMRES_NO_SWEEP", "HIPK_GM_MAP", "HIPK_GM_FOLD", "HIPK_GM_NRES", "HIPK_GM_SPEC", "HIPK_GMRES_NO_STREAM", "HIPK_GM_SWEEP3", "HIPK_SPMV_SELL_NO_WIDE")
 variants = [a.split(",") for a in sys.argv[2:]] or [["HIPK_GMRES_NO_SWEEP=1"], []]
 ref = None
 for rep in range(2):
