@@ -245,7 +245,27 @@ def main():
         n_rows_rank, nnz_rank, spmv_bytes = nx * nx, h.nnz, h.spmv_bytes()
         workload = f"poisson5pt_{nx}x{nx}_N={nx * nx}_cg_tol{args.tol:g}_b=ones" + ("_strong_1rank" if strong else "")
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        if use_dist and w == 0:
+            # first solve of a multi-rank run: if the C-driven loop / the direct RCCL communicator fails on ANY rank, all ranks
+            # agree to continue on the Python loop with torch.distributed collectives (slower per iteration, same bits) instead
+            # of losing the run; the choice is reported in config.collectives
+            import torch.distributed as dist
+            failed = 0
+            try:
+                one_solve()
+            except Exception as e:  # noqa: BLE001
+                failed = 1
+                print(f"[bench rank {rank}] row-partitioned solve failed on the direct-RCCL path: {e}", file=sys.stderr, flush=True)
+            flag = torch.tensor([failed], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                os.environ["HIPK_DIST_NATIVE"] = "0"
+                if prob.comm is not None:
+                    prob.comm = None
+                    prob.comm_kind = "torch.distributed (fallback after a failure of the direct-RCCL path)"
+                one_solve()
+            continue
         one_solve()
     barrier()
     torch.cuda.synchronize()

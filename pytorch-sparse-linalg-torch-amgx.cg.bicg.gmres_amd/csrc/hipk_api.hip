@@ -599,8 +599,12 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                         pk = HIPK_PICK_WIDE(-1);
                         if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
                         if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
+                        // BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927)
+                        constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
+                        if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
+                        if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);  // plain y = A x (hipk_spmv)
                         snprintf(pname, sizeof(pname), "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
-                                 ((a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode) ? a.mode : -1);
+                                 (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1);
 #undef HIPK_PICK_WIDE
                     }
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
