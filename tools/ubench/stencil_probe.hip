@@ -6,6 +6,7 @@
 //   2: as 1, but the masks are only read for tiles flagged "ragged" (scalar branch per tile)
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -I <pkg>/csrc tools/ubench/stencil_probe.hip -o tools/ubench/stencil_probe
 #include "hipk_spmv.h"
+#include "hipk_coded.h"
 
 #include <vector>
 
@@ -209,6 +210,59 @@ __global__ __launch_bounds__(HIPK_THREADS) void stencil_parts_kernel(int n, int 
     }
 }
 
+
+// memory shape of a fused "p = r + beta p, x += alpha p, q = A p" pass (two rows per lane): r and p at the five offsets, x;
+// stores p_new (other buffer), x, q; fused <p_new, q>.  FUSED = 0: the same two passes as separate loops in one kernel is not
+// meaningful -- compare with the sum of the stand-alone kernels instead.
+__global__ __launch_bounds__(HIPK_THREADS) void stencil_fused_kernel(int n, int g, pat_t pt, const char *__restrict__ rb,
+                                                                     const char *__restrict__ pb, double *__restrict__ xv_,
+                                                                     double *__restrict__ pn, double *__restrict__ q,
+                                                                     double alpha, double beta, double *__restrict__ part0) {
+    constexpr int TPC = 8;
+    const int chunk = hipk_xcd_chunk(blockIdx.x, g);
+    if (chunk < 0) return;
+    __shared__ double wsum0[TPC * 4];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wp = wave >> 1, wh = wave & 1;
+    const int t_first = chunk * TPC;
+    const int ntiles = (n + 255) >> 8;
+    const int t_end = t_first + TPC < ntiles ? t_first + TPC : ntiles;
+    for (int tl = t_first + wp; tl < t_end; tl += 2) {
+        const unsigned vo = (unsigned)(tl * 256 + wh * 128 + 2 * lane) * 8u;
+        double2 rv[5], pv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            rv[k] = *(const double2 *)(rb + pt.boff[k] + vo);
+            pv[k] = *(const double2 *)(pb + pt.boff[k] + vo);
+        }
+        double2 xx = *(const double2 *)((const char *)xv_ + vo);
+        double2 s = {0.0, 0.0}, pc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            double2 pj;
+            pj.x = rv[k].x + beta * pv[k].x;
+            pj.y = rv[k].y + beta * pv[k].y;
+            if (k == 2) pc = pj;
+            s.x = s.x + pt.val[k] * pj.x;
+            s.y = s.y + pt.val[k] * pj.y;
+        }
+        xx.x = xx.x + alpha * pv[2].x;
+        xx.y = xx.y + alpha * pv[2].y;
+        *(double2 *)((char *)xv_ + vo) = xx;
+        *(double2 *)((char *)pn + vo) = pc;
+        *(double2 *)((char *)q + vo) = s;
+        double2 d = {pc.x * s.x, pc.y * s.y};
+        const double r = hipk_half_tree2(d);
+        if ((lane & 31) == 0) wsum0[(tl - t_first) * 4 + 2 * wh + (lane >> 5)] = r;
+    }
+    __syncthreads();
+    if (t < 64) {
+        const double r = hipk_wave_fold(wsum0, t_end - t_first, lane);
+        if (lane == 0) part0[chunk] = r;
+    }
+}
+
 int main(int argc, char **argv) {
     const int nx = argc > 1 ? atoi(argv[1]) : 2000;
     const int n = nx * nx, ntiles = (n + 255) / 256, g = (ntiles + 7) / 8;
@@ -326,6 +380,28 @@ int main(int argc, char **argv) {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("parts: %-24s %.2f us per launch\n", names[var], 1e3 * ms / reps);
+    }
+    {
+        double *rr_, *pp_, *pn_, *q_, *x2_;
+        CK(hipMalloc(&rr_, padn * 8));
+        CK(hipMalloc(&pp_, padn * 8));
+        CK(hipMalloc(&pn_, padn * 8));
+        CK(hipMalloc(&q_, padn * 8));
+        CK(hipMalloc(&x2_, padn * 8));
+        CK(hipMemcpy(rr_, hx.data(), padn * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(pp_, hx.data(), padn * 8, hipMemcpyHostToDevice));
+        CK(hipMemset(x2_, 0, padn * 8));
+        const int reps = 400;
+        for (int it = 0; it < reps + 20; ++it) {
+            if (it == 20) CK(hipEventRecord(e0, 0));
+            stencil_fused_kernel<<<grid, HIPK_THREADS>>>(n, g, pt, (const char *)(rr_ + nx + 256), (const char *)(pp_ + nx + 256),
+                                                        x2_ + nx + 256, pn_ + nx + 256, q_ + nx + 256, 1e-3, 0.5, part);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("fused direction + SpMV shape (r, p at five offsets, x; stores p', x, q; 192 MB): %.2f us per launch\n", 1e3 * ms / reps);
     }
     return 0;
 }
