@@ -565,8 +565,61 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                                  (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8);
             const int cfac = (!chunked_env && wide_ok && h->sell_chunked == 2) ? 4 : h->sell_chunked;
             const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && cfac * a.g >= slots;
-            int lgrid;
-            if (chunked) {
+            int lgrid = 0;
+            static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
+            const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;  // read per launch: in-process A/B (tools/gmres_variants.py)
+            constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
+            // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel; fp64, most tiles uniform), mode bits compiled in for
+            // the CG loop's form, the Arnoldi step's, BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927), plain y = A x
+            auto pick_wide = [&](bool st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {
+                void (*pk)(hipk_spmv_args) = nullptr;
+#define HIPK_PICK_WIDE_S(M, S) \
+    (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M, S> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M, S> : hipk_spmv_sell_wide_kernel<4, M, S>)
+#define HIPK_PICK_WIDE(M) (st ? HIPK_PICK_WIDE_S(M, true) : HIPK_PICK_WIDE_S(M, false))
+                pk = HIPK_PICK_WIDE(-1);
+                if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
+                if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
+                if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
+                if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
+#undef HIPK_PICK_WIDE
+#undef HIPK_PICK_WIDE_S
+                snprintf(pname, cap, st ? "hipk_spmv_sell_wide_kernel<%d,%d,true>" : "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
+                         (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1);
+                return pk;
+            };
+            // STRIDED form of that kernel: a persistent grid whose workgroups sweep each XCD's eighth of the tiles together, tile
+            // sums through the combine kernel.  Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned
+            // system, which cannot fill the chip with a workgroup per chunk and used to fall to the one-row-per-lane kernel
+            // (4 M rows with the chunk size of a 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) --
+            // and (b) where a chunk spans four grid lines and more (N = 64 M on one device: 1184 -> 1131 us per CG iteration;
+            // at N = 16 M / 32 M it measured equal or slower in the CG loop: not taken there).  HIPK_SPMV_SELL_STRIDED=0|1 forces
+            // (read per launch: in-process A/B, tools/walk_probe.py)
+            bool strided = false;
+            if (wide_ok && !no_wide && h->sell_chunked != 0) {
+                const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
+                if (se ? atoi(se) != 0 : tpc >= (chunked ? 4 * HIPK_SELL_STRIDED_TPC : HIPK_SELL_STRIDED_TPC)) {
+                    char pname[96];
+                    void (*pk)(hipk_spmv_args) = pick_wide(true, pname, sizeof(pname));
+                    int pocc = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) != hipSuccess || pocc < 1) pocc = 0;
+                    const int per = (ntiles + 7) >> 3;                 // tiles per XCD eighth
+                    int S = (h->n_cu * pocc) >> 3;                      // resident workgroups per XCD
+                    if (S > (per + 3) / 4) S = (per + 3) / 4;           // at least four tiles each (two per wavefront pair)
+                    if (S >= 1 && (per + S - 1) / S <= 128) {           // the kernel holds <= 128 `ucode` words per workgroup
+                        strided = true;
+                        kern = pk;
+                        lgrid = 8 * S;
+                        // a vector alone beyond the 256 MiB Infinity Cache: y streams (N = 64 M: 1160 -> 1131 us per CG iteration;
+                        // at N = 16 M, where the update kernel still finds Ap there, non-temporal stores cost 3 %)
+                        const char *ne = getenv("HIPK_SPMV_NT_Y");  // read per launch: in-process A/B
+                        a.nt_y = ne ? atoi(ne) != 0 : (size_t)h->n_rows * sv > ((size_t)256 << 20);
+                        HIPK_NOTE_KERNEL("%s", pname);
+                    }
+                }
+            }
+            if (strided) {
+                // kern, lgrid: set above
+            } else if (chunked) {
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
                 lgrid = hipk_xcd_grid(a.g);
                 HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>", tname, uw, vls, uni);
@@ -580,7 +633,6 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
                     int pmode = -1;
                     // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
-                    static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
                     if (h->dtype == HIPK_F64 && h->sell_w == 5 && (a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode)
                         pmode = a.mode;
                     if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !no_mode)
@@ -591,22 +643,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                         pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
                     snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
-                    // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel): fp64, most tiles uniform
-                    const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;  // read per launch: in-process A/B (tools/gmres_variants.py)
-                    if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles) {
-#define HIPK_PICK_WIDE(M) \
-    (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M> : hipk_spmv_sell_wide_kernel<4, M>)
-                        pk = HIPK_PICK_WIDE(-1);
-                        if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
-                        if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
-                        // BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927)
-                        constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
-                        if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
-                        if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);  // plain y = A x (hipk_spmv)
-                        snprintf(pname, sizeof(pname), "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
-                                 (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1);
-#undef HIPK_PICK_WIDE
-                    }
+                    if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles)
+                        pk = pick_wide(false, pname, sizeof(pname));
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
                         (pocc * h->n_cu >= a.g || pocc >= occ)) {
@@ -627,7 +665,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             if (prof) prof->before(stream);
             kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
             if (prof) prof->after(stream);
-            if (!chunked && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
+            if ((!chunked || strided) && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
                 hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                     (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
                     a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);

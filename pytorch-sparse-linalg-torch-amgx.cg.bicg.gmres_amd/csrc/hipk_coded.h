@@ -477,6 +477,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // CHUNKED = true (large systems: about as many reduction chunks as resident workgroups): one workgroup per
 //   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
 //   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
+#define HIPK_SELL_STRIDED_TPC 32  // two-rows-per-lane kernel, strided walk: row blocks of few chunks of >= 32 tiles, any block with chunks of 128
 #define HIPK_SELL_MAX_TPC 128  // tiles per chunk the chunked form holds in LDS (chunks up to 32768 rows: N = 64 M)
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
@@ -900,7 +901,14 @@ __device__ __forceinline__ double hipk_half_tree2(double2 d) {  // sums of rows 
     return d.x + d.y;
 }
 
-template <int UNITS, int MODE = -1>
+// STRIDED: the launch is not tied to the reduction chunks -- a persistent grid (a multiple of 8 workgroups), the S = grid / 8
+// workgroups of an XCD walk its eighth of the TILES together: workgroup j takes tiles T0 + j, T0 + j + S, ... (at most 128), so the
+// eighth is swept by one front of S tiles whose x window (and the +-1 grid line around it) stays in that XCD's L2.  A workgroup
+// that walks a chunk of 128 consecutive tiles on its own (N = 64 M) re-reads x[row +- nx] after 64 KB of its own traffic, times the
+// 244 workgroups of the XCD = 16 MB against 4 MB of L2.  It also serves row blocks with FEW chunks of many tiles (a rank of a
+// row-partitioned system: 8 M rows in 244 chunks), which cannot fill the chip with a workgroup per chunk.  The wavefront sums of
+// the fused dots go to the per-tile buffer and hipk_tile_combine_kernel folds them (same fold, same bits).
+template <int UNITS, int MODE = -1, bool STRIDED = false>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
     typedef double T;
     constexpr int G0 = (UNITS + 3) / 4;
@@ -908,12 +916,24 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     static_assert(UNITS == 4 || UNITS == 5 || UNITS == 8, "exact tile sizes only");
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
     const int tpc = a.ch / HIPK_TILE;
-    const int chunk = hipk_xcd_chunk(blockIdx.x, a.g);
+    const int chunk = STRIDED ? 0 : hipk_xcd_chunk(blockIdx.x, a.g);
     if (chunk < 0) return;
-    const int t_first = chunk * tpc;
-    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;
-    __shared__ double wsum0[HIPK_SELL_MAX_TPC * 4];
-    __shared__ double wsum1[HIPK_SELL_MAX_TPC * 4];
+    // local tile i of this workgroup is tile t_first + i * t_step, i < cnt
+    int t_first = chunk * tpc, t_step = 1;
+    int cnt = ((t_first + tpc < ntiles) ? t_first + tpc : ntiles) - t_first;
+    if (STRIDED) {
+        const int per = (ntiles + 7) >> 3;  // tiles per XCD eighth
+        const int S = (int)gridDim.x >> 3;  // workgroups per XCD (the grid is a multiple of 8; the host keeps per / S <= 128)
+        const int T0 = (blockIdx.x & 7) * per;
+        const int T1 = (T0 + per < ntiles) ? T0 + per : ntiles;
+        t_first = T0 + ((int)blockIdx.x >> 3);
+        t_step = S;
+        cnt = (T1 - t_first + S - 1) / S;
+        if (cnt < 0) cnt = 0;
+        if (cnt > 2 * 64) cnt = 2 * 64;  // never: host-side guard (two `ucode` words per lane)
+    }
+    __shared__ double wsum0[STRIDED ? 1 : HIPK_SELL_MAX_TPC * 4];
+    __shared__ double wsum1[STRIDED ? 1 : HIPK_SELL_MAX_TPC * 4];
     __shared__ T dval[HIPK_CODED_MAX];
     __shared__ int doff[HIPK_CODED_MAX];
     const int t = threadIdx.x, lane = t & 63;
@@ -928,8 +948,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     const T *__restrict__ g_dval = (const T *)a.dict_val;
 
     unsigned long long uc_mine = 0ull, uc_more = 0ull;  // requested first: complete before the dictionary reaches LDS (loads
-    if (lane < t_end - t_first) uc_mine = ucode[t_first + lane];                                     // return in order)
-    if (tpc > 64 && lane + 64 < t_end - t_first) uc_more = ucode[t_first + 64 + lane];
+    if (lane < cnt) uc_mine = ucode[t_first + lane * t_step];                                        // return in order)
+    if ((STRIDED || tpc > 64) && lane + 64 < cnt) uc_more = ucode[t_first + (64 + lane) * t_step];
     T dv = (T)0;
     int dofs = 0;
     if (t < a.n_codes) {
@@ -943,16 +963,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
 
     // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's (and t_first + 64 + i's for chunks of more
     // than 64 tiles), a tile's word is read into scalar registers with v_readlane (no memory round trip per tile)
-    auto tile_ucode_of = [&](int tl) -> unsigned long long {
-        const int i = tl - t_first;
+    auto tile_ucode_of = [&](int i) -> unsigned long long {  // of local tile i
         const unsigned long long src = (i & 64) ? uc_more : uc_mine;
         return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)src, i & 63) |
                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(src >> 32), i & 63) << 32);
     };
 
     // ---- the tiles whose rows differ: one row per lane, codes from the planes (as hipk_spmv_sell_pair_kernel, one tile per trip)
-    for (int tl = t_first; tl < t_end; ++tl) {
-        if (tile_ucode_of(tl) != 0ull) continue;
+    for (int i = 0; i < cnt; ++i) {
+        if (tile_ucode_of(i) != 0ull) continue;
+        const int tl = t_first + i * t_step;
         unsigned c[G0];
         {
             const unsigned char *tp = code + (size_t)tl * (UNITS * HIPK_TILE);
@@ -1002,14 +1022,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
             if (mode & HIPK_SPMV_DOT_W) d0 = (double)ow * (double)out;
             if (mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
         }
-        const int slot = (tl - t_first) * 4 + wave;
+        const int slot = i * 4 + wave;
         if (mode & HIPK_SPMV_DOT_W) {
             d0 = hipk_wave_sum(d0);
-            if (lane == 0) wsum0[slot] = d0;
+            if (lane == 0) {
+                if (STRIDED) a.tpart0[(size_t)tl * 4 + wave] = d0;
+                else wsum0[slot] = d0;
+            }
         }
         if (mode & HIPK_SPMV_DOT_YY) {
             d1 = hipk_wave_sum(d1);
-            if (lane == 0) wsum1[slot] = d1;
+            if (lane == 0) {
+                if (STRIDED) a.tpart1[(size_t)tl * 4 + wave] = d1;
+                else wsum1[slot] = d1;
+            }
         }
     }
 
@@ -1026,9 +1052,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
             sbo[k] = 0;
             sv[k] = (T)0;
         }
-        for (int tl = t_first + wp; tl < t_end; tl += 2) {
-            const unsigned long long uc = tile_ucode_of(tl);
+        for (int i = wp; i < cnt; i += 2) {
+            const unsigned long long uc = tile_ucode_of(i);
             if (uc == 0ull) continue;
+            const int tl = t_first + i * t_step;
             if (uc != cur) {
                 cur = uc;
                 kc = -1;
@@ -1082,24 +1109,37 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
                 out.x = od.x * out.x;
                 out.y = od.y * out.y;
             }
-            *(double2 *)((char *)y + vo) = out;
-            const int slot = (tl - t_first) * 4 + 2 * wh + (lane >> 5);
+            if (STRIDED && a.nt_y) {
+                typedef double d2n __attribute__((ext_vector_type(2)));
+                d2n o2;
+                o2.x = out.x;
+                o2.y = out.y;
+                __builtin_nontemporal_store(o2, (d2n *)((char *)y + vo));
+            } else {
+                *(double2 *)((char *)y + vo) = out;
+            }
+            const int slot = i * 4 + 2 * wh + (lane >> 5);
             if (mode & HIPK_SPMV_DOT_W) {
                 double2 d = {ow.x * out.x, ow.y * out.y};
                 const double r = hipk_half_tree2(d);
-                if ((lane & 31) == 0) wsum0[slot] = r;
+                if ((lane & 31) == 0) {
+                    if (STRIDED) a.tpart0[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
+                    else wsum0[slot] = r;
+                }
             }
             if (mode & HIPK_SPMV_DOT_YY) {
                 double2 d = {out.x * out.x, out.y * out.y};
                 const double r = hipk_half_tree2(d);
-                if ((lane & 31) == 0) wsum1[slot] = r;
+                if ((lane & 31) == 0) {
+                    if (STRIDED) a.tpart1[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
+                    else wsum1[slot] = r;
+                }
             }
         }
     }
-    if (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
+    if (!STRIDED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();
         if (wave == 0) {
-            const int cnt = t_end - t_first;
             if (mode & HIPK_SPMV_DOT_W) {
                 const double r = hipk_wave_fold(wsum0, cnt, lane);
                 if (lane == 0) a.part0[chunk] = r;
