@@ -17,6 +17,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - the library never allocates inside a solve: the caller supplies `work`
  *     (size from hipk_*_work_bytes), so solves are graph/stream friendly.
+ *   - a handle owns scratch its kernels write (per-tile sums of the fused dots):
+ *     calls on ONE handle must be ordered on one stream (or by events);
+ *     different handles are independent.
  *   - all reductions are atomic-free with a fixed summation tree
  *     (DESIGN.md "reduction spec"): results are bitwise run-to-run reproducible
  *     and bitwise equal to oracle/krylov_oracle.c.

@@ -571,11 +571,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
             // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel; fp64, most tiles uniform), mode bits compiled in for
             // the CG loop's form, the Arnoldi step's, BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927), plain y = A x
-            auto pick_wide = [&](bool st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {
+            auto pick_wide = [&](int st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {  // st = the kernel's WALK
                 void (*pk)(hipk_spmv_args) = nullptr;
 #define HIPK_PICK_WIDE_S(M, S) \
     (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M, S> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M, S> : hipk_spmv_sell_wide_kernel<4, M, S>)
-#define HIPK_PICK_WIDE(M) (st ? HIPK_PICK_WIDE_S(M, true) : HIPK_PICK_WIDE_S(M, false))
+#define HIPK_PICK_WIDE(M) (st == 1 ? HIPK_PICK_WIDE_S(M, 1) : HIPK_PICK_WIDE_S(M, 0))
                 pk = HIPK_PICK_WIDE(-1);
                 if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
                 if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
@@ -583,38 +583,26 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
 #undef HIPK_PICK_WIDE
 #undef HIPK_PICK_WIDE_S
-                snprintf(pname, cap, st ? "hipk_spmv_sell_wide_kernel<%d,%d,true>" : "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
+                snprintf(pname, cap, st == 1 ? "hipk_spmv_sell_wide_kernel<%d,%d,groups>" : "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
                          (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1);
                 return pk;
             };
-            // STRIDED form of that kernel: a persistent grid whose workgroups sweep each XCD's eighth of the tiles together, tile
-            // sums through the combine kernel.  Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned
-            // system, which cannot fill the chip with a workgroup per chunk and used to fall to the one-row-per-lane kernel
-            // (4 M rows with the chunk size of a 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) --
-            // and (b) where a chunk spans four grid lines and more (N = 64 M on one device: 1184 -> 1131 us per CG iteration;
-            // at N = 16 M / 32 M it measured equal or slower in the CG loop: not taken there).  HIPK_SPMV_SELL_STRIDED=0|1 forces
-            // (read per launch: in-process A/B, tools/walk_probe.py)
+            // grouped walk of that kernel (WALK = 1: one workgroup per 8 consecutive tiles, tile sums through the combine kernel).
+            // Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned system, which cannot fill the chip
+            // with a workgroup per chunk and used to fall to the one-row-per-lane kernel (4 M rows with the chunk size of a
+            // 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) -- and (b) where a chunk holds 64 tiles
+            // and more (N > 16 M on one device; per CG iteration 515 -> 483 us at N = 32 M, 1106 -> 980 us at N = 64 M, where a
+            // chunk-walking workgroup fetched x three times; equal at N = 8 M / 16 M, slower at N = 4 M: not taken there).
+            // HIPK_SPMV_SELL_STRIDED=0|1 forces (read per launch: in-process A/B, tools/walk_probe.py)
             bool strided = false;
             if (wide_ok && !no_wide && h->sell_chunked != 0) {
                 const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
-                if (se ? atoi(se) != 0 : tpc >= (chunked ? 4 * HIPK_SELL_STRIDED_TPC : HIPK_SELL_STRIDED_TPC)) {
+                if (se ? atoi(se) != 0 : tpc >= (chunked ? 64 : 32)) {
                     char pname[96];
-                    void (*pk)(hipk_spmv_args) = pick_wide(true, pname, sizeof(pname));
-                    int pocc = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) != hipSuccess || pocc < 1) pocc = 0;
-                    const int per = (ntiles + 7) >> 3;                 // tiles per XCD eighth
-                    int S = (h->n_cu * pocc) >> 3;                      // resident workgroups per XCD
-                    if (S > (per + 3) / 4) S = (per + 3) / 4;           // at least four tiles each (two per wavefront pair)
-                    if (S >= 1 && (per + S - 1) / S <= 128) {           // the kernel holds <= 128 `ucode` words per workgroup
-                        strided = true;
-                        kern = pk;
-                        lgrid = 8 * S;
-                        // a vector alone beyond the 256 MiB Infinity Cache: y streams (N = 64 M: 1160 -> 1131 us per CG iteration;
-                        // at N = 16 M, where the update kernel still finds Ap there, non-temporal stores cost 3 %)
-                        const char *ne = getenv("HIPK_SPMV_NT_Y");  // read per launch: in-process A/B
-                        a.nt_y = ne ? atoi(ne) != 0 : (size_t)h->n_rows * sv > ((size_t)256 << 20);
-                        HIPK_NOTE_KERNEL("%s", pname);
-                    }
+                    kern = pick_wide(1, pname, sizeof(pname));
+                    lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
+                    strided = true;
+                    HIPK_NOTE_KERNEL("%s", pname);
                 }
             }
             if (strided) {
@@ -644,7 +632,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                                            : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
                     snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
                     if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles)
-                        pk = pick_wide(false, pname, sizeof(pname));
+                        pk = pick_wide(0, pname, sizeof(pname));
                     int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
                         (pocc * h->n_cu >= a.g || pocc >= occ)) {

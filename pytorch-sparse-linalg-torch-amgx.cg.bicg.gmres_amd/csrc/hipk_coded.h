@@ -477,7 +477,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // CHUNKED = true (large systems: about as many reduction chunks as resident workgroups): one workgroup per
 //   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
 //   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
-#define HIPK_SELL_STRIDED_TPC 32  // two-rows-per-lane kernel, strided walk: row blocks of few chunks of >= 32 tiles, any block with chunks of 128
+#define HIPK_SELL_GROUP 8      // two-rows-per-lane kernel, grouped walk (WALK = 1): tiles per workgroup
 #define HIPK_SELL_MAX_TPC 128  // tiles per chunk the chunked form holds in LDS (chunks up to 32768 rows: N = 64 M)
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
@@ -901,16 +901,25 @@ __device__ __forceinline__ double hipk_half_tree2(double2 d) {  // sums of rows 
     return d.x + d.y;
 }
 
-// STRIDED: the launch is not tied to the reduction chunks -- a persistent grid (a multiple of 8 workgroups), the S = grid / 8
-// workgroups of an XCD walk its eighth of the TILES together: workgroup j takes tiles T0 + j, T0 + j + S, ... (at most 128), so the
-// eighth is swept by one front of S tiles whose x window (and the +-1 grid line around it) stays in that XCD's L2.  A workgroup
-// that walks a chunk of 128 consecutive tiles on its own (N = 64 M) re-reads x[row +- nx] after 64 KB of its own traffic, times the
-// 244 workgroups of the XCD = 16 MB against 4 MB of L2.  It also serves row blocks with FEW chunks of many tiles (a rank of a
-// row-partitioned system: 8 M rows in 244 chunks), which cannot fill the chip with a workgroup per chunk.  The wavefront sums of
-// the fused dots go to the per-tile buffer and hipk_tile_combine_kernel folds them (same fold, same bits).
-template <int UNITS, int MODE = -1, bool STRIDED = false>
+// WALK = 1 (groups): the launch is not tied to the reduction chunks -- one workgroup per GROUP of 8 consecutive tiles on an ordinary
+// grid, XCD k taking the k-th eighth of the groups; the wavefront sums of the fused dots go to the per-tile buffer and
+// hipk_tile_combine_kernel folds them (same fold, same bits).  Two uses.
+// (a) Row blocks with FEW chunks of many tiles (a rank of a row-partitioned system: 4 M rows in 245 chunks), which cannot fill the
+//     chip with a workgroup per chunk and used to fall to the one-row-per-lane kernel.
+// (b) Chunks of 64 tiles and more (N > 16 M on one device).  Counters of the N = 64 M matrix (profiles/r02_spmv_n64m_counters.md):
+//     with a workgroup per chunk of 128 consecutive tiles every one of the three x streams of the stencil (rows -nx, 0, +nx) was
+//     fetched from beyond L2 (FETCH_SIZE 1.58 GB per product for a 0.51 GB vector): a workgroup re-reads x[row +- nx] after 64 KB of
+//     its own traffic, times the 244 workgroups of an XCD = 16 MB against 4 MB of L2.  A persistent grid with the workgroups of an
+//     XCD statically interleaved over its eighth did no better (1.45 GB): memory-bound workgroups, unsynchronised over 61 trips,
+//     drift apart by more tiles than that L2 holds.  Handing the tiles out by a per-XCD ticket counter proved the point (0.53 GB: x
+//     once) and was 4.4 x SLOWER -- 125 k device-scope atomics on one line, 12 ns each.  The hardware dispatcher is the cheaper
+//     ticket counter: it starts workgroups in ascending order as slots free up, so with short groups the tiles in flight in an XCD
+//     are one compact front whatever the drift, and the re-reads of x[row +- nx] come from workgroups in flight at the same time
+//     (the shape that works at N = 4 M, where a chunk IS 8 tiles): 0.53 GB fetched, 397 -> 273 us in the CG loop.
+template <int UNITS, int MODE = -1, int WALK = 0>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
     typedef double T;
+    constexpr bool STRIDED = WALK != 0;  // tile sums to the per-tile buffer, no in-kernel fold
     constexpr int G0 = (UNITS + 3) / 4;
     constexpr int NE = UNITS == 5 ? 5 : (UNITS == 4 ? 4 : 8);
     static_assert(UNITS == 4 || UNITS == 5 || UNITS == 8, "exact tile sizes only");
@@ -918,19 +927,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     const int tpc = a.ch / HIPK_TILE;
     const int chunk = STRIDED ? 0 : hipk_xcd_chunk(blockIdx.x, a.g);
     if (chunk < 0) return;
-    // local tile i of this workgroup is tile t_first + i * t_step, i < cnt
-    int t_first = chunk * tpc, t_step = 1;
+    // local tile i of this workgroup is tile t_first + i, i < cnt
+    int t_first = chunk * tpc;
     int cnt = ((t_first + tpc < ntiles) ? t_first + tpc : ntiles) - t_first;
-    if (STRIDED) {
-        const int per = (ntiles + 7) >> 3;  // tiles per XCD eighth
-        const int S = (int)gridDim.x >> 3;  // workgroups per XCD (the grid is a multiple of 8; the host keeps per / S <= 128)
-        const int T0 = (blockIdx.x & 7) * per;
-        const int T1 = (T0 + per < ntiles) ? T0 + per : ntiles;
-        t_first = T0 + ((int)blockIdx.x >> 3);
-        t_step = S;
-        cnt = (T1 - t_first + S - 1) / S;
-        if (cnt < 0) cnt = 0;
-        if (cnt > 2 * 64) cnt = 2 * 64;  // never: host-side guard (two `ucode` words per lane)
+    if (WALK == 1) {
+        const int ngroups = (ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP;
+        const int grp = hipk_xcd_chunk(blockIdx.x, ngroups);
+        if (grp < 0) return;
+        t_first = grp * HIPK_SELL_GROUP;
+        cnt = (t_first + HIPK_SELL_GROUP < ntiles ? t_first + HIPK_SELL_GROUP : ntiles) - t_first;
     }
     __shared__ double wsum0[STRIDED ? 1 : HIPK_SELL_MAX_TPC * 4];
     __shared__ double wsum1[STRIDED ? 1 : HIPK_SELL_MAX_TPC * 4];
@@ -948,8 +953,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     const T *__restrict__ g_dval = (const T *)a.dict_val;
 
     unsigned long long uc_mine = 0ull, uc_more = 0ull;  // requested first: complete before the dictionary reaches LDS (loads
-    if (lane < cnt) uc_mine = ucode[t_first + lane * t_step];                                        // return in order)
-    if ((STRIDED || tpc > 64) && lane + 64 < cnt) uc_more = ucode[t_first + (64 + lane) * t_step];
+    if (lane < cnt) uc_mine = ucode[t_first + lane];                                                 // return in order)
+    if (!STRIDED && tpc > 64 && lane + 64 < cnt) uc_more = ucode[t_first + 64 + lane];
     T dv = (T)0;
     int dofs = 0;
     if (t < a.n_codes) {
@@ -969,10 +974,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(src >> 32), i & 63) << 32);
     };
 
-    // ---- the tiles whose rows differ: one row per lane, codes from the planes (as hipk_spmv_sell_pair_kernel, one tile per trip)
-    for (int i = 0; i < cnt; ++i) {
-        if (tile_ucode_of(i) != 0ull) continue;
-        const int tl = t_first + i * t_step;
+    // ---- a tile whose rows differ: one row per lane, codes from the planes (as hipk_spmv_sell_pair_kernel, one tile per trip);
+    // whole workgroup.  i = the tile's local index (WALK 0: its slots of the LDS sums)
+    auto per_lane_tile = [&](int tl, int i) {
         unsigned c[G0];
         {
             const unsigned char *tp = code + (size_t)tl * (UNITS * HIPK_TILE);
@@ -1037,105 +1041,104 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
                 else wsum1[slot] = d1;
             }
         }
-    }
+    };
 
-    // ---- the uniform tiles of this wavefront pair's parity: two rows per lane
-    {
-        const int wp = wave >> 1, wh = wave & 1;
-        unsigned long long cur = 0ull;
-        const bool w_is_x = (mode & HIPK_SPMV_DOT_W) && a.w == a.x;  // <x, A x> (the CG loop): w is the diagonal entry's operand
-        int kc = -1;        // entry with offset 0, if any
-        long long sbo[NE];  // byte offset of entry k (scalar)
-        T sv[NE];           // its value (scalar)
+    // ---- a uniform tile: two rows per lane, one wavefront PAIR per tile (wh = this wavefront's half of the tile)
+    const int wp = wave >> 1, wh = wave & 1;
+    unsigned long long cur = 0ull;
+    const bool w_is_x = (mode & HIPK_SPMV_DOT_W) && a.w == a.x;  // <x, A x> (the CG loop): w is the diagonal entry's operand
+    int kc = -1;        // entry with offset 0, if any
+    long long sbo[NE];  // byte offset of entry k (scalar)
+    T sv[NE];           // its value (scalar)
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        sbo[k] = 0;
+        sv[k] = (T)0;
+    }
+    auto uniform_tile = [&](int tl, int i, unsigned long long uc) {
+        if (uc != cur) {
+            cur = uc;
+            kc = -1;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+                const int ci = ck == HIPK_SELL_PAD ? 0 : (int)ck;
+                sbo[k] = (long long)__builtin_amdgcn_readfirstlane(doff[ci]) * (long long)sizeof(T);
+                if (ck != HIPK_SELL_PAD && sbo[k] == 0) kc = k;
+                const double v = dval[ci];
+                sv[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                         __builtin_amdgcn_readfirstlane(__double2loint(v)));
+            }
+        }
+        const int r0 = tl * HIPK_TILE + wh * 128 + 2 * lane;
+        const unsigned vo = (unsigned)r0 * (unsigned)sizeof(T);
+        double2 xv[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            sbo[k] = 0;
-            sv[k] = (T)0;
+            const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+            if (ck != HIPK_SELL_PAD) xv[k] = *(const double2 *)(xb + sbo[k] + vo);
         }
-        for (int i = wp; i < cnt; i += 2) {
-            const unsigned long long uc = tile_ucode_of(i);
-            if (uc == 0ull) continue;
-            const int tl = t_first + i * t_step;
-            if (uc != cur) {
-                cur = uc;
-                kc = -1;
+        double2 ow = {0.0, 0.0}, ob = {0.0, 0.0}, od = {0.0, 0.0};
+        if (mode & HIPK_SPMV_DOT_W) {
+            if (w_is_x && kc >= 0) {
 #pragma unroll
-                for (int k = 0; k < NE; ++k) {
-                    const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
-                    const int ci = ck == HIPK_SELL_PAD ? 0 : (int)ck;
-                    sbo[k] = (long long)__builtin_amdgcn_readfirstlane(doff[ci]) * (long long)sizeof(T);
-                    if (ck != HIPK_SELL_PAD && sbo[k] == 0) kc = k;
-                    const double v = dval[ci];
-                    sv[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
-                }
-            }
-            const int r0 = tl * HIPK_TILE + wh * 128 + 2 * lane;
-            const unsigned vo = (unsigned)r0 * (unsigned)sizeof(T);
-            double2 xv[NE];
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
-                if (ck != HIPK_SELL_PAD) xv[k] = *(const double2 *)(xb + sbo[k] + vo);
-            }
-            double2 ow = {0.0, 0.0}, ob = {0.0, 0.0}, od = {0.0, 0.0};
-            if (mode & HIPK_SPMV_DOT_W) {
-                if (w_is_x && kc >= 0) {
-#pragma unroll
-                    for (int k = 0; k < NE; ++k)
-                        if (k == kc) ow = xv[k];
-                } else {
-                    ow = *(const double2 *)((const char *)a.w + vo);
-                }
-            }
-            if (mode & HIPK_SPMV_RESID) ob = *(const double2 *)((const char *)a.bsub + vo);
-            if (mode & HIPK_SPMV_SCALE) od = *(const double2 *)((const char *)a.dscale + vo);
-            double2 s = {0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
-                if (ck != HIPK_SELL_PAD) {
-                    const double px = sv[k] * xv[k].x, py = sv[k] * xv[k].y;
-                    s.x = s.x + px;
-                    s.y = s.y + py;
-                }
-            }
-            double2 out = s;
-            if (mode & HIPK_SPMV_RESID) {
-                out.x = ob.x - out.x;
-                out.y = ob.y - out.y;
-            }
-            if (mode & HIPK_SPMV_SCALE) {
-                out.x = od.x * out.x;
-                out.y = od.y * out.y;
-            }
-            if (STRIDED && a.nt_y) {
-                typedef double d2n __attribute__((ext_vector_type(2)));
-                d2n o2;
-                o2.x = out.x;
-                o2.y = out.y;
-                __builtin_nontemporal_store(o2, (d2n *)((char *)y + vo));
+                for (int k = 0; k < NE; ++k)
+                    if (k == kc) ow = xv[k];
             } else {
-                *(double2 *)((char *)y + vo) = out;
-            }
-            const int slot = i * 4 + 2 * wh + (lane >> 5);
-            if (mode & HIPK_SPMV_DOT_W) {
-                double2 d = {ow.x * out.x, ow.y * out.y};
-                const double r = hipk_half_tree2(d);
-                if ((lane & 31) == 0) {
-                    if (STRIDED) a.tpart0[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
-                    else wsum0[slot] = r;
-                }
-            }
-            if (mode & HIPK_SPMV_DOT_YY) {
-                double2 d = {out.x * out.x, out.y * out.y};
-                const double r = hipk_half_tree2(d);
-                if ((lane & 31) == 0) {
-                    if (STRIDED) a.tpart1[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
-                    else wsum1[slot] = r;
-                }
+                ow = *(const double2 *)((const char *)a.w + vo);
             }
         }
+        if (mode & HIPK_SPMV_RESID) ob = *(const double2 *)((const char *)a.bsub + vo);
+        if (mode & HIPK_SPMV_SCALE) od = *(const double2 *)((const char *)a.dscale + vo);
+        double2 s = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
+            if (ck != HIPK_SELL_PAD) {
+                const double px = sv[k] * xv[k].x, py = sv[k] * xv[k].y;
+                s.x = s.x + px;
+                s.y = s.y + py;
+            }
+        }
+        double2 out = s;
+        if (mode & HIPK_SPMV_RESID) {
+            out.x = ob.x - out.x;
+            out.y = ob.y - out.y;
+        }
+        if (mode & HIPK_SPMV_SCALE) {
+            out.x = od.x * out.x;
+            out.y = od.y * out.y;
+        }
+        *(double2 *)((char *)y + vo) = out;
+        const int slot = i * 4 + 2 * wh + (lane >> 5);
+        if (mode & HIPK_SPMV_DOT_W) {
+            double2 d = {ow.x * out.x, ow.y * out.y};
+            const double r = hipk_half_tree2(d);
+            if ((lane & 31) == 0) {
+                if (STRIDED) a.tpart0[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
+                else wsum0[slot] = r;
+            }
+        }
+        if (mode & HIPK_SPMV_DOT_YY) {
+            double2 d = {out.x * out.x, out.y * out.y};
+            const double r = hipk_half_tree2(d);
+            if ((lane & 31) == 0) {
+                if (STRIDED) a.tpart1[(size_t)tl * 4 + 2 * wh + (lane >> 5)] = r;
+                else wsum1[slot] = r;
+            }
+        }
+    };
+
+    // ---- the tiles whose rows differ first, whole workgroup
+    for (int i = 0; i < cnt; ++i) {
+        if (tile_ucode_of(i) != 0ull) continue;
+        per_lane_tile(t_first + i, i);
+    }
+    // ---- the uniform tiles of this wavefront pair's parity
+    for (int i = wp; i < cnt; i += 2) {
+        const unsigned long long uc = tile_ucode_of(i);
+        if (uc == 0ull) continue;
+        uniform_tile(t_first + i, i, uc);
     }
     if (!STRIDED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();

@@ -64,8 +64,6 @@ struct hipk_spmv_args {
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
     int skip_combine;       // small systems: leave the fused dots as per-wavefront tile sums (hipk_csr_s::tile_part); the
                             //   consumer folds them itself (hipk_fold_tiles8) -- one launch less per SpMV
-    int nt_y;               // strided two-rows-per-lane kernel: y is written with non-temporal stores (vectors beyond the Infinity
-                            //   Cache: the written lines are not kept where the front's x lines wait for their re-reads)
 };
 
 #ifdef __HIPCC__

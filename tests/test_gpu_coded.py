@@ -280,8 +280,9 @@ def _spmv_ex_mode(hipk, h, mode, x, w, b):
                                      [-9000, -1500, -1, 0, 1, 1500, 9000], [-9000, -1500, -2, -1, 0, 1, 1500, 9000]])
 @pytest.mark.parametrize("strided", ["0", "1"])
 def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeypatch):
-    """strided = 1: the workgroups of an XCD sweep its eighth together (tile sums through hipk_tile_combine_kernel), the walk
-    of systems whose chunks span several grid lines (N >= 16 M), forced here at a size the CPU oracle checks in seconds.
+    """strided = 1: the kernel's grouped walk (one workgroup per 8 consecutive tiles on an ordinary grid, tile sums through
+    hipk_tile_combine_kernel) -- what row blocks of few large chunks and systems of N > 16 M take -- forced here at a size the
+    CPU oracle checks in seconds.
     hipk_spmv_sell_wide_kernel (chunk-per-workgroup sizes, fp64, most tiles uniform): uniform tiles from 16-byte accesses, two
     rows per lane, the fused dots' 64-row sums on that layout; tile widths 3-4, 5 and 7-8, a partial last tile, uniform tiles
     with padding (the first and last rows of the band lack entries), an offset list without a diagonal.  Every mode the solvers
@@ -297,7 +298,7 @@ def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeyp
     runs = [(0, x, w), (1, x, x), (1, x, w), (2, x, w), (7, x, w), (6, x, w), (3, x, w)]
     coded = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
     assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_sell_wide_kernel"), hipk.CsrHandle.last_spmv_kernel()
-    assert hipk.CsrHandle.last_spmv_kernel().endswith(",true>") == (strided == "1"), hipk.CsrHandle.last_spmv_kernel()
+    assert hipk.CsrHandle.last_spmv_kernel().endswith(",groups>") == (strided == "1"), hipk.CsrHandle.last_spmv_kernel()
     h.set_path(plain_only=True)
     plain = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
     assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_kernel")
@@ -314,13 +315,12 @@ def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeyp
 @pytest.mark.parametrize("nx", [4000, 8000])
 def test_many_grid_lines_per_chunk_coded_equals_plain(hipk, nx, monkeypatch):
     """BASELINE config 5's matrix on ONE device (nx = 8000: N = 64 M, reduction chunks of 128 tiles = four grid lines) and
-    N = 16 M (32 tiles, strided walk forced): the two-rows-per-lane kernel's strided walk; 25 CG iterations (fused <p, Ap>, the
-    residual form at the end) bitwise equal to the general CSR kernels, which the small-size tests tie to the oracle; and
-    the CG property r_k = b - A x_k to rounding, checked with the plain kernels' SpMV."""
+    N = 16 M (chunks of 32 tiles, grouped walk forced): the two-rows-per-lane kernel's grouped walk; 25 CG iterations (fused
+    <p, Ap>, the residual form at the end) bitwise equal to the general CSR kernels, which the small-size tests tie to the
+    oracle; and the CG property r_k = b - A x_k to rounding, checked with the plain kernels' SpMV."""
     from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
     if nx < 8000:
         monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", "1")                 # nx = 8000 takes it by default
-        monkeypatch.setenv("HIPK_SPMV_NT_Y", "1")                         # as do the non-temporal stores of y
     A = create_poisson_2d_csr(nx, nx, device=DEV)
     n = nx * nx
     h = hipk.CsrHandle(A.crow_indices(), A.col_indices(), A.values(), A.shape)
@@ -334,7 +334,7 @@ def test_many_grid_lines_per_chunk_coded_equals_plain(hipk, nx, monkeypatch):
         res[plain] = (x, st.iterations, st.info, st.residual_norm)
         if not plain:
             k = hipk.CsrHandle.last_spmv_kernel()
-            assert k.startswith("hipk_spmv_sell_wide_kernel") and k.endswith(",true>"), k
+            assert k.startswith("hipk_spmv_sell_wide_kernel") and k.endswith(",groups>"), k
     assert torch.equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
     y = torch.empty_like(b)
     hipk.spmv(h, res[True][0], out=y)                                     # plain kernels (path still plain_only)

@@ -45,9 +45,9 @@ HOT = {
                        "void hipk_gm_normalize_kernel<double>"],
     "hipk_api.hip": ["void hipk_spmv_kernel<double, 1280, true>", "void hipk_spmv_sell_pair_kernel<double, 5, true, 1>",
                      "void hipk_spmv_sell_pair_kernel<double, 5, true, 2>", "void hipk_spmv_sell_pair_kernel<double, 5, true, -1>",
-                     "void hipk_spmv_sell_wide_kernel<5, 1, false>", "void hipk_spmv_sell_wide_kernel<5, 2, false>",
-                     "void hipk_spmv_sell_wide_kernel<5, -1, false>", "void hipk_spmv_sell_wide_kernel<5, 1, true>",
-                     "void hipk_spmv_sell_wide_kernel<5, 2, true>", "void hipk_spmv_sell_wide_kernel<5, -1, true>"],
+                     "void hipk_spmv_sell_wide_kernel<5, 1, 0>", "void hipk_spmv_sell_wide_kernel<5, 2, 0>",
+                     "void hipk_spmv_sell_wide_kernel<5, -1, 0>", "void hipk_spmv_sell_wide_kernel<5, 1, 1>",
+                     "void hipk_spmv_sell_wide_kernel<5, 2, 1>", "void hipk_spmv_sell_wide_kernel<5, -1, 1>"],
 }
 
 

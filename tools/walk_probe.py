@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Coded SpMV on Poisson grids whose reduction chunks span several grid lines (nx = 4000: chunk = 32 tiles = 2 grid lines,
 nx = 8000 = BASELINE config 5 on one GPU: chunk = 128 tiles = 4 grid lines): the two-rows-per-lane kernel with every workgroup
-walking its own chunk (HIPK_SPMV_SELL_STRIDED=0) against the workgroups of an XCD sweeping its eighth together (=1; y written
-with ordinary or non-temporal stores, HIPK_SPMV_NT_Y), in ONE process (the switches are read per launch); stand-alone SpMV, SpMV inside the CG loop, CG time per iteration, x of 200 iterations
-bitwise equal.  HIPK_SPMV_SELL_CHUNKED=0 in the environment measures the one-row-per-lane persistent kernel instead."""
+walking its own chunk (HIPK_SPMV_SELL_STRIDED=0) against one workgroup per group of 8 tiles on an ordinary grid (=1) and the
+library's own choice (unset), in ONE process (the switch is read per launch); stand-alone SpMV, SpMV inside the CG loop, CG
+time per iteration, x of 200 iterations bitwise equal.  HIPK_SPMV_SELL_CHUNKED=0 in the environment measures the
+one-row-per-lane persistent kernel instead."""
 import hashlib
 import json
 import os
@@ -26,15 +27,11 @@ for nx in [int(v) for v in (sys.argv[1:] or ["8000"])]:
     yr = torch.empty_like(xr)
     reps = max(20, int(4e8 // n))
     digests = {}
-    settings = (("0", None), ("1", "0"), ("1", "1"), (None, None))
-    if os.environ.get("WALK_SETTINGS"):  # e.g. "0:,1:1" (strided:nt_y; empty = unset): counter passes, one kernel name per setting
-        settings = tuple(tuple(v or None for v in item.split(":")) for item in os.environ["WALK_SETTINGS"].split(","))
-    for strided, nt in settings:
-        for k, v in (("HIPK_SPMV_SELL_STRIDED", strided), ("HIPK_SPMV_NT_Y", nt)):
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for strided in ("0", "1", None):
+        if strided is None:
+            os.environ.pop("HIPK_SPMV_SELL_STRIDED", None)
+        else:
+            os.environ["HIPK_SPMV_SELL_STRIDED"] = strided
         for _ in range(5):
             _hipk.spmv(h, xr, out=yr)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,8 +55,8 @@ for nx in [int(v) for v in (sys.argv[1:] or ["8000"])]:
         x.zero_()
         pst = _hipk.solve("cg", h, b, x, tol=1e-12, atol=0.0, maxiter=128, profile=True)
         kern = _hipk.CsrHandle.last_spmv_kernel()
-        digests[(strided, nt)] = (ysum, xd)
-        print(json.dumps({"nx": nx, "strided": strided, "nt_y": nt, "chunked_env": os.environ.get("HIPK_SPMV_SELL_CHUNKED"),
+        digests[strided] = (ysum, xd)
+        print(json.dumps({"nx": nx, "strided": strided, "chunked_env": os.environ.get("HIPK_SPMV_SELL_CHUNKED"),
                           "kernel": kern, "kernel_alone": kern_alone, "format_MB": round(h.format_bytes() / 1e6, 1) if hasattr(h, "format_bytes") else None,
                           "spmv_alone_us": round(alone, 2), "spmv_in_cg_us": round(pst.spmv_ms_avg * 1e3, 2),
                           "cg_us_per_iter": round(dt / st.iterations * 1e6, 2), "y_sha": ysum, "x_sha": xd}), flush=True)
