@@ -583,8 +583,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
 #undef HIPK_PICK_WIDE
 #undef HIPK_PICK_WIDE_S
-                snprintf(pname, cap, st == 1 ? "hipk_spmv_sell_wide_kernel<%d,%d,groups>" : "hipk_spmv_sell_wide_kernel<%d,%d>", h->sell_w,
-                         (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1);
+                snprintf(pname, cap, "hipk_spmv_sell_wide_kernel<%d,%d,%d>", h->sell_w,  // the template arguments, as a profiler prints them
+                         (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1, st);
                 return pk;
             };
             // grouped walk of that kernel (WALK = 1: one workgroup per 8 consecutive tiles, tile sums through the combine kernel).

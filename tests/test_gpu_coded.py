@@ -298,7 +298,7 @@ def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeyp
     runs = [(0, x, w), (1, x, x), (1, x, w), (2, x, w), (7, x, w), (6, x, w), (3, x, w)]
     coded = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
     assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_sell_wide_kernel"), hipk.CsrHandle.last_spmv_kernel()
-    assert hipk.CsrHandle.last_spmv_kernel().endswith(",groups>") == (strided == "1"), hipk.CsrHandle.last_spmv_kernel()
+    assert hipk.CsrHandle.last_spmv_kernel().endswith("," + strided + ">"), hipk.CsrHandle.last_spmv_kernel()
     h.set_path(plain_only=True)
     plain = [_spmv_ex_mode(hipk, h, m, xx, ww, b) for m, xx, ww in runs]
     assert hipk.CsrHandle.last_spmv_kernel().startswith("hipk_spmv_kernel")
@@ -334,7 +334,7 @@ def test_many_grid_lines_per_chunk_coded_equals_plain(hipk, nx, monkeypatch):
         res[plain] = (x, st.iterations, st.info, st.residual_norm)
         if not plain:
             k = hipk.CsrHandle.last_spmv_kernel()
-            assert k.startswith("hipk_spmv_sell_wide_kernel") and k.endswith(",groups>"), k
+            assert k.startswith("hipk_spmv_sell_wide_kernel") and k.endswith(",1>"), k   # WALK = 1: groups
     assert torch.equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
     y = torch.empty_like(b)
     hipk.spmv(h, res[True][0], out=y)                                     # plain kernels (path still plain_only)

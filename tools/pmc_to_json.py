@@ -4,7 +4,7 @@ usage: python tools/pmc_to_json.py gpurun_out/<name> profiles/<out>.json [--comm
 Launches that returned at once (iterations past the stop word, unwanted second CGS passes) are dropped: only launches whose
 counter is at least half of the kernel's maximum enter the mean -- except for the GMRES kernels, whose traffic grows with the
 Arnoldi step (every launch above 1 % of the maximum counts there; the mean is then the mean over a restart cycle).
-traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes): gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
+traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; until call 29 of round 2 this script multiplied by 1000 and read 2.3 % low): gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact.  `commit` = the code the counters were taken on (bench.py prints it as
 `traffic_from_commit` and drops the traffic when the kernel that ran is another one)."""
 import collections, csv, glob, json, os, subprocess, sys
@@ -49,6 +49,8 @@ def means(counter_dir, counter):
                 if pat in name:
                     top = max(v)
                     real = [a for a in v if a >= (0.01 if cyc else 0.5) * top]
+                    if key in out and out[key]["launches"] >= len(real):
+                        continue  # several instantiations match: the one launched most often (the solver loop's) stands for the key
                     out[key] = {"kernel": name.split("(")[0].replace("void ", ""), "mean_KB": sum(real) / len(real),
                                 "launches": len(real), "dropped_noop_launches": len(v) - len(real)}
     return out
@@ -62,10 +64,11 @@ for key in fetch:
     kern[key] = {"kernel": fetch[key]["kernel"], "FETCH_SIZE_KB_mean": fetch[key]["mean_KB"],
                  "WRITE_SIZE_KB_mean": w["mean_KB"], "launches": fetch[key]["launches"],
                  "dropped_noop_launches": fetch[key]["dropped_noop_launches"],
-                 "traffic_bytes_per_launch": int(round((2.0 * fetch[key]["mean_KB"] + w["mean_KB"]) * 1000.0)),
+                 "traffic_bytes_per_launch": int(round((2.0 * fetch[key]["mean_KB"] + w["mean_KB"]) * 1024.0)),
                  "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_are": what}
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({src})", "commit": commit,
            "fetch_correction": 2.0,
-           "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE; counters are KB (1000 B); FETCH_SIZE includes Infinity-Cache hits",
+           "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE; counters are KiB (1024 B: WRITE_SIZE of a 32,000,000-byte vector reads 31250.0); "
+                   "FETCH_SIZE includes Infinity-Cache hits",
            "kernels": kern}, open(dst, "w"), indent=1)
 print(json.dumps(kern, indent=1))
