@@ -605,6 +605,19 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     HIPK_NOTE_KERNEL("%s", pname);
                 }
             }
+            // the same walk for the matrices that kernel does not take (fp32 storage, value planes, few uniform tiles): the
+            // one-row-per-lane chunk kernel on a grid of groups, same sizes, same switch
+            a.group_tiles = 0;
+            if (!strided && h->sell_chunked != 0) {
+                const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
+                if (se ? atoi(se) != 0 : tpc >= (chunked ? 64 : 32)) {
+                    kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
+                    a.group_tiles = HIPK_SELL_GROUP;
+                    lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
+                    strided = true;
+                    HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>/groups", tname, uw, vls, uni);
+                }
+            }
             if (strided) {
                 // kern, lgrid: set above
             } else if (chunked) {

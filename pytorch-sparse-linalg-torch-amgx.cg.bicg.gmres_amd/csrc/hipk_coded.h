@@ -492,10 +492,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     const int xcd = blockIdx.x & 7;
     int idx = blockIdx.x >> 3;               // position inside the eighth; advances by gp
     const int tpc = a.ch / HIPK_TILE;        // tiles per reduction chunk
-    const int chunk = CHUNKED ? hipk_xcd_chunk(blockIdx.x, a.g) : 0;
+    // CHUNKED with a.group_tiles > 0 (a scalar: no further instantiations): the workgroup takes a GROUP of that many consecutive
+    // tiles instead of a reduction chunk, on a grid of groups, and leaves the fold to the combine kernel -- the grouped walk of
+    // hipk_spmv_sell_wide_kernel (see there: chunks of many tiles re-fetch x[row +- nx] from beyond L2) for the matrices that
+    // kernel does not take (fp32 storage, value planes, few uniform tiles)
+    const int gt = CHUNKED ? a.group_tiles : 0;
+    const int wtiles = gt > 0 ? gt : tpc;  // tiles per workgroup
+    const int chunk = CHUNKED ? hipk_xcd_chunk(blockIdx.x, gt > 0 ? (ntiles + gt - 1) / gt : a.g) : 0;
     if (CHUNKED && chunk < 0) return;
-    const int t_first = chunk * tpc;
-    const int t_end = (t_first + tpc < ntiles) ? t_first + tpc : ntiles;  // CHUNKED: this workgroup's tiles
+    const int t_first = chunk * wtiles;
+    const int t_end = (t_first + wtiles < ntiles) ? t_first + wtiles : ntiles;  // CHUNKED: this workgroup's tiles
     __shared__ double wsum0[CHUNKED ? HIPK_SELL_MAX_TPC * 4 : 1];
     __shared__ double wsum1[CHUNKED ? HIPK_SELL_MAX_TPC * 4 : 1];
 
@@ -685,13 +691,13 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
         if (mode & HIPK_SPMV_DOT_W) {
             d0 = hipk_wave_sum(d0);
             if (lane == 0) {
-                if (CHUNKED) wsum0[slot] = d0; else a.tpart0[tpi] = d0;
+                if (CHUNKED && gt == 0) wsum0[slot] = d0; else a.tpart0[tpi] = d0;
             }
         }
         if (mode & HIPK_SPMV_DOT_YY) {
             d1 = hipk_wave_sum(d1);
             if (lane == 0) {
-                if (CHUNKED) wsum1[slot] = d1; else a.tpart1[tpi] = d1;
+                if (CHUNKED && gt == 0) wsum1[slot] = d1; else a.tpart1[tpi] = d1;
             }
         }
         rc = rn;
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
             un = u2;
         }
     }
-    if (CHUNKED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
+    if (CHUNKED && gt == 0 && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();
         if (wave == 0) {  // the combine kernel's fold, on the LDS copy of this chunk's wavefront sums
             const int cnt = t_end - t_first;

@@ -62,6 +62,8 @@ struct hipk_spmv_args {
     const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
     const unsigned long long *tile_ucode;  // per tile: the 8 code bytes every row of the tile shares, 0 = rows differ
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
+    int group_tiles;        // hipk_spmv_sell_loop_kernel<.., CHUNKED = true>: > 0 = tiles per workgroup on a grid of groups (set by the
+                            //   launcher), 0 = a workgroup per reduction chunk
     int skip_combine;       // small systems: leave the fused dots as per-wavefront tile sums (hipk_csr_s::tile_part); the
                             //   consumer folds them itself (hipk_fold_tiles8) -- one launch less per SpMV
 };

@@ -209,8 +209,12 @@ def main():
     else:
         solve = dist_bicgstab if solver == "bicgstab" else dist_cg
         x_loc, info, st = solve(prob, tol=tol, maxiter=None if maxiter < 0 else maxiter, check_every=7)
+    kname = ""
+    if use_hip:
+        from pytorch_sparse_solver import _hipk
+        kname = _hipk.CsrHandle.last_spmv_kernel()      # the SpMV kernel this rank's last launch selected
     pieces = [None] * world
-    dist.all_gather_object(pieces, (part.row0, x_loc.cpu().numpy().copy(), info, st.iterations, st.residual_norm))
+    dist.all_gather_object(pieces, (part.row0, x_loc.cpu().numpy().copy(), info, st.iterations, st.residual_norm, kname))
     if rank == 0:
         x = np.concatenate([p[1] for p in sorted(pieces, key=lambda q: q[0])])
         if solver.startswith("gmres"):
@@ -223,7 +227,8 @@ def main():
                "iterations": [p[3] for p in pieces], "ref_iterations": ref.iterations,
                "residual_norm": [p[4] for p in pieces], "ref_residual_norm": ref.residual_norm,
                "n_local": [int(p[1].size) for p in sorted(pieces, key=lambda q: q[0])],
-               "n_ghost": prob.plan.n_ghost, "chunk": part.ch, "chunks": part.g}
+               "n_ghost": prob.plan.n_ghost, "chunk": part.ch, "chunks": part.g,
+               "spmv_kernel": [p[5] for p in sorted(pieces, key=lambda q: q[0])]}
         with open(out, "w") as f:
             json.dump(res, f)
     dist.destroy_process_group()

@@ -186,3 +186,21 @@ dist.destroy_process_group()
     assert r["equal"] and r["info"] == r["info_r"] == 0 and r["it"] == r["it_r"] and r["res"] == r["res_r"], r
     assert r["bi_equal"] and r["bi_info"] == [0, 0] and r["bi_it"][0] == r["bi_it"][1], r
     assert r["gm_equal"] and r["gm_info"][0] == r["gm_info"][1] and r["gm_it"][0] == r["gm_it"][1], r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strided", ["0", "1"])
+@pytest.mark.parametrize("kind,solver,maxiter", [("poisson", "cg", 20), ("convdiff", "bicgstab", 10), ("convdiff", "gmres", 1)])
+def test_dist_large_row_blocks_take_the_two_rows_per_lane_kernel(kind, solver, maxiter, strided, tmp_path, monkeypatch):
+    """Row blocks of the size a GPU really gets (1536 x 1500 grid, 1.15 M rows per rank, two ranks sharing cuda:0, host-staged
+    collectives): the local matrices -- square interior plus halo columns -- take the coded SpMV's two-rows-per-lane kernel, with
+    the chunk walk (HIPK_SPMV_SELL_STRIDED=0) and with the grouped walk that a rank of a 4- / 8-rank run takes (=1; tile sums
+    through the combine kernel into the rank's slice of the global partials).  A few iterations of each row-partitioned solver,
+    bitwise equal to the single-rank oracle solve."""
+    monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", strided)
+    r = _run(2, kind, 1536, 1500, 1e-12, maxiter, tmp_path, mode="native", solver=solver)
+    assert r["bitwise_equal"], {k: v for k, v in r.items() if k != "residual_norm"}
+    assert set(r["info"]) == {r["ref_info"]} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+    for k in r["spmv_kernel"]:
+        assert k.startswith("hipk_spmv_sell_wide_kernel") and k.endswith("," + strided + ">"), r["spmv_kernel"]

@@ -391,8 +391,12 @@ def test_offset_coded_random_values_all_widths(hipk, oracle, n, offsets, chunked
     assert n < 1000 or h.format_bytes() < h.spmv_bytes()                     # tiny systems are all tile padding
 
 
-def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle):
+@pytest.mark.parametrize("groups", ["0", "1"])
+def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle, groups, monkeypatch):
+    """groups = 1: the one-row-per-lane chunk kernel on a grid of groups of 8 tiles (what it takes at N > 16 M and on a rank's
+    row block: hipk_spmv_args::group_tiles), forced at this size; value planes, fp64 and fp32 storage."""
     from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+    monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", groups)
     A = create_variable_diffusion_2d_csr(1500, 1500, device=DEV)             # 2.25M rows: chunked persistent kernel
     n = A.shape[0]
     h = hipk.handle_for(A)
@@ -400,6 +404,7 @@ def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle):
     g = torch.Generator(device=DEV).manual_seed(7)
     x, w, b = (torch.randn(n, dtype=torch.float64, device=DEV, generator=g) for _ in range(3))
     coded = _spmv_ex_all_modes(hipk, h, x, w, b)
+    assert hipk.CsrHandle.last_spmv_kernel().endswith("/groups") == (groups == "1"), hipk.CsrHandle.last_spmv_kernel()
     res = {}
     for plain in (False, True):
         h.set_path(plain_only=plain)
@@ -419,6 +424,36 @@ def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle):
     x32 = x.float()
     y32, y32p = both_paths(hipk, h32, x32, expect="offset_coded")
     assert np.array_equal(y32, y32p) and np.array_equal(y32, oracle.spmv32(crow, col, val.astype(np.float32), x32.cpu().numpy()))
+
+
+@pytest.mark.parametrize("groups", ["0", "1"])
+def test_fp32_storage_poisson_chunk_and_group_walks(hipk, groups, monkeypatch):
+    """fp32 storage of the headline matrix's kind (1500 x 1500 Poisson: pair codes, uniform tiles, but not the fp64-only
+    two-rows-per-lane kernel): the one-row-per-lane kernels with a workgroup per chunk and, forced, per group of 8 tiles; 30 CG
+    iterations and all fused-dot modes bitwise equal to the general CSR kernels."""
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", groups)
+    A = create_poisson_2d_csr(1500, 1500, device=DEV)
+    A32 = torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
+    n = A.shape[0]
+    h = hipk.handle_for(A32)
+    assert h.path() == "coded"
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x, w, b = (torch.randn(n, dtype=torch.float32, device=DEV, generator=g) for _ in range(3))
+    coded = _spmv_ex_all_modes(hipk, h, x, w, b)
+    k = hipk.CsrHandle.last_spmv_kernel()
+    assert k.startswith("hipk_spmv_sell_") and k.endswith("/groups") == (groups == "1"), k
+    res = {}
+    for plain in (False, True):
+        h.set_path(plain_only=plain)
+        xs = torch.zeros_like(b)
+        st = hipk.solve("cg", h, b, xs, tol=1e-6, atol=0.0, maxiter=30)
+        res[plain] = (xs.cpu().numpy(), st.iterations, st.residual_norm)
+    plain = _spmv_ex_all_modes(hipk, h, x, w, b)
+    h.set_path(plain_only=False)
+    for a, c in zip(coded, plain):
+        assert np.array_equal(a, c)
+    assert np.array_equal(res[False][0], res[True][0]) and res[False][1:] == res[True][1:]
 
 
 # ------------------------------------------------------------------ randomized structures through every path

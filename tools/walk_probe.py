@@ -18,12 +18,20 @@ from pytorch_sparse_solver import _hipk  # noqa: E402
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for nx in [int(v) for v in (sys.argv[1:] or ["8000"])]:
-    A = create_poisson_2d_csr(nx, nx, device=dev)
-    h = _hipk.CsrHandle(A.crow_indices(), A.col_indices(), A.values(), A.shape)
+for spec in (sys.argv[1:] or ["8000"]):   # "8000" | "f32:8000" (fp32 storage) | "var:4000" (variable coefficients: offset-coded form)
+    kind, nx = (spec.split(":") + [None])[:2] if ":" in spec else ("f64", spec)
+    nx = int(nx)
+    if kind == "var":
+        from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
+        A = create_variable_diffusion_2d_csr(nx, nx, device=dev)
+    else:
+        A = create_poisson_2d_csr(nx, nx, device=dev)
+    dt_ = torch.float32 if kind == "f32" else torch.float64
+    vals = A.values().to(dt_)
+    h = _hipk.CsrHandle(A.crow_indices(), A.col_indices(), vals, A.shape)
     n = nx * nx
-    b = torch.ones(n, dtype=torch.float64, device=dev)
-    xr = torch.randn(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    b = torch.ones(n, dtype=dt_, device=dev)
+    xr = torch.randn(n, dtype=dt_, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     yr = torch.empty_like(xr)
     reps = max(20, int(4e8 // n))
     digests = {}
@@ -56,11 +64,11 @@ for nx in [int(v) for v in (sys.argv[1:] or ["8000"])]:
         pst = _hipk.solve("cg", h, b, x, tol=1e-12, atol=0.0, maxiter=128, profile=True)
         kern = _hipk.CsrHandle.last_spmv_kernel()
         digests[strided] = (ysum, xd)
-        print(json.dumps({"nx": nx, "strided": strided, "chunked_env": os.environ.get("HIPK_SPMV_SELL_CHUNKED"),
+        print(json.dumps({"nx": nx, "kind": kind, "path": h.path(), "strided": strided, "chunked_env": os.environ.get("HIPK_SPMV_SELL_CHUNKED"),
                           "kernel": kern, "kernel_alone": kern_alone, "format_MB": round(h.format_bytes() / 1e6, 1) if hasattr(h, "format_bytes") else None,
                           "spmv_alone_us": round(alone, 2), "spmv_in_cg_us": round(pst.spmv_ms_avg * 1e3, 2),
                           "cg_us_per_iter": round(dt / st.iterations * 1e6, 2), "y_sha": ysum, "x_sha": xd}), flush=True)
     print("nx", nx, "bitwise equal across settings:", len(set(digests.values())) == 1, flush=True)
-    del A, h, b, xr, yr, x
+    del A, h, b, xr, yr, x, vals
     _hipk.clear_cache()
     torch.cuda.empty_cache()
