@@ -605,12 +605,15 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     HIPK_NOTE_KERNEL("%s", pname);
                 }
             }
-            // the same walk for the matrices that kernel does not take (fp32 storage, value planes, few uniform tiles): the
-            // one-row-per-lane chunk kernel on a grid of groups, same sizes, same switch
+            // the same walk for the offset-coded form (value planes: variable-coefficient stencils), on the one-row-per-lane chunk
+            // kernel with a grid of groups (hipk_spmv_args::group_tiles), from 32 tiles per chunk (N >= 16 M): CG per iteration
+            // 336 -> 327 us at N = 16 M, 731 -> 704 at 32 M, 1573 -> 1418-1503 at 64 M (SpMV 873 -> 716 us).  NOT for pair codes
+            // in fp32 storage, where the two-tiles-per-trip chunk kernel stays ahead (N = 64 M: 539 vs 562 us per iteration); the
+            // switch forces it for any layout (tests, A/B)
             a.group_tiles = 0;
             if (!strided && h->sell_chunked != 0) {
                 const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
-                if (se ? atoi(se) != 0 : tpc >= (chunked ? 64 : 32)) {
+                if (se ? atoi(se) != 0 : (h->coded_layout == 3 && tpc >= 32)) {
                     kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
                     a.group_tiles = HIPK_SELL_GROUP;
                     lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);

@@ -494,8 +494,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_
     const int tpc = a.ch / HIPK_TILE;        // tiles per reduction chunk
     // CHUNKED with a.group_tiles > 0 (a scalar: no further instantiations): the workgroup takes a GROUP of that many consecutive
     // tiles instead of a reduction chunk, on a grid of groups, and leaves the fold to the combine kernel -- the grouped walk of
-    // hipk_spmv_sell_wide_kernel (see there: chunks of many tiles re-fetch x[row +- nx] from beyond L2) for the matrices that
-    // kernel does not take (fp32 storage, value planes, few uniform tiles)
+    // hipk_spmv_sell_wide_kernel (see there: chunks of many tiles re-fetch x[row +- nx] from beyond L2); the launcher takes it
+    // for the offset-coded form (value planes) from N = 16 M, and for any layout when forced (tests)
     const int gt = CHUNKED ? a.group_tiles : 0;
     const int wtiles = gt > 0 ? gt : tpc;  // tiles per workgroup
     const int chunk = CHUNKED ? hipk_xcd_chunk(blockIdx.x, gt > 0 ? (ntiles + gt - 1) / gt : a.g) : 0;
