@@ -88,10 +88,14 @@ __device__ __forceinline__ void hipk_chunk_loop(int64_t n, int ch, int c, F f) {
 // Larger chunks continue with ordinary loads.  NV = 2 keeps the kernels at 8 workgroups per CU.
 // NT: the operands are STREAMS (the iteration's working set is far larger than the 256 MiB Infinity Cache, N >> 8 M rows):
 // non-temporal loads, so that they do not displace each other's lines on their way through.
-template <typename T, int NV, bool NT = false>
+template <typename T, int NV, bool NT = false, int NB = 0>
 struct hipk_pre {
     static constexpr int VEC = hipk_vec<T>::VEC;
-    static constexpr int N = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // register-resident steps per thread
+    static constexpr int N0 = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);  // steps of the smallest chunk
+    // register-resident steps per thread: the smallest chunk's, all requested up front; with the streaming policy optionally
+    // fewer (NB: more operands in the same registers), the rest then arrives in batches of as many steps (see run)
+    static constexpr int N = (NT && NB > 0 && NB < N0) ? NB : N0;
+    static constexpr int B = N;
     T v[N][NV][VEC];
     int nvs[N];
     int64_t i0, step, end;
@@ -122,14 +126,34 @@ struct hipk_pre {
 #pragma unroll
         for (int k = 0; k < N; ++k)
             if (nvs[k] > 0) f(i0 + k * step, nvs[k], v[k]);
-        for (int64_t i = i0 + N * step; i < end; i += step) {
+        // larger chunks (N > 4 M rows): BATCHES of N steps through the same registers -- every load of a batch is issued before
+        // the batch's first store.  The kernels update their operands in place, so the compiler may not move a step's loads
+        // above the previous step's stores, and on this ISA a wavefront waits for its loads in issue order behind them: step by
+        // step, each of a chunk's 64 steps (N = 64 M) paid a full memory round trip.
+        // Only with the streaming policy (NT: systems whose vectors live in HBM): the cache-resident sizes keep the step-by-step
+        // tail, whose registers the hot N = 4 M instantiations are budgeted for (the batched form took them from 64 to 78 VGPRs).
+        for (int64_t ib = i0 + N * step; NT && ib < end; ib += B * step) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int64_t i = ib + k * step;
+                nvs[k] = (i < end) ? ((end - i < VEC) ? (int)(end - i) : VEC) : 0;
+                if (nvs[k] > 0) {
+#pragma unroll
+                    for (int a = 0; a < NV; ++a) {
+                        if (NT) hipk_ld_nt_vec<T>(ptr[a], i, nvs[k], v[k][a]);
+                        else hipk_ld<T>(ptr[a], i, nvs[k], v[k][a]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (nvs[k] > 0) f(ib + k * step, nvs[k], v[k]);
+        }
+        for (int64_t i = i0 + N * step; !NT && i < end; i += step) {
             const int nv = (end - i < VEC) ? (int)(end - i) : VEC;
             T w[NV][VEC];
 #pragma unroll
-            for (int a = 0; a < NV; ++a) {
-                if (NT) hipk_ld_nt_vec<T>(ptr[a], i, nv, w[a]);
-                else hipk_ld<T>(ptr[a], i, nv, w[a]);
-            }
+            for (int a = 0; a < NV; ++a) hipk_ld<T>(ptr[a], i, nv, w[a]);
             f(i, nv, w);
         }
     }

@@ -13,6 +13,7 @@
 // and no host round trip are needed; the host follows the loop through a pinned word the direction kernel
 // stores to (hipk_pacer, hipk_solve.h) and the kernels of iterations >= stop_it return immediately, so the
 // solve stops at exactly the iteration the reference stops at.
+#include <type_traits>
 #include <math.h>
 #include <stdlib.h>
 
@@ -122,8 +123,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const int c = blockIdx.x;
     // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
     // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
-    hipk_pre<T, 2, NT> pre;
-    pre.issue(n, ch, c, {r, (const T *)p});
+    // streaming policy (NT): x is the third batched operand, two steps per batch -- loaded inside the step, behind the previous
+    // step's stores, it cost every step a memory round trip (N = 64 M: 64 steps per thread)
+    typename std::conditional<NT && !NOX, hipk_pre<T, 3, true, 2>, hipk_pre<T, 2, NT>>::type pre;
+    if constexpr (NT && !NOX) pre.issue(n, ch, c, {r, (const T *)p, (const T *)x});
+    else pre.issue(n, ch, c, {r, (const T *)p});
     if (it >= scal->stop_it) return;
     __shared__ double sbuf[2 * HIPK_THREADS];
     double pAp, rr;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851
-    if (NOX) {
+    if constexpr (NOX) {
         pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
             constexpr int VEC = hipk_vec<T>::VEC;
             T pv[VEC];
@@ -147,23 +151,35 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
             }
             hipk_st<T>(p, i, nv, pv);
         });
-    } else {
-    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
-        constexpr int VEC = hipk_vec<T>::VEC;
-        T xv[VEC], pv[VEC];
-        if (NT) hipk_ld_nt_vec<T>((const T *)x, i, nv, xv);
-        else hipk_ld<T>((const T *)x, i, nv, xv);
+    } else if constexpr (NT) {
+        pre.run([&](int64_t i, int nv, T(&v)[3][hipk_vec<T>::VEC]) {
+            constexpr int VEC = hipk_vec<T>::VEC;
+            T xv[VEC], pv[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const T m0 = alpha * v[1][k];
-            xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
-            const T m = beta * v[1][k];
-            pv[k] = v[0][k] + m;  // TSL:852
-        }
-        if (NT) hipk_st_nt_vec<T>(x, i, nv, xv);   // x is not read again before the next direction kernel
-        else hipk_st<T>(x, i, nv, xv);
-        hipk_st<T>(p, i, nv, pv);
-    });
+            for (int k = 0; k < VEC; ++k) {
+                const T m0 = alpha * v[1][k];
+                xv[k] = v[2][k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
+                const T m = beta * v[1][k];
+                pv[k] = v[0][k] + m;  // TSL:852
+            }
+            hipk_st_nt_vec<T>(x, i, nv, xv);  // x is not read again before the next direction kernel
+            hipk_st<T>(p, i, nv, pv);
+        });
+    } else {
+        pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+            constexpr int VEC = hipk_vec<T>::VEC;
+            T xv[VEC], pv[VEC];
+            hipk_ld<T>((const T *)x, i, nv, xv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const T m0 = alpha * v[1][k];
+                xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
+                const T m = beta * v[1][k];
+                pv[k] = v[0][k] + m;  // TSL:852
+            }
+            hipk_st<T>(x, i, nv, xv);
+            hipk_st<T>(p, i, nv, pv);
+        });
     }
     if (c == 0 && threadIdx.x == 0) {
         scal->gamma[(it + 1) & 1] = rr;  // TSL:853

@@ -183,6 +183,29 @@ def test_cg_bit_exact_vs_oracle_and_reference_counts(hipk, oracle, r):
     assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
 
 
+@pytest.mark.parametrize("streams", ["0", "1"])
+def test_cg_multi_step_chunks_both_cache_policies_bit_exact_vs_oracle(hipk, oracle, streams, monkeypatch):
+    """Reduction chunks of more than 2048 elements (n > 4.19 M: 4096 here, eight 16-byte steps per thread -- four requested up
+    front, the rest by the tail of hipk_pre): the vector kernels' step-by-step tail (cache-resident policy, HIPK_CG_STREAMS=0)
+    and the batched tail of the streaming policy (=1: what systems beyond the Infinity Cache take: every load of a batch before
+    its first store) give the oracle's bits -- x, counts, recurrence and true residual of 25 CG iterations."""
+    from pytorch_sparse_solver.module_a import cg, get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
+    monkeypatch.setenv("HIPK_CG_STREAMS", streams)
+    nx, ny = 2100, 2101                                                # 4,412,100 rows: ragged last chunk, ragged last step
+    A = create_poisson_2d_csr(nx, ny)
+    n = nx * ny
+    assert int(hipk.lib().hipk_chunk_size(n)) == 4096
+    g = torch.Generator().manual_seed(3)
+    b = torch.randn(n, dtype=torch.float64, generator=g)
+    x, info = cg(A.to(DEV), b.to(DEV), tol=1e-12, maxiter=25)
+    st = get_last_stats()
+    ref = oracle.cg(A.crow_indices().numpy(), A.col_indices().numpy(), A.values().numpy(), b.numpy(), tol=1e-12, maxiter=25)
+    assert np.array_equal(x.cpu().numpy(), ref.x)
+    assert (info, st.iterations, st.matvecs) == (ref.info, ref.iterations, ref.matvecs) and st.iterations == 25
+    assert st.residual_norm == ref.residual_norm and st.recurrence_rs == ref.recurrence_rs
+
+
 def test_cg_n4m_headline_properties(hipk):
     """BASELINE config 2 at full size: size-independent properties (the oracle run is in bench.py)."""
     from pytorch_sparse_solver.module_a import cg, get_last_stats
