@@ -127,9 +127,9 @@ struct hipk_pre {
         for (int k = 0; k < N; ++k)
             if (nvs[k] > 0) f(i0 + k * step, nvs[k], v[k]);
         // larger chunks (N > 4 M rows): BATCHES of N steps through the same registers -- every load of a batch is issued before
-        // the batch's first store.  The kernels update their operands in place, so the compiler may not move a step's loads
-        // above the previous step's stores, and on this ISA a wavefront waits for its loads in issue order behind them: step by
-        // step, each of a chunk's 64 steps (N = 64 M) paid a full memory round trip.
+        // the batch's first store (the kernels update their operands in place, so the compiler may not move a step's loads above
+        // the previous step's stores).  Same-box A/B at N = 64 M (profiles/r02_vector_tail_ab.txt): CG update kernel 278 -> 272 us,
+        // direction kernel 457 -> 464 us -- the round trips were already hidden by the 30 wavefronts per CU; kept for the 2 %.
         // Only with the streaming policy (NT: systems whose vectors live in HBM): the cache-resident sizes keep the step-by-step
         // tail, whose registers the hot N = 4 M instantiations are budgeted for (the batched form took them from 64 to 78 VGPRs).
         for (int64_t ib = i0 + N * step; NT && ib < end; ib += B * step) {

@@ -123,8 +123,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     const int c = blockIdx.x;
     // r and p are requested up front; x (needed last) is loaded step by step after the fold: all three would
     // take 76 VGPRs and drop the kernel to 6 workgroups per CU (1536 slots < 1954 chunks: a second round)
-    // streaming policy (NT): x is the third batched operand, two steps per batch -- loaded inside the step, behind the previous
-    // step's stores, it cost every step a memory round trip (N = 64 M: 64 steps per thread)
+    // streaming policy (NT): x is the third batched operand, two steps per batch (instead of a load inside the step, behind the
+    // previous step's stores); same-box A/B at N = 64 M: 457 vs 464 us, no gain (profiles/r02_vector_tail_ab.txt)
     typename std::conditional<NT && !NOX, hipk_pre<T, 3, true, 2>, hipk_pre<T, 2, NT>>::type pre;
     if constexpr (NT && !NOX) pre.issue(n, ch, c, {r, (const T *)p, (const T *)x});
     else pre.issue(n, ch, c, {r, (const T *)p});

@@ -65,6 +65,21 @@ int main(int argc, char **argv) {
     run<MODE, 2, true, false>(name, r, p, x, n, bytes);            \
     run<MODE, 2, false, true>(name, r, p, x, n, bytes);            \
     run<MODE, 1, true, true>(name, r, p, x, n, bytes);
+    if (argc > 2) {  // skew sweep: the three vectors in ONE allocation, p and x displaced by k and 2k times `skew` bytes from an n-vector stride
+        double *buf;
+        const long pad = 64L << 20;
+        CK(hipMalloc(&buf, 3 * n * 8 + 3 * pad));
+        CK(hipMemset(buf, 0, 3 * n * 8 + 3 * pad));
+        const long skews[] = {0, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 1L << 20, (1L << 20) + 4096, 3L << 20};
+        for (long sk : skews) {
+            double *rr = buf, *pp = buf + n + sk / 8, *xx = buf + 2 * n + 2 * sk / 8;
+            char name[64];
+            snprintf(name, sizeof(name), "direction, skew %ld B", sk);
+            run<2, 64, true, true>(name, rr, pp, xx, n, 5 * B);
+            run<2, 4, true, true>(name, rr, pp, xx, n, 5 * B);
+        }
+        return 0;
+    }
     ALL(0, "copy 1R 1W", 2 * B)
     ALL(1, "triad 2R 1W", 3 * B)
     ALL(2, "direction 3R 2W (in place)", 5 * B)
