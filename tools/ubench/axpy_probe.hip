@@ -65,6 +65,26 @@ int main(int argc, char **argv) {
     run<MODE, 2, true, false>(name, r, p, x, n, bytes);            \
     run<MODE, 2, false, true>(name, r, p, x, n, bytes);            \
     run<MODE, 1, true, true>(name, r, p, x, n, bytes);
+    if (argc > 2 && argv[2][0] == 'r') {  // re-allocation sweep: does the time of the SAME kernel depend on where the vectors land?
+        for (int rep = 0; rep < 6; ++rep) {
+            double *a[3], *dummy = nullptr;
+            if (rep % 2) CK(hipMalloc(&dummy, (size_t)(rep * 37 + 11) << 20));  // shift what the next allocations get
+            for (int k = 0; k < 3; ++k) { CK(hipMalloc(&a[k], n * 8)); CK(hipMemset(a[k], 0, n * 8)); }
+            char name[64];
+            snprintf(name, sizeof(name), "direction, separate allocs #%d", rep);
+            run<2, 64, true, true>(name, a[0], a[1], a[2], n, 5 * B);
+            printf("   r %p p %p x %p\n", (void *)a[0], (void *)a[1], (void *)a[2]);
+            for (int k = 0; k < 3; ++k) CK(hipFree(a[k]));
+            double *buf;
+            CK(hipMalloc(&buf, 3 * n * 8)); CK(hipMemset(buf, 0, 3 * n * 8));
+            snprintf(name, sizeof(name), "direction, one allocation #%d", rep);
+            run<2, 64, true, true>(name, buf, buf + n, buf + 2 * n, n, 5 * B);
+            printf("   buf %p\n", (void *)buf);
+            CK(hipFree(buf));
+            if (dummy) CK(hipFree(dummy));
+        }
+        return 0;
+    }
     if (argc > 2) {  // skew sweep: the three vectors in ONE allocation, p and x displaced by k and 2k times `skew` bytes from an n-vector stride
         double *buf;
         const long pad = 64L << 20;
