@@ -326,7 +326,10 @@ def main():
                  "bytes this format streams: code planes + x + y" if coded else "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
                 ("cg_update", 2, f"hipk_cg_update_kernel<double,false,{nt_streams}> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
                  "read Ap, r; write r = 24 n"),
-                ("cg_direction", 3, f"hipk_cg_direction_kernel<double,false,{nt_streams},false> (x += alpha p, p = r + beta p)", 5 * n * sv,
+                ("cg_direction", 3, (f"hipk_cg_direction_kernel<double,false,{nt_streams},false> (x += alpha p, p = r + beta p)"
+                                     if os.environ.get("HIPK_CG_FLAT_DIRECTION", "1" if n * sv > 256 * 1024 * 1024 else "0")[0] == "0"
+                                     or nt_streams == "false" else
+                                     "hipk_cg_scalars_kernel + hipk_cg_direction_flat_kernel<double> (x += alpha p, p = r + beta p; both launches timed)"), 5 * n * sv,
                  "read r, p, x; write p, x = 40 n")]
         kernels = []
         for key, which, name, nbytes, what in legs:

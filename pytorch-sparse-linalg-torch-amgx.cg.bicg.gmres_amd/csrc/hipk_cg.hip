@@ -41,6 +41,8 @@ struct hipk_cg_scal {
     double xx;         // <x,x>                               (TSL:1013)
     int64_t stop_it;   // iterations >= stop_it are no-ops
     int64_t *host_sig; // pinned host word the direction kernel reports to (hipk_pacer), or null
+    double dir_alpha;  // hipk_cg_scalars_kernel -> hipk_cg_direction_flat_kernel (streaming policy): gamma / <p,Ap>, <r,r> / gamma
+    double dir_beta;
     hipk_lds_ctl ctl;  // hipk_cg_solve_lds_kernel (small systems: the whole loop in one launch)
 };
 static_assert(sizeof(hipk_cg_scal) <= 256, "the scalar block is 256 bytes");
@@ -188,6 +190,71 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
         const bool done = (it + 1 >= maxiter || rr <= scal->atol2);
         if (done) scal->stop_it = it + 1;
         hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
+    }
+}
+
+// Streaming policy on one device (vectors in HBM: N >> 8 M rows): the direction step as TWO launches -- alpha, beta, the next gamma
+// and the stop test once, by one workgroup (the same fold of the same partials: the same bits); then a FLAT grid of short
+// workgroups (2048 elements each, every load requested before the stop word is read), which a step without a dot is free to use.
+// Why: at N = 64 M a workgroup per 256 KB chunk keeps 1954 x 5 distant streams open; the same bytes move 6-10 % faster from short
+// workgroups over adjacent addresses, and lose less when the vectors landed badly (profiles/r02_axpy_probe_64m.txt,
+// r02_axpy_realloc_64m.txt: 5.8 -> 6.1 TB/s, and 4.9 -> 5.4 TB/s in the slow placement); per workgroup the fold of 2 x 1954
+// partials is what stood in the way.  The extra launch costs ~4 us of an iteration of ~1 ms.
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_scalars_kernel(int g, hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
+                                                                       const double *__restrict__ part_pAp,
+                                                                       const double *__restrict__ part_rr) {
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double pAp, rr;
+    hipk_reduce_parts2(part_pAp, part_rr, g, pAp, rr, sbuf);
+    if (threadIdx.x == 0) {
+        const double gamma = scal->gamma[it & 1];
+        scal->dir_alpha = gamma / pAp;       // TSL:846, the same bits hipk_cg_update_kernel derived
+        scal->dir_beta = rr / gamma;         // TSL:851
+        scal->gamma[(it + 1) & 1] = rr;      // TSL:853
+        const bool done = (it + 1 >= maxiter || rr <= scal->atol2);  // TSL:841 for the NEXT pass (this pass compares against `it`)
+        if (done) scal->stop_it = it + 1;
+        hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_flat_kernel(int64_t n, const hipk_cg_scal *__restrict__ scal, int64_t it,
+                                                                              const T *__restrict__ r, T *__restrict__ p,
+                                                                              T *__restrict__ x) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr int STEPS = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);
+    const int64_t base = (int64_t)blockIdx.x * HIPK_BASE_CHUNK + (int64_t)VEC * threadIdx.x;
+    T rv[STEPS][VEC], pv[STEPS][VEC], xv[STEPS][VEC];
+    int nvs[STEPS];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const int64_t i = base + (int64_t)k * VEC * HIPK_THREADS;
+        nvs[k] = (i < n) ? ((n - i < VEC) ? (int)(n - i) : VEC) : 0;
+        if (nvs[k] > 0) {
+            hipk_ld_nt_vec<T>(r, i, nvs[k], rv[k]);
+            hipk_ld_nt_vec<T>((const T *)p, i, nvs[k], pv[k]);
+            hipk_ld_nt_vec<T>((const T *)x, i, nvs[k], xv[k]);
+        }
+    }
+    if (it >= scal->stop_it) return;  // hipk_cg_scalars_kernel of THIS pass has run: it sets stop_it = it + 1 at the earliest
+    const T alpha = (T)scal->dir_alpha;
+    const T beta = (T)scal->dir_beta;
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        if (nvs[k] > 0) {
+            const int64_t i = base + (int64_t)k * VEC * HIPK_THREADS;
+            T xo[VEC], po[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const T m0 = alpha * pv[k][e];
+                xo[e] = xv[k][e] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
+                const T m = beta * pv[k][e];
+                po[e] = rv[k][e] + m;  // TSL:852
+            }
+            hipk_st_nt_vec<T>(x, i, nvs[k], xo);  // x is not read again before the next direction step
+            hipk_st<T>(p, i, nvs[k], po);
+        }
     }
 }
 
@@ -563,6 +630,11 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     // (HIPK_CG_STREAMS=0/1 forces the choice: A/B measurements)
     bool streams = 4 * (size_t)n * sizeof(T) > (size_t)384 << 20;
     if (const char *e = getenv("HIPK_CG_STREAMS")) streams = e[0] == '1';
+    // with it, and a vector alone beyond the 256 MiB Infinity Cache, the direction step as a scalars launch + a flat grid
+    // (same vectors, same process, per CG iteration: N = 64 M 1079 -> 1011 us; N = 32 M 473 -> 471; N = 16 M, where p still finds
+    // room in that cache, 237 -> 246: not taken there).  HIPK_CG_FLAT_DIRECTION=0|1 forces (tools/flat_probe.py, tests)
+    bool flat_dir = (size_t)n * sizeof(T) > ((size_t)256 << 20);
+    if (const char *e = getenv("HIPK_CG_FLAT_DIRECTION")) flat_dir = e[0] == '1';
 
     int64_t it = 0, stop = INT64_MAX;
     // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel), bounded iterations per launch
@@ -653,7 +725,11 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             if (small)
                 hipk_cg_direction_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter,
                                                                                      A->tile_part, part_b, r, p, x, ntiles);
-            else if (streams)
+            else if (streams && flat_dir) {
+                hipk_cg_scalars_kernel<<<1, HIPK_THREADS, 0, stream>>>(gm.g, scal, it, maxiter, part_a, part_b);
+                hipk_cg_direction_flat_kernel<T><<<(unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK), HIPK_THREADS, 0, stream>>>(
+                    n, scal, it, r, p, x);
+            } else if (streams)
                 hipk_cg_direction_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
                                                                                             part_b, r, p, x);
             else

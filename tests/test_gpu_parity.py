@@ -183,15 +183,17 @@ def test_cg_bit_exact_vs_oracle_and_reference_counts(hipk, oracle, r):
     assert np.linalg.norm(x - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
 
 
-@pytest.mark.parametrize("streams", ["0", "1"])
-def test_cg_multi_step_chunks_both_cache_policies_bit_exact_vs_oracle(hipk, oracle, streams, monkeypatch):
+@pytest.mark.parametrize("streams,flat", [("0", "1"), ("1", "1"), ("1", "0")])
+def test_cg_multi_step_chunks_both_cache_policies_bit_exact_vs_oracle(hipk, oracle, streams, flat, monkeypatch):
     """Reduction chunks of more than 2048 elements (n > 4.19 M: 4096 here, eight 16-byte steps per thread -- four requested up
     front, the rest by the tail of hipk_pre): the vector kernels' step-by-step tail (cache-resident policy, HIPK_CG_STREAMS=0)
     and the batched tail of the streaming policy (=1: what systems beyond the Infinity Cache take: every load of a batch before
-    its first store) give the oracle's bits -- x, counts, recurrence and true residual of 25 CG iterations."""
+    its first store; the direction step as a scalars launch + a flat grid of short workgroups, or -- flat = 0 -- one workgroup
+    per chunk) give the oracle's bits -- x, counts, recurrence and true residual of 25 CG iterations."""
     from pytorch_sparse_solver.module_a import cg, get_last_stats
     from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
     monkeypatch.setenv("HIPK_CG_STREAMS", streams)
+    monkeypatch.setenv("HIPK_CG_FLAT_DIRECTION", flat)
     nx, ny = 2100, 2101                                                # 4,412,100 rows: ragged last chunk, ragged last step
     A = create_poisson_2d_csr(nx, ny)
     n = nx * ny
