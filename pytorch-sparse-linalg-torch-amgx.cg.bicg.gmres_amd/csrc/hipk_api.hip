@@ -587,7 +587,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                          (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1, st);
                 return pk;
             };
-            // grouped walk of that kernel (WALK = 1: one workgroup per 8 consecutive tiles, tile sums through the combine kernel).
+            // grouped walk of that kernel (WALK = 1: one workgroup per 4 consecutive tiles, tile sums through the combine kernel).
             // Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned system, which cannot fill the chip
             // with a workgroup per chunk and used to fall to the one-row-per-lane kernel (4 M rows with the chunk size of a
             // 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) -- and (b) where a chunk holds 64 tiles

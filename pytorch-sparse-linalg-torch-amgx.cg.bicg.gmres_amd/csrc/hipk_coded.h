@@ -477,7 +477,11 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 // CHUNKED = true (large systems: about as many reduction chunks as resident workgroups): one workgroup per
 //   reduction chunk, its tiles in ascending order; the wavefront sums stay in LDS and the workgroup itself forms
 //   the chunk partial with the spec's fold (hipk_wave_fold) -- no combine launch (4.9 us per CG iteration).
-#define HIPK_SELL_GROUP 8      // two-rows-per-lane kernel, grouped walk (WALK = 1): tiles per workgroup
+#ifndef HIPK_SELL_GROUP
+// tiles per workgroup of the grouped walk.  Same box, library twins (tools/r02_call46.sh), CG per iteration at N = 32 M / 64 M and on a
+// rank-shaped block of 4 M rows: 2 tiles 496 / 1030 / 72.2 us, 4 tiles 481 / 998 / 69.2, 8 tiles 489 / 1007 / 69.2, 16 tiles 503 / 1022 / 72.0
+#define HIPK_SELL_GROUP 4
+#endif
 #define HIPK_SELL_MAX_TPC 128  // tiles per chunk the chunked form holds in LDS (chunks up to 32768 rows: N = 64 M)
 // VALS = true: offset-coded layout -- the dictionary holds column offsets only, the values come from per-tile value
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
@@ -907,7 +911,7 @@ __device__ __forceinline__ double hipk_half_tree2(double2 d) {  // sums of rows 
     return d.x + d.y;
 }
 
-// WALK = 1 (groups): the launch is not tied to the reduction chunks -- one workgroup per GROUP of 8 consecutive tiles on an ordinary
+// WALK = 1 (groups): the launch is not tied to the reduction chunks -- one workgroup per GROUP of 4 consecutive tiles on an ordinary
 // grid, XCD k taking the k-th eighth of the groups; the wavefront sums of the fused dots go to the per-tile buffer and
 // hipk_tile_combine_kernel folds them (same fold, same bits).  Two uses.
 // (a) Row blocks with FEW chunks of many tiles (a rank of a row-partitioned system: 4 M rows in 245 chunks), which cannot fill the

@@ -280,7 +280,7 @@ def _spmv_ex_mode(hipk, h, mode, x, w, b):
                                      [-9000, -1500, -1, 0, 1, 1500, 9000], [-9000, -1500, -2, -1, 0, 1, 1500, 9000]])
 @pytest.mark.parametrize("strided", ["0", "1"])
 def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeypatch):
-    """strided = 1: the kernel's grouped walk (one workgroup per 8 consecutive tiles on an ordinary grid, tile sums through
+    """strided = 1: the kernel's grouped walk (one workgroup per 4 consecutive tiles on an ordinary grid, tile sums through
     hipk_tile_combine_kernel) -- what row blocks of few large chunks and systems of N > 16 M take -- forced here at a size the
     CPU oracle checks in seconds.
     hipk_spmv_sell_wide_kernel (chunk-per-workgroup sizes, fp64, most tiles uniform): uniform tiles from 16-byte accesses, two
@@ -393,7 +393,7 @@ def test_offset_coded_random_values_all_widths(hipk, oracle, n, offsets, chunked
 
 @pytest.mark.parametrize("groups", ["0", "1"])
 def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle, groups, monkeypatch):
-    """groups = 1: the one-row-per-lane chunk kernel on a grid of groups of 8 tiles (what it takes at N > 16 M and on a rank's
+    """groups = 1: the one-row-per-lane chunk kernel on a grid of groups of 4 tiles (what it takes at N > 16 M and on a rank's
     row block: hipk_spmv_args::group_tiles), forced at this size; value planes, fp64 and fp32 storage."""
     from pytorch_sparse_solver.utils.matrix_utils import create_variable_diffusion_2d_csr
     monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", groups)
@@ -429,7 +429,7 @@ def test_offset_coded_fused_dots_fp32_and_whole_solves(hipk, oracle, groups, mon
 @pytest.mark.parametrize("groups", ["0", "1"])
 def test_fp32_storage_poisson_chunk_and_group_walks(hipk, groups, monkeypatch):
     """fp32 storage of the headline matrix's kind (1500 x 1500 Poisson: pair codes, uniform tiles, but not the fp64-only
-    two-rows-per-lane kernel): the one-row-per-lane kernels with a workgroup per chunk and, forced, per group of 8 tiles; 30 CG
+    two-rows-per-lane kernel): the one-row-per-lane kernels with a workgroup per chunk and, forced, per group of 4 tiles; 30 CG
     iterations and all fused-dot modes bitwise equal to the general CSR kernels."""
     from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
     monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", groups)

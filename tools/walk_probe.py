@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Coded SpMV on Poisson grids whose reduction chunks span several grid lines (nx = 4000: chunk = 32 tiles = 2 grid lines,
 nx = 8000 = BASELINE config 5 on one GPU: chunk = 128 tiles = 4 grid lines): the two-rows-per-lane kernel with every workgroup
-walking its own chunk (HIPK_SPMV_SELL_STRIDED=0) against one workgroup per group of 8 tiles on an ordinary grid (=1) and the
+walking its own chunk (HIPK_SPMV_SELL_STRIDED=0) against one workgroup per group of 4 tiles on an ordinary grid (=1) and the
 library's own choice (unset), in ONE process (the switch is read per launch); stand-alone SpMV, SpMV inside the CG loop, CG
 time per iteration, x of 200 iterations bitwise equal.  HIPK_SPMV_SELL_CHUNKED=0 in the environment measures the
 one-row-per-lane persistent kernel instead."""
