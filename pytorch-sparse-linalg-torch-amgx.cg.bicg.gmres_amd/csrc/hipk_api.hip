@@ -592,12 +592,14 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             // with a workgroup per chunk and used to fall to the one-row-per-lane kernel (4 M rows with the chunk size of a
             // 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) -- and (b) where a chunk holds 64 tiles
             // and more (N > 16 M on one device; per CG iteration 515 -> 483 us at N = 32 M, 1106 -> 980 us at N = 64 M, where a
-            // chunk-walking workgroup fetched x three times; equal at N = 8 M / 16 M, slower at N = 4 M: not taken there).
+            // chunk-walking workgroup fetched x three times) -- and, with four tiles per group, from 16 tiles per chunk: N = 8 M
+            // 118.8 -> 117.1 us, N = 16 M equal, a rank's block of a 2-rank weak-scaling run (4 M rows, chunk 4096) 67.6 -> 66.5;
+            // slower at N = 4 M (8 tiles per chunk, 56.6 -> 58.7: one more launch): not taken there.
             // HIPK_SPMV_SELL_STRIDED=0|1 forces (read per launch: in-process A/B, tools/walk_probe.py)
             bool strided = false;
             if (wide_ok && !no_wide && h->sell_chunked != 0) {
                 const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
-                if (se ? atoi(se) != 0 : tpc >= (chunked ? 64 : 32)) {
+                if (se ? atoi(se) != 0 : tpc >= (chunked ? 16 : 32)) {
                     char pname[96];
                     kern = pick_wide(1, pname, sizeof(pname));
                     lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
