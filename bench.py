@@ -14,10 +14,14 @@ resident in HBM.  Workloads:
 Launch: `python bench.py --gpus N ...` starts its N ranks itself (children of `python -m torch.distributed.run`,
 spawned BEFORE this process touches the GPU; the JSON line is relayed, a failing child fails the parent); under
 `torch.distributed.run` (WORLD_SIZE set) it is a rank.  Rank 0 prints ONE JSON line.
-Extra objects: `kernels` (the three kernels of the CG iteration, HIP events around their launches inside the solver loop),
-`roofline` (the longest of them; N > 1: the local SpMV), `spmv` (the metric's SpMV GB/s; the Poisson matrix takes the coded
+Extra objects: `kernels` (the three kernels of the CG iteration, each timed INSIDE the solver loop by start/stop events bound to
+its dispatch -- hipExtLaunchKernel -- i.e. the dispatch's own begin/end timestamps, the durations `rocprofv3 --kernel-trace`
+prints; nothing is calibrated or subtracted), `roofline` (the longest of them, plus `legs`: that kernel, the GENERAL CSR SpMV on
+SURVEY 8d's bytes -- the north star's kernel -- and the same CG kernels on the N = 64 M system, whose vectors cannot sit in the
+256 MiB Infinity Cache: the HBM-resident figure), `spmv` (the metric's SpMV GB/s; the Poisson matrix takes the coded
 path -- one byte per entry -- so the general CSR kernels are measured beside it on the same matrix), `cpu_baseline` (the
-oracle's C restatement on the host cores + the torch-CPU generic loop, bounded samples).
+oracle's C restatement on the host cores + the torch-CPU generic loop, bounded samples).  `traffic` comes from committed
+rocprofv3 --pmc passes and is quoted only when they were taken on the library build that is running (hipk_build_id).
 """
 import argparse
 import json
@@ -37,7 +41,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 NX = 2000
 # per-kernel HBM traffic from committed rocprofv3 --pmc passes (tools/prof_bench.sh + tools/pmc_to_json.py): NOT measured
 # in this run (PMC needs rocprofv3 attached); stamped with the commit it was taken at and dropped when the kernel differs
-PMC_FILES = ("r02_pmc_kernels.json", "r01j_pmc_kernels.json")
+PMC_FILES = ("r03_pmc_kernels.json",)
 
 
 def parse():
@@ -52,6 +56,7 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6000)
+    ap.add_argument("--no-n64m", action="store_true", help="skip the N = 64 M (HBM-resident) roofline leg")
     return ap.parse_args()
 
 
@@ -163,14 +168,17 @@ def _loop_spmv_kernel(h, v):
     return h.last_spmv_kernel()
 
 
-def load_pmc():
+def load_pmc(build_id):
+    """Committed per-kernel counter traffic, only if it was taken on the library build that is running."""
     for name in PMC_FILES:
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return name, d
         except Exception:
             continue
-    return None, {}
+        if d.get("build_id") == build_id:
+            return name, d, None
+        return name, {}, f"profiles/{name} was taken on build {d.get('build_id')}, this library is build {build_id}"
+    return None, {}, "no counter profile committed for this round"
 
 
 def main():
@@ -206,6 +214,7 @@ def main():
         json_fd = os.dup(1)
         os.dup2(2, 1)
     handle_ms = None
+    cold_first_solve_ms = None
     if use_dist:
         import torch.distributed as dist
         from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
@@ -234,6 +243,12 @@ def main():
         h = _hipk.handle_for(A)     # index narrowing + validation, dictionary, code planes, uniform-tile analysis
         torch.cuda.synchronize()
         handle_ms = (time.perf_counter() - t0) * 1e3
+        # the first cg() of a process on a fresh matrix, as a user pays it: handle creation (above) + the first solve
+        # (code-object load of the kernels it touches included); outside the timed region, reported in config
+        t0 = time.perf_counter()
+        cg(A, b, tol=args.tol)
+        torch.cuda.synchronize()
+        cold_first_solve_ms = handle_ms + (time.perf_counter() - t0) * 1e3
 
         def barrier():
             pass
@@ -284,22 +299,26 @@ def main():
         dt = tt.item()
     x, info, st = last
 
-    # ---- roofline leg: each kernel of the CG iteration timed with HIP events around its launches INSIDE the
-    # solver loop (params.profile selects the kernel; event-pair overhead calibrated and subtracted), same inputs, right
-    # after the timed region.  `roofline` is the dominant (longest) kernel; `kernels` lists all three.
+    # ---- roofline leg: each kernel of the CG iteration timed INSIDE the solver loop by start/stop events bound to its
+    # dispatch (params.profile selects the kernel; hipk_solve.h: hipExtLaunchKernel): the dispatch's own begin/end
+    # timestamps, i.e. the durations rocprofv3 --kernel-trace prints for the same launches.  Nothing is subtracted.
+    # `roofline` is the dominant (longest) kernel of the headline iteration; `roofline.legs` adds the general CSR SpMV and
+    # the N = 64 M (HBM-resident) run of the same CG kernels; `kernels` lists all three kernels of the iteration.
     roof = None
     spmv_standalone = None
     kernels = None
     spmv_report = None
+    TIMING = ("dispatch begin/end timestamps (start/stop events bound to the launch, hipExtLaunchKernel) = the durations "
+              "rocprofv3 --kernel-trace prints; nothing subtracted")
     if not use_dist:
         n = nx * nx
         sv = 8
-        pmc_name, pmc_doc = load_pmc()
-        pmc = pmc_doc.get("kernels", {}) if nx == NX else {}
+        build_id = _hipk.lib().hipk_build_id().decode()
+        pmc_name, pmc_doc, pmc_dropped = load_pmc(build_id)
 
-        def traffic_of(key, kernel_ran):
-            """PMC traffic of a committed profile, only when it was taken on the same kernel instantiation."""
-            e = pmc.get(key)
+        def traffic_of(section, key, kernel_ran):
+            """PMC traffic of the committed profile of THIS build, only when it was taken on the same kernel instantiation."""
+            e = pmc_doc.get(section, {}).get(key)
             if not e:
                 return None
             prof_kernel = e.get("kernel", "").replace(" ", "")
@@ -307,53 +326,69 @@ def main():
                 return None
             return e.get("traffic_bytes_per_launch")
 
-        def in_loop(which, handle=h):
-            xx = torch.zeros_like(b)
-            pst = _hipk.solve("cg", handle, b, xx, tol=args.tol, atol=0.0, maxiter=256, profile=which)
-            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled, pst.event_overhead_ms * 1e3
+        def in_loop(which, handle, rhs):
+            xx = torch.zeros_like(rhs)
+            pst = _hipk.solve("cg", handle, rhs, xx, tol=args.tol, atol=0.0, maxiter=256, profile=which)
+            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled
+
+        def cg_legs(handle, rhs, nn, section, bound):
+            """The three kernels of the CG iteration on `handle`: name, algorithmic bytes, in-loop duration."""
+            path = handle.path()
+            fb = handle.format_bytes()
+            sb = handle.spmv_bytes()
+            spmv_kernel = _loop_spmv_kernel(handle, rhs)
+            coded_ = path in ("coded", "offset_coded")
+            spmv_name = (f"{spmv_kernel} (coded SpMV + fused <p,Ap> partials)" if coded_
+                         else f"{spmv_kernel} (CSR SpMV + fused <p,Ap> tile partials; {path})")
+            # x, r, p, Ap beyond 384 MiB: the vector kernels' non-temporal instantiation (csrc/hipk_cg.hip)
+            nt = 4 * nn * sv > 384 * 1024 * 1024
+            nts = "true" if nt else "false"
+            flat = nt and os.environ.get("HIPK_CG_FLAT_DIRECTION", "1" if nn * sv > 256 * 1024 * 1024 else "0")[0] != "0"
+            legs = [("spmv", 1, spmv_name, fb if coded_ else sb,
+                     "bytes this format streams: code planes + x + y" if coded_ else "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
+                    ("cg_update", 2, f"hipk_cg_update_kernel<double,false,{nts}> (r -= alpha Ap, <r,r> partials)", 3 * nn * sv,
+                     "read Ap, r; write r = 24 n"),
+                    ("cg_direction", 3,
+                     ("hipk_cg_direction_flat_kernel<double> (x += alpha p, p = r + beta p; the one-workgroup hipk_cg_scalars_kernel "
+                      "before it is timed separately: `scalars_launch_us`)" if flat else
+                      f"hipk_cg_direction_kernel<double,false,{nts},false> (x += alpha p, p = r + beta p)"), 5 * nn * sv,
+                     "read r, p, x; write p, x = 40 n")]
+            out = []
+            for key, which, name, nbytes, what in legs:
+                us, cnt = in_loop(which, handle, rhs)
+                k = {"key": key, "kernel": name, "bound": bound, "avg_launch_us": us, "launches_timed": cnt,
+                     "algorithmic_bytes_per_launch": nbytes, "bytes_are": what,
+                     "achieved_GBps": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBPS,
+                     "traffic": traffic_of(section, key, name)}
+                if key == "spmv" and coded_:   # CSR-formula bytes over the coded kernel's time: an EFFECTIVE figure, no fraction of peak
+                    k["effective_GBps_on_csr_bytes"] = sb / us / 1e3
+                    k["csr_formula_bytes"] = sb
+                if key == "cg_direction" and flat:
+                    k["scalars_launch_us"] = in_loop(4, handle, rhs)[0]
+                out.append(k)
+            return out
+
+        def roof_of(k, why):
+            return {"bound": k["bound"], "kernel": k["kernel"] + ", timed inside the CG loop", "achieved": k["achieved_GBps"],
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": k["traffic"],
+                    "avg_launch_us": k["avg_launch_us"], "launches_timed": k["launches_timed"],
+                    "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "bytes_are": k["bytes_are"], "why": why}
 
         path = h.path()
         fbytes = h.format_bytes()
-        # the chunk-per-workgroup pair form needs chunks of <= 64 tiles; larger chunks take the persistent loop kernel
-        # the instantiation the CG loop's SpMV launches select (the library reports it: hipk_last_spmv_kernel)
-        spmv_kernel = _loop_spmv_kernel(h, b)
-        spmv_name = {"coded": f"{spmv_kernel} (coded SpMV, uniform tiles two rows per lane from one word per tile, + fused <p,Ap> chunk partials)",
-                     "tile_fast": f"{spmv_kernel} (CSR SpMV + fused <p,Ap> tile partials)"}.get(path, f"{spmv_kernel} ({path})")
         coded = path in ("coded", "offset_coded")
-        # x, r, p, Ap beyond 384 MiB: the vector kernels' non-temporal instantiation (csrc/hipk_cg.hip)
-        nt_streams = "true" if 4 * n * sv > 384 * 1024 * 1024 else "false"
-        legs = [("spmv", 1, spmv_name, fbytes if coded else spmv_bytes,
-                 "bytes this format streams: code planes + x + y" if coded else "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8"),
-                ("cg_update", 2, f"hipk_cg_update_kernel<double,false,{nt_streams}> (r -= alpha Ap, <r,r> partials)", 3 * n * sv,
-                 "read Ap, r; write r = 24 n"),
-                ("cg_direction", 3, (f"hipk_cg_direction_kernel<double,false,{nt_streams},false> (x += alpha p, p = r + beta p)"
-                                     if os.environ.get("HIPK_CG_FLAT_DIRECTION", "1" if n * sv > 256 * 1024 * 1024 else "0")[0] == "0"
-                                     or nt_streams == "false" else
-                                     "hipk_cg_scalars_kernel + hipk_cg_direction_flat_kernel<double> (x += alpha p, p = r + beta p; both launches timed)"), 5 * n * sv,
-                 "read r, p, x; write p, x = 40 n")]
-        kernels = []
-        for key, which, name, nbytes, what in legs:
-            us, cnt, over = in_loop(which)
-            k = {"key": key, "kernel": name, "avg_launch_us": us, "launches_timed": cnt,
-                 "algorithmic_bytes_per_launch": nbytes, "bytes_are": what,
-                 "achieved_GBps": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBPS,
-                 "event_pair_overhead_us_subtracted": over, "traffic": traffic_of(key, name),
-                 "traffic_measured_in_this_run": False}
-            if key == "spmv" and coded:   # CSR-formula bytes over the coded kernel's time: an EFFECTIVE figure, no fraction of peak
-                k["effective_GBps_on_csr_bytes"] = spmv_bytes / us / 1e3
-                k["csr_formula_bytes"] = spmv_bytes
-            kernels.append(k)
+        # N = 4 M: the iteration's working set on the coded path (codes 20 MB + x, r, p, Ap 128 MB) sits in the 256 MiB
+        # Infinity Cache, so these kernels are fed by that cache AND HBM: their rates are not fractions of an HBM roofline
+        kernels = cg_legs(h, b, n, "kernels", "infinity-cache+hbm")
         dom = max(kernels, key=lambda k: k["avg_launch_us"])
-        roof = {"bound": "hbm", "kernel": dom["kernel"] + ", timed inside the CG loop", "achieved": dom["achieved_GBps"],
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": dom["traffic"],
-                "traffic_measured_in_this_run": False,
-                "traffic_from_commit": pmc_doc.get("commit") if dom["traffic"] is not None else None,
-                "traffic_source": (f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)"
-                                   if dom["traffic"] is not None else None),
-                "avg_launch_us": dom["avg_launch_us"], "launches_timed": dom["launches_timed"],
-                "event_pair_overhead_us_subtracted": dom["event_pair_overhead_us_subtracted"],
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "why_this_kernel": "longest kernel of the iteration (see `kernels` for all three and `spmv` for the SpMV legs)"}
+        roof = roof_of(dom, "longest kernel of the headline (N = 4 M) CG iteration")
+        roof["timing"] = TIMING
+        roof["traffic_from_build"] = build_id if dom["traffic"] is not None else None
+        roof["traffic_source"] = (f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, same library build)"
+                                  if dom["traffic"] is not None else None)
+        roof["traffic_dropped_because"] = pmc_dropped if dom["traffic"] is None else None
+        roof["library_build_id"] = build_id
+        roof["legs"] = {"cg_dominant_n4m": roof_of(dom, "longest kernel of the headline CG iteration (working set in the Infinity Cache)")}
 
         def standalone(handle):
             g = torch.Generator(device=dev).manual_seed(0)
@@ -383,7 +418,7 @@ def main():
         if coded:
             h.set_path(plain_only=True)
             try:
-                pus, pcnt, _ = in_loop(1)
+                pus, pcnt = in_loop(1, h, b)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 _, _, pst2 = one_solve()
@@ -395,9 +430,35 @@ def main():
                     "GBps": spmv_bytes / pus / 1e3,
                     "frac_of_hbm_peak": spmv_bytes / pus / 1e3 / HBM_PEAK_GBPS, "standalone_us": standalone(h),
                     "cg_iters_per_sec": pst2.iterations / pdt,
-                    "traffic": traffic_of("spmv_plain", pname), "traffic_measured_in_this_run": False}
+                    "traffic": traffic_of("kernels", "spmv_plain", pname)}
+                # the north star's kernel: general CSR SpMV on SURVEY 8d's bytes.  320 MB per product, 160 MB of it (`val`)
+                # loaded non-temporal: beyond the Infinity Cache -> an HBM figure
+                roof["legs"]["csr_spmv_n4m"] = {
+                    "bound": "hbm", "kernel": f"{pname} (general CSR SpMV + fused <p,Ap> tile partials), timed inside the CG loop "
+                                              "of the same matrix with the coded form switched off",
+                    "achieved": spmv_bytes / pus / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": spmv_bytes / pus / 1e3 / HBM_PEAK_GBPS, "traffic": traffic_of("kernels", "spmv_plain", pname),
+                    "avg_launch_us": pus, "launches_timed": pcnt, "algorithmic_bytes_per_launch": spmv_bytes,
+                    "bytes_are": "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8",
+                    "why": "the north star's kernel (target >= 0.70); cg_iters_per_sec on these kernels: "
+                           f"{pst2.iterations / pdt:.0f}"}
             finally:
                 h.set_path(plain_only=False)
+        # ---- HBM-resident leg: the same CG kernels on BASELINE config 5's matrix (8000 x 8000, N = 64 M) on this one device:
+        # vectors of 512 MB each cannot sit in the 256 MiB Infinity Cache
+        if nx == NX and not args.no_n64m and not strong:
+            nb = 8000
+            Ab = create_poisson_2d_csr(nb, nb, device=dev)
+            bb = torch.ones(nb * nb, dtype=torch.float64, device=dev)
+            hb = _hipk.handle_for(Ab)
+            big = cg_legs(hb, bb, nb * nb, "kernels_n64m", "hbm")
+            bdom = max(big, key=lambda k: k["avg_launch_us"])
+            roof["legs"]["cg_dominant_n64m"] = roof_of(bdom, "longest kernel of the CG iteration at N = 64 M (BASELINE config 5's system on one "
+                                                             "device): vectors of 512 MB, HBM-resident")
+            roof["legs"]["cg_kernels_n64m"] = big
+            del Ab, bb, hb
+            _hipk.clear_cache()
+            torch.cuda.empty_cache()
 
     if use_dist:
         # roofline leg at N > 1: this rank's local SpMV (no communication), HIP events on the launch stream,
@@ -444,6 +505,7 @@ def main():
                        "relres": st.residual_norm / st.b_norm,
                        "step": "one full cg() solve" + ("" if use_dist else " via the public API"),
                        "handle_creation_ms_outside_timed_region": handle_ms,
+                       "cold_first_solve_ms": cold_first_solve_ms,
                        "rccl_ranks": world if use_dist else None,
                        "collectives": getattr(prob, "comm_kind", None) if use_dist else None},
             "spmv_standalone": spmv_standalone,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HIPK_VERSION 200
+#define HIPK_VERSION 300
 
 typedef struct hipk_csr_s *hipk_csr_t;
 typedef void *hipk_stream_t; /* hipStream_t */
@@ -64,8 +64,9 @@ typedef struct {
     int32_t gmres_method;  /* hipk_gmres_method                                                            */
     int32_t check_every;   /* stream-ordered polling interval of the fallback pacing (<=0: default), see below */
     int32_t gpu_tolerances;/* 1: GMRES uses the `device.type=='cuda'` tolerance branch (TSL:737-740)       */
-    int32_t profile;       /* 1: bracket every SpMV launch with events and report stats.spmv_ms_avg;
-                              CG only: 2 = the update kernel, 3 = the direction kernel instead              */
+    int32_t profile;       /* 1: time every SpMV launch of the loop (start/stop events bound to the dispatch) and report
+                              stats.spmv_ms_avg; CG only: 2 = the update kernel, 3 = the direction kernel (large systems:
+                              its flat-grid launch), 4 = the scalars launch that precedes the flat-grid one           */
     int32_t reserved;
 } hipk_params;
 
@@ -81,12 +82,16 @@ typedef struct {
     double threshold;       /* the value residual_norm was compared against                         */
     double recurrence_rs;   /* last recurrence <r,r> (CG: gamma)                                    */
     double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
-    double spmv_ms_avg;     /* average SpMV kernel time when params.profile=1 (event-pair overhead removed) */
+    double spmv_ms_avg;     /* average duration of the kernel params.profile selects: the dispatch's own begin/end timestamps
+                               (start/stop events bound to the launch, hipExtLaunchKernel) = what rocprofv3 --kernel-trace prints */
     int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
-    double event_overhead_ms; /* what an event pair adds to the kernel it brackets (null-kernel calibration), already subtracted */
+    double event_overhead_ms; /* always 0 since version 300 (nothing is subtracted any more); kept for layout compatibility */
 } hipk_stats;
 
 int hipk_version(void);
+/* 16 hex digits: sha1 over the sources this library was compiled from (csrc/Makefile).  Counter profiles under profiles/ carry it;
+ * bench.py quotes a `traffic` figure only when it was taken on the build that is running. */
+const char *hipk_build_id(void);
 const char *hipk_last_error(void);
 
 /* Number of visible HIP devices whose arch is gfx950 (0 => nothing can run). */

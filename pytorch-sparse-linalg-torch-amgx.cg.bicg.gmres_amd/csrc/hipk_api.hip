@@ -24,7 +24,9 @@ extern "C" const char *hipk_last_error(void) { return g_err; }
 static thread_local char g_spmv_kernel[96] = "";
 extern "C" const char *hipk_last_spmv_kernel(void) { return g_spmv_kernel; }
 #define HIPK_NOTE_KERNEL(...) snprintf(g_spmv_kernel, sizeof(g_spmv_kernel), __VA_ARGS__)
+#include "hipk_build_id.h"
 extern "C" int hipk_version(void) { return HIPK_VERSION; }
+extern "C" const char *hipk_build_id(void) { return HIPK_BUILD_ID; }
 
 extern "C" int hipk_device_count(void) {
     int n = 0;
@@ -504,12 +506,10 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     if (rowwave) {
         HIPK_NOTE_KERNEL("hipk_spmv_rowwave_kernel<%s>", h->dtype == HIPK_F64 ? "double" : "float");
         const int rgrid = (int)((a.n + 3) / 4);
-        if (prof) prof->before(stream);
         if (h->dtype == HIPK_F64)
-            hipk_spmv_rowwave_kernel<double><<<rgrid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_rowwave_kernel<double>, rgrid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_spmv_rowwave_kernel<float><<<rgrid, HIPK_THREADS, 0, stream>>>(a);
-        if (prof) prof->after(stream);
+            hipk_launch_timed(prof, hipk_spmv_rowwave_kernel<float>, rgrid, HIPK_THREADS, 0, stream, a);
         if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
             if (h->dtype == HIPK_F64)
                 hipk_rowdot_kernel<double><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
@@ -668,9 +668,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
 #undef HIPK_PICK_LOOP
 #undef HIPK_PICK_LOOP_V
 #undef HIPK_PICK_LOOP_U
-            if (prof) prof->before(stream);
-            kern<<<lgrid, HIPK_THREADS, 0, stream>>>(a);
-            if (prof) prof->after(stream);
+            hipk_launch_timed(prof, kern, lgrid, HIPK_THREADS, 0, stream, a);
             if ((!chunked || strided) && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
                 hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                     (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
@@ -679,15 +677,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             HIPK_CHECK_HIP(hipGetLastError());
             return HIPK_OK;
         }
-        if (prof) prof->before(stream);
         HIPK_NOTE_KERNEL("hipk_spmv_coded_kernel<%s,1>", h->dtype == HIPK_F64 ? "double" : "float");
-#define HIPK_LAUNCH_CODED(T, RR) hipk_spmv_coded_kernel<T, RR><<<cgrid, HIPK_THREADS, lds, stream>>>(a)
         if (h->dtype == HIPK_F64)
-            HIPK_LAUNCH_CODED(double, 1);
+            hipk_launch_timed(prof, hipk_spmv_coded_kernel<double, 1>, cgrid, HIPK_THREADS, lds, stream, a);
         else
-            HIPK_LAUNCH_CODED(float, 1);
-#undef HIPK_LAUNCH_CODED
-        if (prof) prof->after(stream);
+            hipk_launch_timed(prof, hipk_spmv_coded_kernel<float, 1>, cgrid, HIPK_THREADS, lds, stream, a);
         if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
             hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
                 (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
@@ -696,7 +690,6 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         HIPK_CHECK_HIP(hipGetLastError());
         return HIPK_OK;
     }
-    if (prof) prof->before(stream);
     {
         const bool f64 = h->dtype == HIPK_F64, shortrows = h->max_row_len <= HIPK_LONG_ROW;
         const int cap = (f64 && h->max_tile_nnz <= 1280 && shortrows) ? 1280 : (h->max_tile_nnz <= 2048 && shortrows) ? 2048 : f64 ? 1280 : 2048;
@@ -705,18 +698,17 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     }
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)
-            hipk_spmv_kernel<double, 1280, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_kernel<double, 1280, true>, grid, HIPK_THREADS, 0, stream, a);
         else if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)  // e.g. 7-point 3-D stencils (1792 per tile)
-            hipk_spmv_kernel<double, 2048, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_kernel<double, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_spmv_kernel<double, 1280, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_kernel<double, 1280, false>, grid, HIPK_THREADS, 0, stream, a);
     } else {
         if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)
-            hipk_spmv_kernel<float, 2048, true><<<grid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_kernel<float, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_spmv_kernel<float, 2048, false><<<grid, HIPK_THREADS, 0, stream>>>(a);
+            hipk_launch_timed(prof, hipk_spmv_kernel<float, 2048, false>, grid, HIPK_THREADS, 0, stream, a);
     }
-    if (prof) prof->after(stream);
     if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
             (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,

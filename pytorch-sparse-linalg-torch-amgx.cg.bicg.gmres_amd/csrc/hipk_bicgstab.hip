@@ -889,7 +889,6 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     HIPK_CHECK_HIP(hipGetLastError());
     hipk_bi_scal hs;
     HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
-    prof.calibrate(stream);
     HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
 

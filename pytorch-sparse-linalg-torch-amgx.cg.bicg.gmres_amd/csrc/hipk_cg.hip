@@ -712,30 +712,31 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             sa.it = it;
             // params.profile selects which kernel the event pairs bracket: 1 SpMV, 2 update, 3 direction
             if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
-            if (prm->profile == 2) prof.before(stream);
+            hipk_spmv_profiler *pu = prm->profile == 2 ? &prof : nullptr, *pd = prm->profile == 3 ? &prof : nullptr;
             if (small)
-                hipk_cg_update_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, A->tile_part, Ap, r,
-                                                                                  part_b, ntiles);
+                hipk_launch_timed(pu, hipk_cg_update_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                                  A->tile_part, Ap, r, part_b, ntiles);
             else if (streams)
-                hipk_cg_update_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
+                hipk_launch_timed(pu, hipk_cg_update_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                                  part_a, Ap, r, part_b, 0);
             else
-                hipk_cg_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, part_a, Ap, r, part_b);
-            if (prm->profile == 2) prof.after(stream);
-            if (prm->profile == 3) prof.before(stream);
+                hipk_launch_timed(pu, hipk_cg_update_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, part_a, Ap, r,
+                                  part_b, 0);
             if (small)
-                hipk_cg_direction_kernel<T, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter,
-                                                                                     A->tile_part, part_b, r, p, x, ntiles);
+                hipk_launch_timed(pd, hipk_cg_direction_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                                  maxiter, A->tile_part, part_b, r, p, x, ntiles);
             else if (streams && flat_dir) {
-                hipk_cg_scalars_kernel<<<1, HIPK_THREADS, 0, stream>>>(gm.g, scal, it, maxiter, part_a, part_b);
-                hipk_cg_direction_flat_kernel<T><<<(unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK), HIPK_THREADS, 0, stream>>>(
-                    n, scal, it, r, p, x);
+                // profile 3 times the flat kernel (the step's 40 n bytes), profile 4 the scalars launch before it
+                hipk_launch_timed(prm->profile == 4 ? &prof : nullptr, hipk_cg_scalars_kernel, 1, HIPK_THREADS, 0, stream, gm.g, scal, it,
+                                  maxiter, part_a, part_b);
+                hipk_launch_timed(pd, hipk_cg_direction_flat_kernel<T>, (unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK),
+                                  HIPK_THREADS, 0, stream, n, scal, it, r, p, x);
             } else if (streams)
-                hipk_cg_direction_kernel<T, false, true><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
-                                                                                            part_b, r, p, x);
+                hipk_launch_timed(pd, hipk_cg_direction_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                                  maxiter, part_a, part_b, r, p, x, 0);
             else
-                hipk_cg_direction_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, maxiter, part_a,
-                                                                                part_b, r, p, x);
-            if (prm->profile == 3) prof.after(stream);
+                hipk_launch_timed(pd, hipk_cg_direction_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, maxiter,
+                                  part_a, part_b, r, p, x, 0);
         }
         if ((it & 63) == 63) HIPK_CHECK_HIP(hipGetLastError());
     }
@@ -758,9 +759,6 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     HIPK_CHECK_HIP(hipGetLastError());
     hipk_cg_scal hs;
     HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
-    // calibration kernel: a chunked dot over r (reads 16 n bytes, writes the spare partial slot): the size class of
-    // the kernels the pairs bracketed
-    prof.calibrate(stream, [&]() { (void)hipk_launch_dot_parts(n, r, r, A->dtype, part_c, stream); });
     HIPK_CHECK_HIP(hipMemcpyAsync(&hs, scal, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
 

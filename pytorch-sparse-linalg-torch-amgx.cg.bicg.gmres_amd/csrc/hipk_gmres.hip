@@ -2291,7 +2291,6 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     HIPK_CHECK_HIP(hipGetLastError());
     double fin[4];
     HIPK_CHECK_HIP(hipEventRecord(whole.b, stream));
-    prof.calibrate(stream);
     HIPK_CHECK_HIP(hipMemcpyAsync(fin, scal, sizeof(fin), hipMemcpyDeviceToHost, stream));
     HIPK_CHECK_HIP(hipStreamSynchronize(stream));
     st->iterations = cycles;

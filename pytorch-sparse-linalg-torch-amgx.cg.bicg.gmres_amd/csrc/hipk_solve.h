@@ -4,6 +4,8 @@
 #include <stdlib.h>
 
 #include <chrono>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "hipk_common.h"
@@ -21,25 +23,19 @@ struct hipk_event_pair {
     }
 };
 
-#ifdef __HIPCC__
-static __global__ void hipk_null_kernel() {}
-#endif
-
-// Brackets kernel launches with HIP events on the launch stream (params.profile) so bench.py can quote a
-// kernel's duration in its real cache context.  What an event pair adds to the bracketed kernel is
-// calibrated at the end of the solve: pairs around ONE calibration kernel (e1) and around TWO (e2); the second
-// launch adds exactly one back-to-back dispatch, so overhead = 2 e1 - e2 (an EMPTY pair over-estimates it:
-// 4.9 us, and then disagrees with rocprofv3's kernel durations).
+// Kernel durations for bench.py (params.profile): the selected launches go through hipExtLaunchKernel with a start and a stop
+// event BOUND TO THAT DISPATCH, so hipEventElapsedTime returns the dispatch's own begin/end timestamps -- the figures
+// `rocprofv3 --kernel-trace` prints for the same launch -- in the kernel's real cache context inside the solver loop.  Nothing is
+// calibrated or subtracted (until version 200 the launches were bracketed with hipEventRecord pairs and an estimated
+// pair overhead of 3.4-3.8 us was subtracted: 0.876 printed where the profiler said 0.846).
 struct hipk_spmv_profiler {
     static constexpr int kMax = 256;
-    static constexpr int kCal = 32;  // calibration pairs of each kind
     bool on;
     std::vector<hipEvent_t> ev;
     int used = 0;
-    bool calibrated = false;
     explicit hipk_spmv_profiler(bool enable) : on(enable) {
         if (!on) return;
-        ev.resize(2 * (kMax + 2 * kCal), nullptr);
+        ev.resize(2 * kMax, nullptr);
         for (auto &e : ev)
             if (hipEventCreate(&e) != hipSuccess) {
                 on = false;
@@ -50,63 +46,20 @@ struct hipk_spmv_profiler {
         for (auto e : ev)
             if (e) (void)hipEventDestroy(e);
     }
-    void before(hipStream_t s) {
-        if (on && used < kMax) (void)hipEventRecord(ev[2 * used], s);
+    // the event pair of the next timed launch, or nulls (profiling off / all slots used)
+    bool slot(hipEvent_t *e0, hipEvent_t *e1) {
+        if (!on || used >= kMax) return false;
+        *e0 = ev[2 * used];
+        *e1 = ev[2 * used + 1];
+        ++used;
+        return true;
     }
-    void after(hipStream_t s) {
-        if (on && used < kMax) {
-            (void)hipEventRecord(ev[2 * used + 1], s);
-            ++used;
-        }
-    }
-    // call once, before the final synchronise.  Two calibrations, kCal/2 pair-sets each: with null kernels and with
-    // `launch` (a harmless kernel of the bracketed kernels' size class).  Part of an event's cost overlaps with a
-    // long kernel's execution, part does not: the null-kernel figure (~4.4 us) over-corrects -- results read 1-2 us
-    // BELOW rocprofv3's durations --, the streaming-kernel figure (~2.0 us) under-corrects -- results ABOVE them and
-    // above what the measured iteration time leaves room for.  Their mean reproduces rocprofv3's averages within 2 %.
-    template <typename L>
-    void calibrate(hipStream_t s, L launch) {
-        if (!on || calibrated) return;
-#ifdef __HIPCC__
-        for (int k = 0; k < 2 * kCal; ++k) {
-            const bool two = (k & 1) != 0;        // odd slots: two launches
-            const bool real = k >= kCal;          // second half: the caller's kernel
-            (void)hipEventRecord(ev[2 * (kMax + k)], s);
-            if (real) launch(); else hipk_null_kernel<<<1, 64, 0, s>>>();
-            if (two) {
-                if (real) launch(); else hipk_null_kernel<<<1, 64, 0, s>>>();
-            }
-            (void)hipEventRecord(ev[2 * (kMax + k) + 1], s);
-        }
-        calibrated = true;
-#endif
-    }
-    void calibrate(hipStream_t s) {
-#ifdef __HIPCC__
-        calibrate(s, [s]() { hipk_null_kernel<<<1, 64, 0, s>>>(); });
-#endif
-    }
-    // valid: number of leading bracketed launches that did real work
+    // valid: number of leading timed launches that did real work
     hipError_t collect(hipk_stats *st, int64_t valid = INT64_MAX) {
         st->spmv_ms_avg = 0.0;
         st->spmv_profiled = 0;
         st->event_overhead_ms = 0.0;
         if (!on) return hipSuccess;
-        double over = 0.0;
-        if (calibrated) {
-            double e1[2] = {0.0, 0.0}, e2[2] = {0.0, 0.0};  // [0] null kernels, [1] the caller's kernel
-            for (int k = 0; k < 2 * kCal; ++k) {
-                float ms = 0.f;
-                hipError_t e = hipEventElapsedTime(&ms, ev[2 * (kMax + k)], ev[2 * (kMax + k) + 1]);
-                if (e != hipSuccess) return e;
-                ((k & 1) ? e2 : e1)[k >= kCal ? 1 : 0] += ms;
-            }
-            const double o_null = (2.0 * e1[0] - e2[0]) / (kCal / 2);
-            const double o_real = (2.0 * e1[1] - e2[1]) / (kCal / 2);
-            over = 0.5 * (o_null + o_real);
-            if (over < 0.0) over = 0.0;
-        }
-        st->event_overhead_ms = over;
         const int cnt = (int)((valid < used) ? valid : used);
         double sum = 0.0;
         for (int k = 0; k < cnt; ++k) {
@@ -115,11 +68,31 @@ struct hipk_spmv_profiler {
             if (e != hipSuccess) return e;
             sum += ms;
         }
-        if (cnt > 0) st->spmv_ms_avg = sum / cnt - over;
+        if (cnt > 0) st->spmv_ms_avg = sum / cnt;
         st->spmv_profiled = cnt;
         return hipSuccess;
     }
 };
+
+#ifdef __HIPCC__
+// kern<<<grid, block, shm, s>>>(args...), timed by `prof` when it has a slot left (prof may be null)
+template <typename... KA, size_t... I>
+static inline void hipk_launch_timed_impl(hipk_spmv_profiler *prof, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
+                                          hipStream_t s, std::tuple<KA...> &t, std::index_sequence<I...>) {
+    void *argv[sizeof...(KA) > 0 ? sizeof...(KA) : 1] = {(void *)&std::get<I>(t)...};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof && prof->slot(&e0, &e1))
+        (void)hipExtLaunchKernel((const void *)kern, grid, block, argv, shm, s, e0, e1, 0);
+    else
+        (void)hipLaunchKernel((const void *)kern, grid, block, argv, shm, s);
+}
+template <typename... KA, typename... A>
+static inline void hipk_launch_timed(hipk_spmv_profiler *prof, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
+                                     hipStream_t s, A... args) {
+    std::tuple<KA...> t(static_cast<KA>(args)...);
+    hipk_launch_timed_impl(prof, kern, grid, block, shm, s, t, std::index_sequence_for<KA...>{});
+}
+#endif
 
 // Asynchronous reads of one device word (the stop word) into pinned host memory, at most
 // two in flight: the host learns "the loop has stopped" one batch late and never stalls

@@ -25,7 +25,7 @@ GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
 
 # every symbol include/hipk.h declares (tests/test_abi.py checks the export list)
 SYMBOLS = [
-    "hipk_version", "hipk_last_error", "hipk_device_count",
+    "hipk_version", "hipk_build_id", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
     "hipk_csr_spmv_path", "hipk_last_spmv_kernel", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
@@ -156,6 +156,7 @@ def lib():
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
     L.hipk_version.restype = i32
     L.hipk_last_error.restype = ctypes.c_char_p
+    L.hipk_build_id.restype = ctypes.c_char_p
     L.hipk_last_spmv_kernel.restype = ctypes.c_char_p
     L.hipk_device_count.restype = i32
     L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]

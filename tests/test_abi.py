@@ -25,7 +25,8 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/hipk.h but not exported by libhipk.so"
     assert sorted(_hipk.SYMBOLS) == declared, "python binding list out of sync with include/hipk.h"
-    assert L.hipk_version() == 200
+    assert L.hipk_version() == 300
+    assert len(L.hipk_build_id()) == 16
     assert L.hipk_scratch_bytes() == 4 * 2048 * 8
     # geometry helpers are pure host code
     assert (L.hipk_chunk_size(4_000_000), L.hipk_chunk_count(4_000_000)) == (2048, 1954)

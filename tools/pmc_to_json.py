@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel HBM-side traffic from the rocprofv3 --pmc passes of tools/prof_bench.sh / tools/prof_solvers.sh.
-usage: python tools/pmc_to_json.py gpurun_out/<name> profiles/<out>.json [--commit SHA]
+usage: python tools/pmc_to_json.py gpurun_out/<name> profiles/<out>.json [--commit SHA] [--build-id ID]
+`build_id` = hipk_build_id() of the library the counters were taken on (default: the library in the tree, which is the one the
+profiled command loaded when this runs in the same gpurun call); bench.py quotes `traffic` only when it equals its own.
 Launches that returned at once (iterations past the stop word, unwanted second CGS passes) are dropped: only launches whose
 counter is at least half of the kernel's maximum enter the mean -- except for the GMRES kernels, whose traffic grows with the
 Arnoldi step (every launch above 1 % of the maximum counts there; the mean is then the mean over a restart cycle).
@@ -19,14 +21,27 @@ else:
         commit = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:
         pass
+build_id = None
+if "--build-id" in sys.argv:
+    build_id = sys.argv[sys.argv.index("--build-id") + 1]
+else:
+    try:
+        import ctypes
+        _L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd/pytorch_sparse_solver/_lib/libhipk.so"))
+        _L.hipk_build_id.restype = ctypes.c_char_p
+        build_id = _L.hipk_build_id().decode()
+    except Exception:
+        pass
 N = 4_000_000
+NB = 64_000_000
 MB = 1e6
 # key -> (kernel-name pattern, algorithmic bytes per launch at N = 4 M fp64 (None: varies), what they are, cycle-mean kernels)
 KEYS = {
-    "spmv": ("hipk_spmv_sell_", None, "coded SpMV: bytes its format streams (hipk_csr_format_bytes)", False),
+    "spmv": ("hipk_spmv_sell_wide_kernel<5, 1, 0>", None, "coded SpMV: bytes its format streams (hipk_csr_format_bytes)", False),
     "spmv_plain": ("hipk_spmv_kernel<double", 319_904_004, "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8", False),
-    "cg_update": ("hipk_cg_update_kernel<double", 24 * N, "read Ap, r; write r", False),
-    "cg_direction": ("hipk_cg_direction_kernel<double", 40 * N, "read r, p, x; write p, x", False),
+    "cg_update": ("hipk_cg_update_kernel<double, false, false>", 24 * N, "read Ap, r; write r", False),
+    "cg_direction": ("hipk_cg_direction_kernel<double, false, false, false>", 40 * N, "read r, p, x; write p, x", False),
     "gm_multidot": ("hipk_gm_multidot_stream_kernel<double", int(17.5 * 8 * N), "mean over k = 0..29 of 8n(k+2): w + k+1 columns", True),
     "gm_update": ("hipk_gm_update_stream_kernel<double", int(18.5 * 8 * N), "mean over k = 0..29 of 8n(k+3): w in/out + k+1 columns", True),
     "gm_normalize": ("hipk_gm_normalize_kernel<double", 16 * N, "read w, write v", False),
@@ -35,9 +50,15 @@ KEYS = {
     "bi_supdate": ("hipk_bi_supdate_kernel<double", 24 * N, "read r, q; write s", False),
     "bi_xupdate": ("hipk_bi_xupdate_kernel<double", 56 * N, "read x, p, s, t, rhat; write x, r", False),
 }
+# the same CG kernels on the N = 64 M system of bench.py's HBM-resident leg (other instantiations: streaming policy, grouped walk)
+KEYS_N64M = {
+    "spmv": ("hipk_spmv_sell_wide_kernel<5, 1, 1>", None, "coded SpMV, grouped walk: bytes its format streams", False),
+    "cg_update": ("hipk_cg_update_kernel<double, false, true>", 24 * NB, "read Ap, r; write r", False),
+    "cg_direction": ("hipk_cg_direction_flat_kernel<double>", 40 * NB, "read r, p, x; write p, x", False),
+}
 
 
-def means(counter_dir, counter):
+def means(counter_dir, counter, KEYS=KEYS):
     out = {}
     for f in glob.glob(os.path.join(src, "**", counter_dir, "**", "*counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(list)
@@ -56,9 +77,10 @@ def means(counter_dir, counter):
     return out
 
 
-fetch, write = means("pmc_fetch", "FETCH_SIZE"), means("pmc_write", "WRITE_SIZE")
-kern = {}
-for key in fetch:
+def section(KEYS):
+  fetch, write = means("pmc_fetch", "FETCH_SIZE", KEYS), means("pmc_write", "WRITE_SIZE", KEYS)
+  kern = {}
+  for key in fetch:
     w = write.get(key, {"mean_KB": 0.0})
     _, alg, what, _ = KEYS[key]
     kern[key] = {"kernel": fetch[key]["kernel"], "FETCH_SIZE_KB_mean": fetch[key]["mean_KB"],
@@ -66,9 +88,13 @@ for key in fetch:
                  "dropped_noop_launches": fetch[key]["dropped_noop_launches"],
                  "traffic_bytes_per_launch": int(round((2.0 * fetch[key]["mean_KB"] + w["mean_KB"]) * 1024.0)),
                  "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_are": what}
-json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({src})", "commit": commit,
+  return kern
+
+
+kern, kern_big = section(KEYS), section(KEYS_N64M)
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({src})", "commit": commit, "build_id": build_id,
            "fetch_correction": 2.0,
            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE; counters are KiB (1024 B: WRITE_SIZE of a 32,000,000-byte vector reads 31250.0); "
                    "FETCH_SIZE includes Infinity-Cache hits",
-           "kernels": kern}, open(dst, "w"), indent=1)
+           "kernels": kern, "kernels_n64m": kern_big}, open(dst, "w"), indent=1)
 print(json.dumps(kern, indent=1))
