@@ -39,7 +39,16 @@ def test_bench_line_default_and_dist_rehearsal():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["info"] == 0 and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
+    roof = d["roofline"]
+    assert roof["bound"] == "infinity-cache+hbm" and 0 < roof["frac"] < 1.2
+    assert "nothing subtracted" in roof["timing"] and len(roof["library_build_id"]) == 16
+    # legs: the dominant CG kernel and the general CSR SpMV (the N = 64 M leg only runs at the headline size)
+    assert roof["legs"]["cg_dominant_n4m"]["frac"] == roof["frac"]
+    assert roof["legs"]["csr_spmv_n4m"]["bound"] == "hbm" and roof["legs"]["csr_spmv_n4m"]["avg_launch_us"] > 0
+    assert "hipk_spmv_kernel" in roof["legs"]["csr_spmv_n4m"]["kernel"]
+    # a traffic figure is only quoted from a counter profile of the library build that is running
+    assert roof["traffic"] is None or roof["traffic_from_build"] == roof["library_build_id"]
+    assert d["config"]["cold_first_solve_ms"] > d["config"]["handle_creation_ms_outside_timed_region"] > 0
     for k in d["kernels"]:
         assert 0 < k["frac_of_hbm_peak"] < 1.2, k       # no fraction-of-peak above what a cache-resident toy grid can show
     assert d["spmv"]["GBps_on_format_bytes"] > 0 and "effective_GBps_on_csr_bytes" in d["spmv"]
