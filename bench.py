@@ -308,8 +308,10 @@ def main():
     spmv_standalone = None
     kernels = None
     spmv_report = None
-    TIMING = ("dispatch begin/end timestamps (start/stop events bound to the launch, hipExtLaunchKernel) = the durations "
-              "rocprofv3 --kernel-trace prints; nothing subtracted")
+    TIMING = ("every launch of 256 profiled CG iterations carries start/stop events bound to its dispatch (hipExtLaunchKernel); "
+              "avg_launch_us = stop of the launch - stop of the launch before it on the stream = the time the kernel occupies "
+              "the stream (the three kernels add up to the iteration time); nothing subtracted; dispatch_span_us = the launch's "
+              "own stop - start, for reference; rocprofv3 --kernel-trace averages of the same command: profiles/")
     if not use_dist:
         n = nx * nx
         sv = 8
@@ -329,7 +331,7 @@ def main():
         def in_loop(which, handle, rhs):
             xx = torch.zeros_like(rhs)
             pst = _hipk.solve("cg", handle, rhs, xx, tol=args.tol, atol=0.0, maxiter=256, profile=which)
-            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled
+            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled, pst.dispatch_span_ms_avg * 1e3
 
         def cg_legs(handle, rhs, nn, section, bound):
             """The three kernels of the CG iteration on `handle`: name, algorithmic bytes, in-loop duration."""
@@ -355,8 +357,9 @@ def main():
                      "read r, p, x; write p, x = 40 n")]
             out = []
             for key, which, name, nbytes, what in legs:
-                us, cnt = in_loop(which, handle, rhs)
+                us, cnt, span = in_loop(which, handle, rhs)
                 k = {"key": key, "kernel": name, "bound": bound, "avg_launch_us": us, "launches_timed": cnt,
+                     "dispatch_span_us": span,
                      "algorithmic_bytes_per_launch": nbytes, "bytes_are": what,
                      "achieved_GBps": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBPS,
                      "traffic": traffic_of(section, key, name)}
@@ -365,6 +368,7 @@ def main():
                     k["csr_formula_bytes"] = sb
                 if key == "cg_direction" and flat:
                     k["scalars_launch_us"] = in_loop(4, handle, rhs)[0]
+                    k["avg_launch_us_is"] = "the flat-grid launch alone; the step's two launches take avg_launch_us + scalars_launch_us"
                 out.append(k)
             return out
 
@@ -372,7 +376,7 @@ def main():
             return {"bound": k["bound"], "kernel": k["kernel"] + ", timed inside the CG loop", "achieved": k["achieved_GBps"],
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": k["traffic"],
                     "avg_launch_us": k["avg_launch_us"], "launches_timed": k["launches_timed"],
-                    "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "bytes_are": k["bytes_are"], "why": why}
+                    "dispatch_span_us": k["dispatch_span_us"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "bytes_are": k["bytes_are"], "why": why}
 
         path = h.path()
         fbytes = h.format_bytes()
@@ -383,6 +387,9 @@ def main():
         dom = max(kernels, key=lambda k: k["avg_launch_us"])
         roof = roof_of(dom, "longest kernel of the headline (N = 4 M) CG iteration")
         roof["timing"] = TIMING
+        # cross-check: the three chain figures against the iteration time of the timed region (wall clock / iterations)
+        roof["iteration_us_sum_of_kernels"] = sum(k["avg_launch_us"] for k in kernels)
+        roof["iteration_us_from_timed_region"] = dt / max(iters_total, 1) * 1e6
         roof["traffic_from_build"] = build_id if dom["traffic"] is not None else None
         roof["traffic_source"] = (f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, same library build)"
                                   if dom["traffic"] is not None else None)
@@ -418,7 +425,7 @@ def main():
         if coded:
             h.set_path(plain_only=True)
             try:
-                pus, pcnt = in_loop(1, h, b)
+                pus, pcnt, pspan = in_loop(1, h, b)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 _, _, pst2 = one_solve()
@@ -438,8 +445,8 @@ def main():
                                               "of the same matrix with the coded form switched off",
                     "achieved": spmv_bytes / pus / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": spmv_bytes / pus / 1e3 / HBM_PEAK_GBPS, "traffic": traffic_of("kernels", "spmv_plain", pname),
-                    "avg_launch_us": pus, "launches_timed": pcnt, "algorithmic_bytes_per_launch": spmv_bytes,
-                    "bytes_are": "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8",
+                    "avg_launch_us": pus, "launches_timed": pcnt, "dispatch_span_us": pspan,
+                    "algorithmic_bytes_per_launch": spmv_bytes, "bytes_are": "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8",
                     "why": "the north star's kernel (target >= 0.70); cg_iters_per_sec on these kernels: "
                            f"{pst2.iterations / pdt:.0f}"}
             finally:

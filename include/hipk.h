@@ -82,10 +82,13 @@ typedef struct {
     double threshold;       /* the value residual_norm was compared against                         */
     double recurrence_rs;   /* last recurrence <r,r> (CG: gamma)                                    */
     double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
-    double spmv_ms_avg;     /* average duration of the kernel params.profile selects: the dispatch's own begin/end timestamps
-                               (start/stop events bound to the launch, hipExtLaunchKernel) = what rocprofv3 --kernel-trace prints */
+    double spmv_ms_avg;     /* average duration of the kernel params.profile selects.  CG: stop event of the launch minus stop
+                               event of the launch before it on the stream (every launch of the profiled iterations carries
+                               events bound to its dispatch, hipExtLaunchKernel): the time the kernel occupies the stream; the
+                               figures of an iteration's kernels add up to the iteration time.  BiCGStab / GMRES (SpMV launches
+                               only): the launch's own stop - start.  Nothing is subtracted. */
     int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
-    double event_overhead_ms; /* always 0 since version 300 (nothing is subtracted any more); kept for layout compatibility */
+    double dispatch_span_ms_avg; /* stop - start of the selected launches' own events (version 200: event_overhead_ms) */
 } hipk_stats;
 
 int hipk_version(void);

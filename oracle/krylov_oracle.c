@@ -46,6 +46,8 @@
 #define ORC_MAX_PARTS 2048
 #define ORC_BASE_CHUNK 2048
 #define ORC_LONG_ROW 32
+#define ORC_MAXM 127 /* largest GMRES restart (the reference accepts any, TSL:641-644) */
+#define ORC_LD 128
 #define ORC_EPS64 2.220446049250313e-16 /* torch.finfo(torch.float64).eps */
 #define ORC_EPS32 1.1920928955078125e-07 /* torch.finfo(torch.float32).eps */
 #ifdef ORC_F32
@@ -642,72 +644,78 @@ int orc_bicgstab_jacobi(int64_t n, const int32_t *crow, const int32_t *col, cons
 /* `_lstsq` normal equations + Cholesky, fallback general solve (TSL:391-428).
    H is (m+1) x m row-major with leading dimension ldh; uses rows 0..k, cols 0..k-1. */
 static void lstsq_normal(const double *H, int ldh, int k, double beta0, double *y) {
-    double a2[32 * 32], b2[32], L[32 * 32];
+    /* restart <= ORC_MAXM: the arrays live on the heap with leading dimension ORC_LD (the arithmetic does not depend on it) */
+    double *a2 = (double *)malloc(sizeof(double) * ORC_LD * ORC_LD), *L = (double *)calloc((size_t)ORC_LD * ORC_LD, sizeof(double));
+    double *M = (double *)malloc(sizeof(double) * ORC_LD * (ORC_LD + 1));
+    double b2[ORC_LD], z[ORC_LD];
     for (int i = 0; i < k; ++i) {
         for (int j = 0; j < k; ++j) {
             double s = 0.0;
             for (int p = 0; p <= k; ++p) s = fma(H[p * ldh + i], H[p * ldh + j], s);
-            a2[i * 32 + j] = s;
+            a2[i * ORC_LD + j] = s;
         }
         b2[i] = H[0 * ldh + i] * beta0; /* beta_vec = [beta0, 0, ...] */
     }
     int ok = 1;
-    memset(L, 0, sizeof(L));
     for (int j = 0; j < k && ok; ++j) {
-        double d = a2[j * 32 + j];
-        for (int p = 0; p < j; ++p) d = fma(-L[j * 32 + p], L[j * 32 + p], d);
+        double d = a2[j * ORC_LD + j];
+        for (int p = 0; p < j; ++p) d = fma(-L[j * ORC_LD + p], L[j * ORC_LD + p], d);
         if (!(d > 0.0)) {
             ok = 0;
             break;
         }
         const double ljj = sqrt(d);
-        L[j * 32 + j] = ljj;
+        L[j * ORC_LD + j] = ljj;
         for (int i = j + 1; i < k; ++i) {
-            double s = a2[i * 32 + j];
-            for (int p = 0; p < j; ++p) s = fma(-L[i * 32 + p], L[j * 32 + p], s);
-            L[i * 32 + j] = s / ljj;
+            double s = a2[i * ORC_LD + j];
+            for (int p = 0; p < j; ++p) s = fma(-L[i * ORC_LD + p], L[j * ORC_LD + p], s);
+            L[i * ORC_LD + j] = s / ljj;
         }
     }
     if (ok) {
-        double z[32];
         for (int i = 0; i < k; ++i) {
             double s = b2[i];
-            for (int p = 0; p < i; ++p) s = fma(-L[i * 32 + p], z[p], s);
-            z[i] = s / L[i * 32 + i];
+            for (int p = 0; p < i; ++p) s = fma(-L[i * ORC_LD + p], z[p], s);
+            z[i] = s / L[i * ORC_LD + i];
         }
         for (int i = k - 1; i >= 0; --i) {
             double s = z[i];
-            for (int p = i + 1; p < k; ++p) s = fma(-L[p * 32 + i], y[p], s);
-            y[i] = s / L[i * 32 + i];
+            for (int p = i + 1; p < k; ++p) s = fma(-L[p * ORC_LD + i], y[p], s);
+            y[i] = s / L[i * ORC_LD + i];
         }
+        free(a2);
+        free(L);
+        free(M);
         return;
     }
     /* torch.linalg.solve fallback: Gaussian elimination with partial pivoting */
-    double M[32 * 33];
     for (int i = 0; i < k; ++i) {
-        for (int j = 0; j < k; ++j) M[i * 33 + j] = a2[i * 32 + j];
-        M[i * 33 + k] = b2[i];
+        for (int j = 0; j < k; ++j) M[i * (ORC_LD + 1) + j] = a2[i * ORC_LD + j];
+        M[i * (ORC_LD + 1) + k] = b2[i];
     }
     for (int c = 0; c < k; ++c) {
         int piv = c;
         for (int i = c + 1; i < k; ++i)
-            if (fabs(M[i * 33 + c]) > fabs(M[piv * 33 + c])) piv = i;
+            if (fabs(M[i * (ORC_LD + 1) + c]) > fabs(M[piv * (ORC_LD + 1) + c])) piv = i;
         if (piv != c)
             for (int j = 0; j <= k; ++j) {
-                const double tmp = M[c * 33 + j];
-                M[c * 33 + j] = M[piv * 33 + j];
-                M[piv * 33 + j] = tmp;
+                const double tmp = M[c * (ORC_LD + 1) + j];
+                M[c * (ORC_LD + 1) + j] = M[piv * (ORC_LD + 1) + j];
+                M[piv * (ORC_LD + 1) + j] = tmp;
             }
         for (int i = c + 1; i < k; ++i) {
-            const double f = M[i * 33 + c] / M[c * 33 + c];
-            for (int j = c; j <= k; ++j) M[i * 33 + j] = fma(-f, M[c * 33 + j], M[i * 33 + j]);
+            const double f = M[i * (ORC_LD + 1) + c] / M[c * (ORC_LD + 1) + c];
+            for (int j = c; j <= k; ++j) M[i * (ORC_LD + 1) + j] = fma(-f, M[c * (ORC_LD + 1) + j], M[i * (ORC_LD + 1) + j]);
         }
     }
     for (int i = k - 1; i >= 0; --i) {
-        double s = M[i * 33 + k];
-        for (int p = i + 1; p < k; ++p) s = fma(-M[i * 33 + p], y[p], s);
-        y[i] = s / M[i * 33 + i];
+        double s = M[i * (ORC_LD + 1) + k];
+        for (int p = i + 1; p < k; ++p) s = fma(-M[i * (ORC_LD + 1) + p], y[p], s);
+        y[i] = s / M[i * (ORC_LD + 1) + i];
     }
+    free(a2);
+    free(L);
+    free(M);
 }
 
 /* `_givens_rotation` (TSL:508-518) */
@@ -738,14 +746,15 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
                       const real *b, real *x, double tol, double atol, int restart, int64_t maxiter,
                       int method /*0 batched,1 incremental*/, int gpu_tolerances, orc_stats *st) {
     memset(st, 0, sizeof(*st));
-    if (restart < 1 || restart > 31) return -1;
+    if (restart < 1 || restart > ORC_MAXM) return -1;
     if (maxiter < 0) maxiter = 10 * n;
     const int m = restart;
     const size_t nb = sizeof(real) * (size_t)n;
     real *V = (real *)malloc(nb * (size_t)(m + 1)); /* column j at V + j*n */
     real *tmp = (real *)malloc(nb);
-    double H[32 * 32], R[32 * 32], gv[32][2], beta_vec[33], rvec[32], hvec[32], y[32];
-    const int ldh = 32;
+    const int ldh = ORC_LD;
+    double *H = (double *)malloc(sizeof(double) * (ORC_LD + 1) * ORC_LD), *R = (double *)malloc(sizeof(double) * ORC_LD * ORC_LD);
+    double gv[ORC_LD][2], beta_vec[ORC_LD + 1], rvec[ORC_LD], hvec[ORC_LD], y[ORC_LD];
 
     const double bs = orc_dot(n, b, b);
     const double b_norm = norm_from_sq(bs);
@@ -772,9 +781,9 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
     int64_t cycles = 0;
     int happy = 0;
     while (cycles < maxiter && res_norm > atol_eff) {
-        memset(H, 0, sizeof(H));
-        memset(R, 0, sizeof(R));
-        for (int i = 0; i < 32; ++i) R[i * 32 + i] = 1.0; /* TSL:581 */
+        memset(H, 0, sizeof(double) * (ORC_LD + 1) * ORC_LD);
+        memset(R, 0, sizeof(double) * ORC_LD * ORC_LD);
+        for (int i = 0; i < ORC_LD; ++i) R[i * ORC_LD + i] = 1.0; /* TSL:581 */
         memset(gv, 0, sizeof(gv));
         memset(beta_vec, 0, sizeof(beta_vec));
         beta_vec[0] = res_norm;
@@ -821,7 +830,7 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
             breakdown = (norm1 == 0.0);
             if (method == 1) {
                 /* TSL:595-623 */
-                double hc[33];
+                double hc[ORC_LD + 1];
                 for (int j = 0; j <= k + 1; ++j) hc[j] = H[j * ldh + k];
                 for (int i = 0; i < k; ++i) {
                     const double cs = gv[i][0], sn = gv[i][1];
@@ -835,7 +844,7 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
                 gv[k][1] = sn;
                 hc[k] = cs * hc[k] - sn * hc[k + 1];
                 hc[k + 1] = 0.0;
-                for (int j = 0; j <= k; ++j) R[j * 32 + k] = hc[j];
+                for (int j = 0; j <= k; ++j) R[j * ORC_LD + k] = hc[j];
                 const double t0 = cs * beta_vec[k] - sn * beta_vec[k + 1];
                 beta_vec[k + 1] = sn * beta_vec[k] + cs * beta_vec[k + 1];
                 beta_vec[k] = t0;
@@ -850,8 +859,8 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
             } else {
                 for (int i = k - 1; i >= 0; --i) { /* solve_triangular, TSL:630 */
                     double s = beta_vec[i];
-                    for (int p = i + 1; p < k; ++p) s = fma(-R[i * 32 + p], y[p], s);
-                    y[i] = s / R[i * 32 + i];
+                    for (int p = i + 1; p < k; ++p) s = fma(-R[i * ORC_LD + p], y[p], s);
+                    y[i] = s / R[i * ORC_LD + i];
                 }
             }
 #pragma omp parallel for schedule(static) if (g_threads > 1)
@@ -886,6 +895,8 @@ static int gmres_impl(int64_t n, const int32_t *crow, const int32_t *col, const 
     st->recurrence_rs = res_norm;
     free(V);
     free(tmp);
+    free(H);
+    free(R);
     return 0;
 }
 

@@ -269,7 +269,7 @@ def gmres(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=No
                          -1 if maxiter is None else int(maxiter), method, 1 if gpu_tolerances else 0,
                          ctypes.byref(st))
     if rc != 0:
-        raise ValueError("oracle gmres supports 1 <= restart <= 31")
+        raise ValueError("oracle gmres supports 1 <= restart <= 127")
     return _result(x, st)
 
 
@@ -294,7 +294,7 @@ def gmres_jacobi(crow, col, val, dinv, b, x0=None, tol=1e-5, atol=0.0, restart=2
                                 int(restart), -1 if maxiter is None else int(maxiter), method,
                                 1 if gpu_tolerances else 0, ctypes.byref(st))
     if rc != 0:
-        raise ValueError("oracle gmres supports 1 <= restart <= 31")
+        raise ValueError("oracle gmres supports 1 <= restart <= 127")
     return _result(x, st)
 
 
@@ -359,5 +359,5 @@ def gmres32(crow, col, val, b, x0=None, tol=1e-5, atol=0.0, restart=20, maxiter=
                            -1 if maxiter is None else int(maxiter), method, 1 if gpu_tolerances else 0,
                            ctypes.byref(st))
     if rc != 0:
-        raise ValueError("oracle gmres supports 1 <= restart <= 31")
+        raise ValueError("oracle gmres supports 1 <= restart <= 127")
     return _result(x, st)

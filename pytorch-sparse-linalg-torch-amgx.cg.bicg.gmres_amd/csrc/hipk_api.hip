@@ -507,16 +507,15 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         HIPK_NOTE_KERNEL("hipk_spmv_rowwave_kernel<%s>", h->dtype == HIPK_F64 ? "double" : "float");
         const int rgrid = (int)((a.n + 3) / 4);
         if (h->dtype == HIPK_F64)
-            hipk_launch_timed(prof, hipk_spmv_rowwave_kernel<double>, rgrid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_rowwave_kernel<double>, rgrid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_launch_timed(prof, hipk_spmv_rowwave_kernel<float>, rgrid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_rowwave_kernel<float>, rgrid, HIPK_THREADS, 0, stream, a);
         if (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)) {
             if (h->dtype == HIPK_F64)
                 hipk_rowdot_kernel<double><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
             else
                 hipk_rowdot_kernel<float><<<ntiles, HIPK_THREADS, 0, stream>>>(a);
-            if (!a.skip_combine) hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
-                (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+            if (!a.skip_combine) hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream, (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
                 a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
         }
         HIPK_CHECK_HIP(hipGetLastError());
@@ -668,10 +667,9 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
 #undef HIPK_PICK_LOOP
 #undef HIPK_PICK_LOOP_V
 #undef HIPK_PICK_LOOP_U
-            hipk_launch_timed(prof, kern, lgrid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, kern, lgrid, HIPK_THREADS, 0, stream, a);
             if ((!chunked || strided) && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
-                hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
-                    (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
+                hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream, (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
                     a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
             }
             HIPK_CHECK_HIP(hipGetLastError());
@@ -679,12 +677,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         }
         HIPK_NOTE_KERNEL("hipk_spmv_coded_kernel<%s,1>", h->dtype == HIPK_F64 ? "double" : "float");
         if (h->dtype == HIPK_F64)
-            hipk_launch_timed(prof, hipk_spmv_coded_kernel<double, 1>, cgrid, HIPK_THREADS, lds, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_coded_kernel<double, 1>, cgrid, HIPK_THREADS, lds, stream, a);
         else
-            hipk_launch_timed(prof, hipk_spmv_coded_kernel<float, 1>, cgrid, HIPK_THREADS, lds, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_coded_kernel<float, 1>, cgrid, HIPK_THREADS, lds, stream, a);
         if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
-            hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
-                (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+            hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream, (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
                 a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
         }
         HIPK_CHECK_HIP(hipGetLastError());
@@ -698,20 +695,19 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     }
     if (h->dtype == HIPK_F64) {
         if (h->max_tile_nnz <= 1280 && h->max_row_len <= HIPK_LONG_ROW)
-            hipk_launch_timed(prof, hipk_spmv_kernel<double, 1280, true>, grid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_kernel<double, 1280, true>, grid, HIPK_THREADS, 0, stream, a);
         else if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)  // e.g. 7-point 3-D stencils (1792 per tile)
-            hipk_launch_timed(prof, hipk_spmv_kernel<double, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_kernel<double, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_launch_timed(prof, hipk_spmv_kernel<double, 1280, false>, grid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_kernel<double, 1280, false>, grid, HIPK_THREADS, 0, stream, a);
     } else {
         if (h->max_tile_nnz <= 2048 && h->max_row_len <= HIPK_LONG_ROW)
-            hipk_launch_timed(prof, hipk_spmv_kernel<float, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_kernel<float, 2048, true>, grid, HIPK_THREADS, 0, stream, a);
         else
-            hipk_launch_timed(prof, hipk_spmv_kernel<float, 2048, false>, grid, HIPK_THREADS, 0, stream, a);
+            hipk_launch_timed(prof, HIPK_K_SPMV, hipk_spmv_kernel<float, 2048, false>, grid, HIPK_THREADS, 0, stream, a);
     }
     if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
-        hipk_tile_combine_kernel<<<(a.g + 3) / 4, HIPK_THREADS, 0, stream>>>(
-            (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
+        hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream, (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr, a.part0,
             a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
     }
     HIPK_CHECK_HIP(hipGetLastError());

@@ -704,7 +704,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
 
     hipk_event_pair whole;
     HIPK_CHECK_HIP(whole.create());
-    hipk_spmv_profiler prof(prm->profile != 0);
+    hipk_spmv_profiler prof(prm->profile != 0 ? HIPK_K_SPMV : 0);
     HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
 
     hipk_spmv_args sa;
@@ -795,10 +795,13 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 8192;
         if (ca.max_its < 1) ca.max_its = 1;
-        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
+        // tests: HIPK_TEST_LDS_NOT_RESIDENT=k makes the k-th launch of this solve report its workgroups as not co-resident
+        const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+        int launch_no = 0;
         hipk_bi_scal hs0;
         for (;;) {
             ca.it0 = it;
+            ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
             HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 3 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
             if (local)
@@ -817,7 +820,14 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                     local = false;
                     continue;
                 }
-                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // not co-resident; nothing was modified: the launch sequence below takes over
+                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // not co-resident; this launch modified nothing: the launch sequence below takes over
+                if (it > 0) {
+                    // ... from iteration `it` of an EARLIER launch: the vectors and scalars are in memory, but part_rr / part_rhr hold
+                    // that launch's 8 g SUB-partials, not the g chunk partials the direction kernel folds.  Recompute them from r
+                    // and rhat (the spec's plain dot: the bits the x-update kernel of the launch sequence would have left)
+                    if ((rc = hipk_launch_dot_parts(n, r, r, A->dtype, part_rr, stream)) != HIPK_OK) return rc;
+                    if ((rc = hipk_launch_dot_parts(n, rhat, r, A->dtype, part_rhr, stream)) != HIPK_OK) return rc;
+                }
                 lds_loop = false;
                 break;
             }

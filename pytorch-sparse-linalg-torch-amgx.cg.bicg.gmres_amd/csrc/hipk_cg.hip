@@ -582,7 +582,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
 
     hipk_event_pair whole;
     HIPK_CHECK_HIP(whole.create());
-    hipk_spmv_profiler prof(prm->profile != 0);
+    hipk_spmv_profiler prof(prm->profile, /*chain=*/true);   // every launch of the profiled iterations is timed (hipk_solve.h)
     HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
 
     hipk_spmv_args sa;
@@ -675,10 +675,13 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 16384;
         if (ca.max_its < 1) ca.max_its = 1;
-        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
+        // tests: HIPK_TEST_LDS_NOT_RESIDENT=k makes the k-th launch of this solve report its workgroups as not co-resident
+        const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+        int launch_no = 0;
         hipk_cg_scal hs0;
         for (;;) {
             ca.it0 = it;
+            ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
             HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
             if (local)
@@ -710,32 +713,31 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         if (stop <= it) break;
         {
             sa.it = it;
-            // params.profile selects which kernel the event pairs bracket: 1 SpMV, 2 update, 3 direction
-            if ((rc = hipk_launch_spmv(A, sa, stream, prm->profile == 1 ? &prof : nullptr)) != HIPK_OK) return rc;
-            hipk_spmv_profiler *pu = prm->profile == 2 ? &prof : nullptr, *pd = prm->profile == 3 ? &prof : nullptr;
+            // params.profile selects the kernel whose durations are reported (1 SpMV, 2 update, 3 direction, 4 scalars)
+            if ((rc = hipk_launch_spmv(A, sa, stream, &prof)) != HIPK_OK) return rc;
             if (small)
-                hipk_launch_timed(pu, hipk_cg_update_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                hipk_launch_timed(&prof, HIPK_K_UPDATE, hipk_cg_update_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
                                   A->tile_part, Ap, r, part_b, ntiles);
             else if (streams)
-                hipk_launch_timed(pu, hipk_cg_update_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                hipk_launch_timed(&prof, HIPK_K_UPDATE, hipk_cg_update_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
                                   part_a, Ap, r, part_b, 0);
             else
-                hipk_launch_timed(pu, hipk_cg_update_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, part_a, Ap, r,
+                hipk_launch_timed(&prof, HIPK_K_UPDATE, hipk_cg_update_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, part_a, Ap, r,
                                   part_b, 0);
             if (small)
-                hipk_launch_timed(pd, hipk_cg_direction_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                hipk_launch_timed(&prof, HIPK_K_DIRECTION, hipk_cg_direction_kernel<T, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
                                   maxiter, A->tile_part, part_b, r, p, x, ntiles);
             else if (streams && flat_dir) {
                 // profile 3 times the flat kernel (the step's 40 n bytes), profile 4 the scalars launch before it
-                hipk_launch_timed(prm->profile == 4 ? &prof : nullptr, hipk_cg_scalars_kernel, 1, HIPK_THREADS, 0, stream, gm.g, scal, it,
+                hipk_launch_timed(&prof, HIPK_K_SCALARS, hipk_cg_scalars_kernel, 1, HIPK_THREADS, 0, stream, gm.g, scal, it,
                                   maxiter, part_a, part_b);
-                hipk_launch_timed(pd, hipk_cg_direction_flat_kernel<T>, (unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK),
+                hipk_launch_timed(&prof, HIPK_K_DIRECTION, hipk_cg_direction_flat_kernel<T>, (unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK),
                                   HIPK_THREADS, 0, stream, n, scal, it, r, p, x);
             } else if (streams)
-                hipk_launch_timed(pd, hipk_cg_direction_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
+                hipk_launch_timed(&prof, HIPK_K_DIRECTION, hipk_cg_direction_kernel<T, false, true>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it,
                                   maxiter, part_a, part_b, r, p, x, 0);
             else
-                hipk_launch_timed(pd, hipk_cg_direction_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, maxiter,
+                hipk_launch_timed(&prof, HIPK_K_DIRECTION, hipk_cg_direction_kernel<T>, gm.g, HIPK_THREADS, 0, stream, n, gm.ch, gm.g, scal, it, maxiter,
                                   part_a, part_b, r, p, x, 0);
         }
         if ((it & 63) == 63) HIPK_CHECK_HIP(hipGetLastError());
@@ -1266,11 +1268,14 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
         ca.maxiter = maxiter;
         ca.max_its = e ? atoll(e) : 16384;
         if (ca.max_its < 1) ca.max_its = 1;
-        ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
+        // tests: HIPK_TEST_LDS_NOT_RESIDENT=k makes the k-th launch of this solve report its workgroups as not co-resident
+        const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+        int launch_no = 0;
         const int lgrid = lds_spread ? kGmSub * gm.g : 8 * kGmSub * gm.g;
         hipk_pcg_scal hs0;
         for (;;) {
             ca.it0 = it;
+            ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
             HIPK_CHECK_HIP(hipMemsetAsync(ca.flag_a, 0, 2 * kHoMaxWg * sizeof(unsigned long long), stream));
             HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
             if (local)
@@ -1289,7 +1294,14 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
                     local = false;
                     continue;
                 }
-                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // nothing was modified: the launch sequence below takes over
+                if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) lds_loop_failed = true;   // this launch modified nothing: the launch sequence below takes over
+                if (it > 0) {
+                    // ... from iteration `it` of an EARLIER launch: x, r, p are in memory, but <r,z> only as scal->gamma[it & 1]
+                    // (part_z[1] was the kernel's sub-partial scratch), while the launch sequence folds it from the chunk
+                    // partials part_z[it & 1].  Rebuild that slot as {gamma, 0, 0, ...}: the fold of it is gamma, bit for bit
+                    HIPK_CHECK_HIP(hipMemsetAsync(part_z[it & 1], 0, (size_t)gm.g * sizeof(double), stream));
+                    HIPK_CHECK_HIP(hipMemcpyAsync(part_z[it & 1], &scal->gamma[it & 1], sizeof(double), hipMemcpyDeviceToDevice, stream));
+                }
                 lds_loop = false;
                 break;
             }

@@ -1979,7 +1979,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
 
     hipk_event_pair whole;
     HIPK_CHECK_HIP(whole.create());
-    hipk_spmv_profiler prof(prm->profile != 0);
+    hipk_spmv_profiler prof(prm->profile != 0 ? HIPK_K_SPMV : 0);
     HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
 
     hipk_spmv_args sa;
@@ -2088,6 +2088,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     bool predict[HIPK_GM_LDH];
     for (int j = 0; j < HIPK_GM_LDH; ++j) predict[j] = (j == 0) && env_int("HIPK_GM_SPEC", 1) != 2;  // 2: learn everything (tests)
     int happy = 0;
+    int lds_launch_no = 0;
     int64_t prof_valid = 0;
     rc = HIPK_OK;
     const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
@@ -2119,7 +2120,11 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             ca.atol_eff = atol_eff;
             ca.cycles_left = maxiter - cycles;
             ca.max_cycles = env_int("HIPK_GM_LAUNCH_CYCLES", 64);
-            ca.test_not_resident = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? 1 : 0;
+            {   // tests: HIPK_TEST_LDS_NOT_RESIDENT=k makes the k-th one-launch kernel of this solve report "not co-resident"
+                const char *fe = getenv("HIPK_TEST_LDS_NOT_RESIDENT");
+                const int fail_launch = fe ? (atoi(fe) > 1 ? atoi(fe) : 1) : 0;
+                ca.test_not_resident = (++lds_launch_no == fail_launch) ? 1 : 0;
+            }
             ca.bar = &scal->bar;
             ca.eps = eps_t;
             ca.stamps = getenv("HIPK_GM_STAMPS") ? (unsigned long long *)(part_spare + 1600) : nullptr;

@@ -23,19 +23,28 @@ struct hipk_event_pair {
     }
 };
 
-// Kernel durations for bench.py (params.profile): the selected launches go through hipExtLaunchKernel with a start and a stop
-// event BOUND TO THAT DISPATCH, so hipEventElapsedTime returns the dispatch's own begin/end timestamps -- the figures
-// `rocprofv3 --kernel-trace` prints for the same launch -- in the kernel's real cache context inside the solver loop.  Nothing is
-// calibrated or subtracted (until version 200 the launches were bracketed with hipEventRecord pairs and an estimated
-// pair overhead of 3.4-3.8 us was subtracted: 0.876 printed where the profiler said 0.846).
+// Kernel durations for bench.py (params.profile = the KIND of kernel to report: 1 SpMV, 2 CG update, 3 CG direction, 4 the
+// scalars launch of the flat direction step).  Timed launches go through hipExtLaunchKernel with a start and a stop event bound
+// to that dispatch; nothing is calibrated or subtracted (until version 200 hipEventRecord pairs bracketed the launches and an
+// estimated pair overhead of 3.4-3.8 us was subtracted: 0.876 printed where the profiler said 0.846).  Two figures per kind:
+//  * SPAN  = stop - start of the launch's own events;
+//  * CHAIN (CG loop: EVERY launch of the profiled iterations is timed) = stop of the launch - stop of the launch before it on the
+//    stream: the time the kernel occupies the stream, dispatch hand-over included.  The chain figures of an iteration's kernels add
+//    up to the iteration time by construction, and they are what agrees with `rocprofv3 --kernel-trace` averages (whose sum over
+//    the iteration's kernels also equals the measured iteration time); the span starts 0.6-1.5 us earlier (5 us under the tracer).
 struct hipk_spmv_profiler {
-    static constexpr int kMax = 256;
+    static constexpr int kMax = 256;        // launches of the selected kind
+    static constexpr int kSlots = 5 * kMax; // all timed launches (chain mode: a CG iteration has 3-4)
     bool on;
+    bool chain = false;
+    int select;
     std::vector<hipEvent_t> ev;
-    int used = 0;
-    explicit hipk_spmv_profiler(bool enable) : on(enable) {
+    std::vector<unsigned char> kind;
+    int used = 0, used_sel = 0;
+    explicit hipk_spmv_profiler(int profile, bool chain_mode = false) : on(profile != 0), chain(chain_mode), select(profile) {
         if (!on) return;
-        ev.resize(2 * kMax, nullptr);
+        ev.resize(2 * (chain ? kSlots : kMax), nullptr);
+        kind.resize(chain ? kSlots : kMax, 0);
         for (auto &e : ev)
             if (hipEventCreate(&e) != hipSuccess) {
                 on = false;
@@ -46,51 +55,65 @@ struct hipk_spmv_profiler {
         for (auto e : ev)
             if (e) (void)hipEventDestroy(e);
     }
-    // the event pair of the next timed launch, or nulls (profiling off / all slots used)
-    bool slot(hipEvent_t *e0, hipEvent_t *e1) {
-        if (!on || used >= kMax) return false;
+    // the event pair of the next launch if it is to be timed (kind 0: a helper launch, timed only as a link of the chain)
+    bool slot(int k, hipEvent_t *e0, hipEvent_t *e1) {
+        if (!on || used_sel >= kMax || (size_t)used >= kind.size()) return false;
+        if (!chain && k != select) return false;
         *e0 = ev[2 * used];
         *e1 = ev[2 * used + 1];
+        kind[used] = (unsigned char)k;
         ++used;
+        if (k == select) ++used_sel;
         return true;
     }
-    // valid: number of leading timed launches that did real work
+    // valid: number of leading launches of the selected kind that did real work
     hipError_t collect(hipk_stats *st, int64_t valid = INT64_MAX) {
         st->spmv_ms_avg = 0.0;
         st->spmv_profiled = 0;
-        st->event_overhead_ms = 0.0;
+        st->dispatch_span_ms_avg = 0.0;
         if (!on) return hipSuccess;
-        const int cnt = (int)((valid < used) ? valid : used);
-        double sum = 0.0;
-        for (int k = 0; k < cnt; ++k) {
+        double span = 0.0, occ = 0.0;
+        int cnt = 0, nocc = 0;
+        for (int i = 0; i < used && cnt < valid; ++i) {
+            if (kind[i] != select) continue;
             float ms = 0.f;
-            hipError_t e = hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
+            hipError_t e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
             if (e != hipSuccess) return e;
-            sum += ms;
+            span += ms;
+            ++cnt;
+            if (chain && i > 0) {
+                e = hipEventElapsedTime(&ms, ev[2 * (i - 1) + 1], ev[2 * i + 1]);
+                if (e != hipSuccess) return e;
+                occ += ms;
+                ++nocc;
+            }
         }
-        if (cnt > 0) st->spmv_ms_avg = sum / cnt;
+        if (cnt > 0) st->dispatch_span_ms_avg = span / cnt;
+        st->spmv_ms_avg = (chain && nocc > 0) ? occ / nocc : st->dispatch_span_ms_avg;
         st->spmv_profiled = cnt;
         return hipSuccess;
     }
 };
 
+enum { HIPK_K_AUX = 0, HIPK_K_SPMV = 1, HIPK_K_UPDATE = 2, HIPK_K_DIRECTION = 3, HIPK_K_SCALARS = 4 };
+
 #ifdef __HIPCC__
-// kern<<<grid, block, shm, s>>>(args...), timed by `prof` when it has a slot left (prof may be null)
+// kern<<<grid, block, shm, s>>>(args...), timed by `prof` (may be null) when it wants launches of this kind
 template <typename... KA, size_t... I>
-static inline void hipk_launch_timed_impl(hipk_spmv_profiler *prof, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
+static inline void hipk_launch_timed_impl(hipk_spmv_profiler *prof, int kind, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
                                           hipStream_t s, std::tuple<KA...> &t, std::index_sequence<I...>) {
     void *argv[sizeof...(KA) > 0 ? sizeof...(KA) : 1] = {(void *)&std::get<I>(t)...};
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof && prof->slot(&e0, &e1))
+    if (prof && prof->slot(kind, &e0, &e1))
         (void)hipExtLaunchKernel((const void *)kern, grid, block, argv, shm, s, e0, e1, 0);
     else
         (void)hipLaunchKernel((const void *)kern, grid, block, argv, shm, s);
 }
 template <typename... KA, typename... A>
-static inline void hipk_launch_timed(hipk_spmv_profiler *prof, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
+static inline void hipk_launch_timed(hipk_spmv_profiler *prof, int kind, void (*kern)(KA...), dim3 grid, dim3 block, size_t shm,
                                      hipStream_t s, A... args) {
     std::tuple<KA...> t(static_cast<KA>(args)...);
-    hipk_launch_timed_impl(prof, kern, grid, block, shm, s, t, std::index_sequence_for<KA...>{});
+    hipk_launch_timed_impl(prof, kind, kern, grid, block, shm, s, t, std::index_sequence_for<KA...>{});
 }
 #endif
 

@@ -76,7 +76,7 @@ class Stats(ctypes.Structure):
         ("solve_ms", ctypes.c_double),
         ("spmv_ms_avg", ctypes.c_double),
         ("spmv_profiled", ctypes.c_int64),
-        ("event_overhead_ms", ctypes.c_double),
+        ("dispatch_span_ms_avg", ctypes.c_double),
     ]
 
 
@@ -96,7 +96,7 @@ class SolveStats:
     solve_ms: float
     spmv_ms_avg: float
     spmv_profiled: int
-    event_overhead_ms: float = 0.0
+    dispatch_span_ms_avg: float = 0.0
 
 
 class HipkError(RuntimeError):
@@ -553,7 +553,7 @@ def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Par
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
-                      event_overhead_ms=st.event_overhead_ms)
+                      dispatch_span_ms_avg=st.dispatch_span_ms_avg)
 
 
 def solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
@@ -607,7 +607,7 @@ def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
-                      event_overhead_ms=st.event_overhead_ms)
+                      dispatch_span_ms_avg=st.dispatch_span_ms_avg)
 
 
 def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
@@ -635,7 +635,7 @@ def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Ten
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
-                      event_overhead_ms=st.event_overhead_ms)
+                      dispatch_span_ms_avg=st.dispatch_span_ms_avg)
 
 
 def solve_cg_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
@@ -834,4 +834,4 @@ def _solve_with_callback(kind: str, h: CsrHandle, M, b: torch.Tensor, x: torch.T
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
-                      event_overhead_ms=st.event_overhead_ms)
+                      dispatch_span_ms_avg=st.dispatch_span_ms_avg)

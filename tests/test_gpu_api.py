@@ -660,6 +660,48 @@ def test_one_launch_kernels_fall_back_when_their_workgroups_are_not_resident(mon
 
 
 @pytest.mark.gpu
+def test_one_launch_kernels_fall_back_in_the_middle_of_a_solve(monkeypatch):
+    """a LATER launch of a one-launch loop may find its workgroups not co-resident (the first ran, e.g. the
+    16384-iteration bound was reached or HIPK_*_LAUNCH_ITS is set).  The launch sequences then take over from iteration it > 0,
+    where the one-launch kernels keep their reduction state in another layout (Jacobi-PCG: <r,z> only as a scalar; BiCGStab: 8 g
+    sub-partials).  Launches bounded to 7 iterations / 2 cycles, the SECOND launch fails: same bits as an undisturbed solve."""
+    import torch
+    from pytorch_sparse_solver.module_a import JacobiPreconditioner, bicgstab, cg, get_last_stats, gmres
+    from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr
+    dev = "cuda:0"
+    P, C = create_poisson_2d_csr(60, 50, device=dev), create_convdiff_2d_csr(60, 50, device=dev)
+    # a variable diagonal so that the Jacobi preconditioner is not a multiple of the identity
+    Pv = torch.sparse_csr_tensor(P.crow_indices(), P.col_indices(),
+                                 P.values() * (1.0 + 0.25 * torch.sin(torch.arange(P.values().numel(), device=dev, dtype=torch.float64))),
+                                 size=P.shape)
+    Pd = (Pv.to_dense() + Pv.to_dense().T) / 2 + 2.0 * torch.eye(P.shape[0], device=dev, dtype=torch.float64)
+    Ps = Pd.to_sparse_csr()
+    cases = ((cg, P, dict(tol=1e-9)), (cg, Ps, dict(tol=1e-9, M=JacobiPreconditioner(Ps))),
+             (bicgstab, C, dict(tol=1e-9)), (bicgstab, C, dict(tol=1e-9, M=JacobiPreconditioner(C))),
+             (gmres, C, dict(tol=1e-9, restart=20, maxiter=30)),
+             (gmres, C, dict(tol=1e-9, restart=20, maxiter=30, solve_method="incremental")))
+    envs = {"HIPK_CG_LAUNCH_ITS": "7", "HIPK_BICGSTAB_LAUNCH_ITS": "7", "HIPK_GM_LAUNCH_CYCLES": "2",
+            "HIPK_TEST_LDS_NOT_RESIDENT": "2"}
+    for fn, A, kw in cases:
+        n = A.shape[0]
+        b = torch.randn(n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+        out = []
+        for disturbed in (False, True):
+            for k, v in envs.items():
+                if disturbed:
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x, info = fn(A, b, **kw)
+            st = get_last_stats()
+            out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
+        assert out[0][1] == 0 and out[0][2] > (2 if fn is gmres else 7) and torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], \
+            (fn.__name__, list(kw), out[0][1:], out[1][1:])
+    for k in envs:
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.gpu
 def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypatch):
     """Large systems (more than 8 reduction chunks): the streaming-policy kernels (non-temporal loads of the basis columns
     beyond the resident ones) and the speculative second CGS pass (launched only where predicted; a miss is caught on the
