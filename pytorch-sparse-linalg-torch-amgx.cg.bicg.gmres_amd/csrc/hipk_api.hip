@@ -24,7 +24,11 @@ extern "C" const char *hipk_last_error(void) { return g_err; }
 static thread_local char g_spmv_kernel[96] = "";
 extern "C" const char *hipk_last_spmv_kernel(void) { return g_spmv_kernel; }
 #define HIPK_NOTE_KERNEL(...) snprintf(g_spmv_kernel, sizeof(g_spmv_kernel), __VA_ARGS__)
+#if __has_include("hipk_build_id.h")   // written by the Makefile (sha1 over the sources); absent in ad-hoc compiles of this file
 #include "hipk_build_id.h"
+#else
+#define HIPK_BUILD_ID "unstamped-build!"
+#endif
 extern "C" int hipk_version(void) { return HIPK_VERSION; }
 extern "C" const char *hipk_build_id(void) { return HIPK_BUILD_ID; }
 

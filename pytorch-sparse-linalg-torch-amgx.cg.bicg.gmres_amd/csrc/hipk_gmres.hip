@@ -25,8 +25,27 @@
 #include "hipk_spmv.h"
 #include "hipk_handoff.h"
 
-#define HIPK_GM_MAXM 31
+#define HIPK_GM_MAXM 31        // restart bound of the small-system (LDS / one-launch) kernels and of the arrays INSIDE hipk_gm_scal
 #define HIPK_GM_LDH 32
+#define HIPK_GM_MAXM_BIG 255   // restart bound of the launch sequences: beyond 31 the Hessenberg arrays live in the workspace
+
+// Where the m-dependent small arrays of a cycle live: inside hipk_gm_scal (restart <= 31, leading dimension 32) or in a block of
+// the workspace sized for the solve's restart (hipk_gm_big_doubles).  Filled by hipk_gm_cycle_init_kernel; the kernels of the
+// launch sequences address H, R, ... through it, the small-system kernels (restart <= 31 only) use the struct's arrays directly.
+struct hipk_gm_view {
+    double *H;         // (m+2) x ldh, row-major
+    double *R;         // ldh x ldh
+    double *gv;        // 2 ldh
+    double *beta_vec;  // ldh + 1
+    double *hvec, *rvec;  // ldh each
+    int ldh, m;
+};
+static inline int hipk_gm_big_ld(int m) { return ((m + 1 + 7) / 8) * 8; }
+static inline size_t hipk_gm_big_doubles(int m) {   // 0 for restart <= 31
+    if (m <= HIPK_GM_MAXM) return 0;
+    const size_t ld = (size_t)hipk_gm_big_ld(m);
+    return (((size_t)(m + 2) * ld + ld * ld + 2 * ld + (ld + 1) + 2 * ld) + 31) / 32 * 32;
+}
 #define HIPK_EPS64 2.220446049250313e-16
 #define HIPK_EPS32 1.1920928955078125e-07
 #define HIPK_INV_SQRT2 0.7071067811865476
@@ -65,14 +84,17 @@ struct hipk_gm_scal {
                             // of the current cycle's normal equations failed -- H, steps_done and the basis are in memory, the
                             // host finishes this cycle (general solve, TSL:424-428)
     int rep_breakdown;      // a breakdown (TSL:387) happened in one of the launch's cycles
+    hipk_gm_view v;         // see above (set by hipk_gm_cycle_init_kernel)
 };
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
 static constexpr int kGmSlots = 8;  // ww, qq, res, bb, xx, spare x3
 
-struct hipk_gm_y {
-    double y[HIPK_GM_LDH];
+template <int KC>
+struct hipk_gm_yN {
+    double y[KC];
 };
+typedef hipk_gm_yN<HIPK_GM_LDH> hipk_gm_y;
 
 // ---- reduce 8 per-thread values at once with the spec tree (sbuf: 8*256 doubles)
 __device__ __forceinline__ void hipk_block_sum8(double (&v)[8], int nb, double *sbuf) {
@@ -110,11 +132,13 @@ __device__ __forceinline__ double hipk_fold8(const double *__restrict__ part, in
 }
 
 // second CGS pass iff ||r|| < ||q|| / sqrt(2)  (TSL:313-326); shared by hipk_gm_decide_kernel and the SMALL multi-dot
-__device__ __forceinline__ int hipk_gm_want_pass2(const hipk_gm_scal *scal, int k, double qq, double eps, double *qnorm_out) {
+__device__ __forceinline__ int hipk_gm_want_pass2(const hipk_gm_scal *scal, int k, double qq, double eps, double *qnorm_out,
+                                                  const double *rvec = nullptr) {
+    if (rvec == nullptr) rvec = scal->rvec;   // small-system kernels: the struct's own array
     double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
     if (!(qnorm > eps)) qnorm = 0.0;
     double rr = 0.0;
-    for (int j = 0; j <= k; ++j) rr = fma(scal->rvec[j], scal->rvec[j], rr);
+    for (int j = 0; j <= k; ++j) rr = fma(rvec[j], rvec[j], rr);
     double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
     if (!(rnorm > eps)) rnorm = 0.0;
     *qnorm_out = qnorm;
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_hreduce_kernel(hipk_gm_s
     __shared__ double sbuf[HIPK_THREADS];
     const int j = blockIdx.x;
     const double h = hipk_reduce_parts(part + (size_t)j * HIPK_MAX_PARTS, g, sbuf);
-    if (threadIdx.x == 0) scal->hvec[j] = h;
+    if (threadIdx.x == 0) scal->v.hvec[j] = h;
 }
 
 // q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305)
@@ -346,7 +370,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
     if (threadIdx.x < HIPK_GM_LDH) {
         double hj = 0.0;
         if (threadIdx.x <= k)
-            hj = SMALL ? hipk_fold8(part_md + (size_t)threadIdx.x * HIPK_MAX_PARTS, g) : scal->hvec[threadIdx.x];
+            hj = SMALL ? hipk_fold8(part_md + (size_t)threadIdx.x * HIPK_MAX_PARTS, g) : scal->v.hvec[threadIdx.x];
         hs[threadIdx.x] = hj;
     }
     __syncthreads();
@@ -386,7 +410,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_update_kernel(
     if (threadIdx.x == 0) {
         part_qq[c] = acc;
         if (c == 0) {
-            for (int j = 0; j <= k; ++j) scal->rvec[j] = ((pass == 0) ? 0.0 : scal->rvec[j]) + hs[j];
+            double *rvec = SMALL ? scal->rvec : scal->v.rvec;
+            for (int j = 0; j <= k; ++j) rvec[j] = ((pass == 0) ? 0.0 : rvec[j]) + hs[j];
         }
     }
 }
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_decide_kernel(hipk_gm_sc
     const double qq = hipk_reduce_parts(part_qq, g, sbuf);
     if (threadIdx.x == 0) {
         double qnorm;
-        scal->pass2 = hipk_gm_want_pass2(scal, k, qq, eps, &qnorm);
+        scal->pass2 = hipk_gm_want_pass2(scal, k, qq, eps, &qnorm, scal->v.rvec);
         scal->qnorm = qnorm;
     }
 }
@@ -439,18 +464,23 @@ __device__ __forceinline__ void hipk_block_sumN(double (&v)[NC], double *sbuf) {
     __syncthreads();
 }
 
-// part[j*MAXP + c] = chunk partial of <V_j, w>.  grid = g * (k/8 + 1): workgroup b takes chunk b % g of column group b / g.
-// NC = live columns of the workgroup's group, a compile-time bound (1, 2, 4, 8): the early Arnoldi steps (64-320 MB) are
-// latency-bound -- with NC <= 2 the chunk's four steps are all in flight at once and the tree only carries live columns.
+// part[j*MAXP + c] = chunk partial of <V_j, w>.  grid = g * (k / GW + 1), GW = max(8, NC): workgroup b takes chunk b % g of
+// column group b / g.  NC = compile-time bound on the live columns of a group: 1, 2, 4, 8 for the latency-bound first steps (with
+// NC <= 2 the chunk's four steps are all in flight at once and the tree only carries live columns), 16 and 32 beyond -- ONE group
+// up to k = 31, so w is read once per step (round 2 took groups of 8 throughout: w re-read per group, PMC 1.15 x the algorithmic
+// bytes over a GMRES(30) cycle).  The column loads still go out in batches of eight (8 x 16 B per lane in flight) and the block
+// tree runs per batch of eight accumulators (16 KB of LDS whatever NC).  Per column the accumulation order is the spec's.
 template <typename T, int NC>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_stream_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
     const T *__restrict__ w, double *__restrict__ part, int g, int nres) {
     if (k >= scal->stop_step) return;
     if (pass == 1 && !scal->pass2) return;
+    constexpr int GW = NC < 8 ? 8 : NC;   // columns per group
+    constexpr int NB = NC < 8 ? NC : 8;   // columns per load batch / tree batch
     const int grp = blockIdx.x / g, c = blockIdx.x % g;
-    __shared__ double sbuf[NC * HIPK_THREADS];
-    const int j0 = 8 * grp;
+    __shared__ double sbuf[NB * HIPK_THREADS];
+    const int j0 = GW * grp;
     double acc[NC];
 #pragma unroll
     for (int b = 0; b < NC; ++b) acc[b] = 0.0;
@@ -458,32 +488,45 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_stream_kernel(
         constexpr int VEC = hipk_vec<T>::VEC;
         T wv[VEC];
         hipk_ld<T>(w, i, nv, wv);
-        T vv[NC][VEC];
 #pragma unroll
-        for (int b = 0; b < NC; ++b)
-            if (j0 + b <= k) {
-                if (j0 + b < nres) hipk_ld<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
-                else hipk_ld_nt_vec<T>(V + (int64_t)(j0 + b) * ldv, i, nv, vv[b]);
+        for (int b0 = 0; b0 < NC; b0 += NB) {
+            if (j0 + b0 <= k) {   // uniform
+                T vv[NB][VEC];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (j0 + b0 + b <= k) {
+                        if (j0 + b0 + b < nres) hipk_ld<T>(V + (int64_t)(j0 + b0 + b) * ldv, i, nv, vv[b]);
+                        else hipk_ld_nt_vec<T>(V + (int64_t)(j0 + b0 + b) * ldv, i, nv, vv[b]);
+                    }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (j0 + b0 + b <= k) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (e < nv) acc[b0 + b] = fma((double)vv[b][e], (double)wv[e], acc[b0 + b]);
+                    }
             }
-#pragma unroll
-        for (int b = 0; b < NC; ++b)
-            if (j0 + b <= k) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    if (e < nv) acc[b] = fma((double)vv[b][e], (double)wv[e], acc[b]);
-            }
+        }
     });
-    hipk_block_sumN<NC>(acc, sbuf);
-    if (threadIdx.x == 0) {
 #pragma unroll
-        for (int b = 0; b < NC; ++b)
-            if (j0 + b <= k) part[(size_t)(j0 + b) * HIPK_MAX_PARTS + c] = acc[b];
+    for (int b0 = 0; b0 < NC; b0 += NB) {
+        if (j0 + b0 <= k) {   // uniform
+            double a8[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) a8[b] = acc[b0 + b];
+            hipk_block_sumN<NB>(a8, sbuf);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (j0 + b0 + b <= k) part[(size_t)(j0 + b0 + b) * HIPK_MAX_PARTS + c] = a8[b];
+            }
+        }
     }
 }
 
 // q = w - V h in place, partials of <q,q>; rvec += h   (TSL:302-305).  grid = g.
 // KC = compile-time bound on the live columns (8: the first eight Arnoldi steps, one round of column loads and few enough
-// registers for 8 workgroups per CU -- those steps are latency-bound; 32: the general form).
+// registers for 8 workgroups per CU -- those steps are latency-bound; 32: the general form; 256: restart > 31, batches in a run-time loop).
 template <typename T, int KC>
 __global__ __launch_bounds__(HIPK_THREADS, (KC <= 8 ? 8 : 1)) void hipk_gm_update_stream_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
@@ -492,8 +535,9 @@ __global__ __launch_bounds__(HIPK_THREADS, (KC <= 8 ? 8 : 1)) void hipk_gm_updat
     if (pass == 1 && !scal->pass2) return;
     const int c = blockIdx.x;
     __shared__ double sbuf[HIPK_THREADS];
-    __shared__ double hs[HIPK_GM_LDH];
-    if (threadIdx.x < HIPK_GM_LDH) hs[threadIdx.x] = (threadIdx.x <= k) ? scal->hvec[threadIdx.x] : 0.0;
+    constexpr int HS = KC < HIPK_GM_LDH ? HIPK_GM_LDH : KC;
+    __shared__ double hs[HS];
+    if (threadIdx.x < HS) hs[threadIdx.x] = (threadIdx.x <= k) ? scal->v.hvec[threadIdx.x] : 0.0;
     __syncthreads();
     double acc = 0.0;
     hipk_chunk_loop<T, 1>(n, ch, c, [&](int64_t i, int nv) {
@@ -503,7 +547,8 @@ __global__ __launch_bounds__(HIPK_THREADS, (KC <= 8 ? 8 : 1)) void hipk_gm_updat
         double s[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s[e] = 0.0;
-#pragma unroll
+        constexpr int kUnroll = KC <= HIPK_GM_LDH ? KC / 8 : 1;
+#pragma unroll kUnroll   // restart > 31: a run-time loop over the batches (60 VGPRs instead of 190-256)
         for (int j0 = 0; j0 < KC; j0 += 8) {  // batches of eight column loads, then their FMAs in column order
             if (j0 <= k) {
                 T vv[8][VEC];
@@ -533,7 +578,8 @@ __global__ __launch_bounds__(HIPK_THREADS, (KC <= 8 ? 8 : 1)) void hipk_gm_updat
     if (threadIdx.x == 0) {
         part_qq[c] = acc;
         if (c == 0) {
-            for (int j = 0; j <= k; ++j) scal->rvec[j] = ((pass == 0) ? 0.0 : scal->rvec[j]) + hs[j];
+            double *rvec = scal->v.rvec;
+            for (int j = 0; j <= k; ++j) rvec[j] = ((pass == 0) ? 0.0 : rvec[j]) + hs[j];
         }
     }
 }
@@ -580,7 +626,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
         // pass was wanted after all, nothing is stored: the step is stopped and reported, the host re-enqueues the cycle
         // from this step with the second pass in place.
         double qnorm;
-        if (hipk_gm_want_pass2(scal, k, qq, eps, &qnorm)) {
+        if (hipk_gm_want_pass2(scal, k, qq, eps, &qnorm, scal->v.rvec)) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 scal->redo = 1;
                 scal->redo_step = k;
@@ -607,18 +653,21 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
     // (the launch then waits for workgroup 0 alone).
     if (blockIdx.x == 0) {
         if (!use) norm1 = 0.0;
-        double *H = scal->H;
+        const hipk_gm_view v = scal->v;
+        double *H = v.H;
+        const int ldh = v.ldh;
         const int t = threadIdx.x;
-        __shared__ double hc[HIPK_GM_LDH + 1], gvs[2 * HIPK_GM_LDH];
+        __shared__ double hc[HIPK_GM_MAXM_BIG + 2], gvs[2 * (HIPK_GM_MAXM_BIG + 1)];
         if (t <= k) {
-            const double rj = scal->rvec[t];
-            H[t * HIPK_GM_LDH + k] = rj;
+            const double rj = v.rvec[t];
+            H[t * ldh + k] = rj;
             hc[t] = rj;
         }
-        if (t < 2 * k && scal->incremental) gvs[t] = scal->gv[t];
+        if (scal->incremental)
+            for (int i = t; i < 2 * k; i += HIPK_THREADS) gvs[i] = v.gv[i];
         __syncthreads();
         if (t == 0) {
-            H[(k + 1) * HIPK_GM_LDH + k] = norm1;
+            H[(k + 1) * ldh + k] = norm1;
             hc[k + 1] = norm1;
             scal->steps_done = k + 1;
             bool stop = false;
@@ -637,15 +686,15 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
                 }
                 double cs, sn;
                 hipk_givens(hc[k], hc[k + 1], cs, sn);
-                scal->gv[2 * k] = cs;
-                scal->gv[2 * k + 1] = sn;
+                v.gv[2 * k] = cs;
+                v.gv[2 * k + 1] = sn;
                 {
                     const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
                     hc[k] = p0 - p1;
                 }
                 hc[k + 1] = 0.0;
-                for (int j = 0; j <= k; ++j) scal->R[j * HIPK_GM_LDH + k] = hc[j];
-                double *bv = scal->beta_vec;
+                for (int j = 0; j <= k; ++j) v.R[j * ldh + k] = hc[j];
+                double *bv = v.beta_vec;
                 const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
                 const double t0 = p0 - p1;
                 const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
@@ -1755,14 +1804,38 @@ __global__ void hipk_gm_resume_kernel(hipk_gm_scal *__restrict__ scal) {
     scal->pass2 = 0;
 }
 
-__global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int incremental, double ptol) {
+// big: the workspace block of a solve with restart m > 31 (hipk_gm_big_doubles(m) doubles), else null: the struct's own arrays
+__global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int incremental, double ptol, double *big = nullptr,
+                                          int m = HIPK_GM_MAXM) {
     const int t = threadIdx.x;
-    for (int i = t; i < (HIPK_GM_MAXM + 2) * HIPK_GM_LDH; i += blockDim.x) scal->H[i] = 0.0;
-    for (int i = t; i < HIPK_GM_LDH * HIPK_GM_LDH; i += blockDim.x)
-        scal->R[i] = ((i / HIPK_GM_LDH) == (i % HIPK_GM_LDH)) ? 1.0 : 0.0;  // TSL:581
-    for (int i = t; i < HIPK_GM_LDH * 2; i += blockDim.x) scal->gv[i] = 0.0;
-    for (int i = t; i <= HIPK_GM_LDH; i += blockDim.x) scal->beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
+    hipk_gm_view v;
+    if (big != nullptr) {
+        const int ld = ((m + 1 + 7) / 8) * 8;
+        v.ldh = ld;
+        v.m = m;
+        v.H = big;
+        v.R = v.H + (size_t)(m + 2) * ld;
+        v.gv = v.R + (size_t)ld * ld;
+        v.beta_vec = v.gv + 2 * ld;
+        v.hvec = v.beta_vec + (ld + 1);
+        v.rvec = v.hvec + ld;
+    } else {
+        v.ldh = HIPK_GM_LDH;
+        v.m = HIPK_GM_MAXM;
+        v.H = scal->H;
+        v.R = scal->R;
+        v.gv = scal->gv;
+        v.beta_vec = scal->beta_vec;
+        v.hvec = scal->hvec;
+        v.rvec = scal->rvec;
+    }
+    const int ld = v.ldh;
+    for (int i = t; i < (v.m + 2) * ld; i += blockDim.x) v.H[i] = 0.0;
+    for (int i = t; i < ld * ld; i += blockDim.x) v.R[i] = ((i / ld) == (i % ld)) ? 1.0 : 0.0;  // TSL:581
+    for (int i = t; i < ld * 2; i += blockDim.x) v.gv[i] = 0.0;
+    for (int i = t; i <= ld; i += blockDim.x) v.beta_vec[i] = (i == 0) ? scal->res_norm : 0.0;
     if (t == 0) {
+        scal->v = v;
         scal->bar = 0;
         scal->xcc_mask = 0;
         scal->redo = 0;
@@ -1778,10 +1851,10 @@ __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int i
 }
 
 // x += V[:, :k] y   (TSL:488-490)
-template <typename T>
+template <typename T, int KC = HIPK_GM_LDH>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_xupdate_kernel(int64_t n, int ch, int k,
                                                                        const T *__restrict__ V, int64_t ldv,
-                                                                       T *__restrict__ x, hipk_gm_y yy) {
+                                                                       T *__restrict__ x, hipk_gm_yN<KC> yy) {
     hipk_chunk_loop<T>(n, ch, blockIdx.x, [&](int64_t i, int nv) {
         constexpr int VEC = hipk_vec<T>::VEC;
         T xv[VEC];
@@ -1789,11 +1862,30 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_xupdate_kernel(int64_t n
         double s[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s[e] = 0.0;
+        if constexpr (KC <= HIPK_GM_LDH) {
 #pragma unroll
-        for (int j = 0; j < HIPK_GM_LDH; ++j) {
-            if (j < k) {
+            for (int j = 0; j < KC; ++j) {
+                if (j < k) {
+                    T vv[VEC];
+                    hipk_ld_nt_vec<T>(V + (int64_t)j * ldv, i, nv, vv);   // every column is read once: stream it
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], yy.y[j], s[e]);
+                }
+            }
+        } else {   // restart > 31: the same chain, four column loads in flight
+            int j = 0;
+            for (; j + 4 <= k; j += 4) {
+                T vv[4][VEC];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) hipk_ld_nt_vec<T>(V + (int64_t)(j + b) * ldv, i, nv, vv[b]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[b][e], yy.y[j + b], s[e]);
+            }
+            for (; j < k; ++j) {
                 T vv[VEC];
-                hipk_ld_nt_vec<T>(V + (int64_t)j * ldv, i, nv, vv);   // every column is read once: stream it
+                hipk_ld_nt_vec<T>(V + (int64_t)j * ldv, i, nv, vv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) s[e] = fma((double)vv[e], yy.y[j], s[e]);
             }
@@ -1847,70 +1939,70 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_final_kernel(hipk_gm_sca
 // `_lstsq` (TSL:391-428): normal equations + Cholesky, general solve when Cholesky fails.
 // Same operation order as oracle/krylov_oracle.c::lstsq_normal.
 static void hipk_lstsq_normal(const double *H, int ldh, int k, double beta0, double *y) {
-    double a2[32 * 32], b2[32], L[32 * 32];
+    // leading dimension LD of the scratch arrays: 32 up to restart 31 (as ever), k beyond; the arithmetic does not depend on it
+    const int LD = k <= 32 ? 32 : k;
+    std::vector<double> a2v((size_t)LD * LD), b2v(LD), Lv((size_t)LD * LD, 0.0), zv(LD), Mv((size_t)LD * (LD + 1));
+    double *a2 = a2v.data(), *b2 = b2v.data(), *L = Lv.data(), *z = zv.data(), *M = Mv.data();
     for (int i = 0; i < k; ++i) {
         for (int j = 0; j < k; ++j) {
             double s = 0.0;
             for (int p = 0; p <= k; ++p) s = fma(H[p * ldh + i], H[p * ldh + j], s);
-            a2[i * 32 + j] = s;
+            a2[i * LD + j] = s;
         }
         b2[i] = H[0 * ldh + i] * beta0;
     }
     bool ok = true;
-    memset(L, 0, sizeof(L));
     for (int j = 0; j < k && ok; ++j) {
-        double d = a2[j * 32 + j];
-        for (int p = 0; p < j; ++p) d = fma(-L[j * 32 + p], L[j * 32 + p], d);
+        double d = a2[j * LD + j];
+        for (int p = 0; p < j; ++p) d = fma(-L[j * LD + p], L[j * LD + p], d);
         if (!(d > 0.0)) {
             ok = false;
             break;
         }
         const double ljj = sqrt(d);
-        L[j * 32 + j] = ljj;
+        L[j * LD + j] = ljj;
         for (int i = j + 1; i < k; ++i) {
-            double s = a2[i * 32 + j];
-            for (int p = 0; p < j; ++p) s = fma(-L[i * 32 + p], L[j * 32 + p], s);
-            L[i * 32 + j] = s / ljj;
+            double s = a2[i * LD + j];
+            for (int p = 0; p < j; ++p) s = fma(-L[i * LD + p], L[j * LD + p], s);
+            L[i * LD + j] = s / ljj;
         }
     }
     if (ok) {
-        double z[32];
         for (int i = 0; i < k; ++i) {
             double s = b2[i];
-            for (int p = 0; p < i; ++p) s = fma(-L[i * 32 + p], z[p], s);
-            z[i] = s / L[i * 32 + i];
+            for (int p = 0; p < i; ++p) s = fma(-L[i * LD + p], z[p], s);
+            z[i] = s / L[i * LD + i];
         }
         for (int i = k - 1; i >= 0; --i) {
             double s = z[i];
-            for (int p = i + 1; p < k; ++p) s = fma(-L[p * 32 + i], y[p], s);
-            y[i] = s / L[i * 32 + i];
+            for (int p = i + 1; p < k; ++p) s = fma(-L[p * LD + i], y[p], s);
+            y[i] = s / L[i * LD + i];
         }
         return;
     }
-    double M[32 * 33];
     for (int i = 0; i < k; ++i) {
-        for (int j = 0; j < k; ++j) M[i * 33 + j] = a2[i * 32 + j];
-        M[i * 33 + k] = b2[i];
+        for (int j = 0; j < k; ++j) M[i * (LD + 1) + j] = a2[i * LD + j];
+        M[i * (LD + 1) + k] = b2[i];
     }
     for (int c = 0; c < k; ++c) {
         int piv = c;
         for (int i = c + 1; i < k; ++i)
-            if (fabs(M[i * 33 + c]) > fabs(M[piv * 33 + c])) piv = i;
+            if (fabs(M[i * (LD + 1) + c]) > fabs(M[piv * (LD + 1) + c])) piv = i;
         if (piv != c)
             for (int j = 0; j <= k; ++j) {
-                const double tmp = M[c * 33 + j];
-                M[c * 33 + j] = M[piv * 33 + j];
-                M[piv * 33 + j] = tmp;
+                const double tmp = M[c * (LD + 1) + j];
+                M[c * (LD + 1) + j] = M[piv * (LD + 1) + j];
+                M[piv * (LD + 1) + j] = tmp;
             }
         for (int i = c + 1; i < k; ++i) {
-            const double f = M[i * 33 + c] / M[c * 33 + c];
-            for (int j = c; j <= k; ++j) M[i * 33 + j] = fma(-f, M[c * 33 + j], M[i * 33 + j]);
+            const double f = M[i * (LD + 1) + c] / M[c * (LD + 1) + c];
+            for (int j = c; j <= k; ++j) M[i * (LD + 1) + j] = fma(-f, M[c * (LD + 1) + j], M[i * (LD + 1) + j]);
         }
     }
     for (int i = k - 1; i >= 0; --i) {
-        double s = M[i * 33 + k];
-        for (int p = i + 1; p < k; ++p) s = fma(-M[i * 33 + p], y[p], s);
-        y[i] = s / M[i * 33 + i];
+        double s = M[i * (LD + 1) + k];
+        for (int p = i + 1; p < k; ++p) s = fma(-M[i * (LD + 1) + p], y[p], s);
+        y[i] = s / M[i * (LD + 1) + i];
     }
 }
 
@@ -1922,8 +2014,9 @@ static inline double hipk_tmin(double a, double b) {
 extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
-    const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM ? HIPK_GM_MAXM : restart);
-    return kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) + (size_t)(m + 2) * vec;
+    const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM_BIG ? HIPK_GM_MAXM_BIG : restart);
+    return kGmHeader + hipk_gm_big_doubles(m) * sizeof(double) + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) +
+           (size_t)(m + 2) * vec;
 }
 
 // partials of || d .* v ||^2 (||M b|| of the preconditioned solver, TSL:750)
@@ -1964,12 +2057,15 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     const size_t vec = hipk_align_up((size_t)n * sizeof(T), 256);
     const int64_t ldv = (int64_t)(vec / sizeof(T));
     hipk_gm_scal *scal = (hipk_gm_scal *)work;
-    double *parts = (double *)(work + kGmHeader);
+    // restart > 31: H, R, the Givens pairs, beta, h and r live in a block of the workspace behind the header (hipk_gm_view)
+    const size_t big_n = hipk_gm_big_doubles(m);
+    double *big = big_n ? (double *)(work + kGmHeader) : nullptr;
+    double *parts = (double *)(work + kGmHeader + big_n * sizeof(double));
     double *part_ww = parts, *part_qq = parts + HIPK_MAX_PARTS, *part_res = parts + 2 * HIPK_MAX_PARTS;
     double *part_bb = parts + 3 * HIPK_MAX_PARTS, *part_xx = parts + 4 * HIPK_MAX_PARTS;
     double *part_spare = parts + 5 * HIPK_MAX_PARTS;
     double *part_md = parts + (size_t)kGmSlots * HIPK_MAX_PARTS;
-    char *vbase = work + kGmHeader + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double);
+    char *vbase = (char *)parts + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double);
     T *V = (T *)vbase;
     T *tmp = (T *)(vbase + (size_t)(m + 1) * vec);
     const int incremental = (prm->gmres_method == HIPK_GMRES_INCREMENTAL) ? 1 : 0;
@@ -2053,8 +2149,10 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         hipk_set_error("out of host memory");
         return HIPK_ERR_ARG;
     }
+    std::vector<double> big_host(big_n);
     int64_t cycles = 0;
-    const bool small = gm.g <= 8 && !getenv("HIPK_GMRES_NO_SMALL");  // launch-bound systems: fewer launches per step
+    // launch-bound systems: fewer launches per step (their kernels keep H in the struct's 32-wide arrays: restart <= 31)
+    const bool small = gm.g <= 8 && m <= HIPK_GM_MAXM && !getenv("HIPK_GMRES_NO_SMALL");
     const bool wide = small && gm.ch == HIPK_BASE_CHUNK && !getenv("HIPK_GMRES_NO_WIDE");  // hipk_gm_update_wide_kernel
     // small systems with short rows: the whole restart cycle in ONE launch (hipk_gm_cycle_small_kernel)
     bool cyc = wide && !ext && A->max_row_len <= HIPK_LONG_ROW && !getenv("HIPK_GMRES_NO_CYCLE");
@@ -2064,7 +2162,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     // workgroups once failed to meet (a shared device) does not try again: the wait for that verdict takes seconds
     static bool lds_cycle_failed = false;
     // 9 .. 32 chunks (n <= 65536): the same kernel with its workgroups spread over the chip (agent-scope hand-offs)
-    const bool lds_spread = gm.g > 8 && gm.g <= 32 && gm.ch == HIPK_BASE_CHUNK && !ext && A->max_row_len <= HIPK_LONG_ROW &&
+    const bool lds_spread = gm.g > 8 && gm.g <= 32 && m <= HIPK_GM_MAXM && gm.ch == HIPK_BASE_CHUNK && !ext && A->max_row_len <= HIPK_LONG_ROW &&
                             !getenv("HIPK_GMRES_NO_SMALL") && !getenv("HIPK_GMRES_NO_CYCLE") && !getenv("HIPK_NO_LDS_SPREAD");
     bool cyc_lds = (cyc || lds_spread) && hipk_gm_solve_lds_bytes<T>(m) <= 80 * 1024 &&
                    kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_cycle_failed && !getenv("HIPK_GMRES_NO_LDS_CYCLE");
@@ -2080,20 +2178,21 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     // its hand-offs through the shared L2 of ONE XCD (plain stores; placement verified by the kernel), else agent-scope stores
     bool cyc_local = !lds_spread && !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    const bool stream_k = !small && !getenv("HIPK_GMRES_NO_STREAM");  // large systems: hipk_gm_*_stream_kernel
+    const bool stream_k = !small && (m > HIPK_GM_MAXM || !getenv("HIPK_GMRES_NO_STREAM"));  // large systems: hipk_gm_*_stream_kernel
+    const bool md_wide = env_int("HIPK_GM_MD_WIDE", 1) != 0;   // multi-dot with up to 32 columns per workgroup (w read once), 0: groups of 8
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
     // large systems: second-pass launches only at the steps where a second CGS pass is expected (step 0, then every step
     // that ever asked for one in this solve); a miss is caught on the device and the cycle re-enqueued from that step
     const bool spec = !small && env_int("HIPK_GM_SPEC", 1) != 0;
-    bool predict[HIPK_GM_LDH];
-    for (int j = 0; j < HIPK_GM_LDH; ++j) predict[j] = (j == 0) && env_int("HIPK_GM_SPEC", 1) != 2;  // 2: learn everything (tests)
+    bool predict[HIPK_GM_MAXM_BIG + 1];
+    for (int j = 0; j <= HIPK_GM_MAXM_BIG; ++j) predict[j] = (j == 0) && env_int("HIPK_GM_SPEC", 1) != 2;  // 2: learn everything (tests)
     int happy = 0;
     int lds_launch_no = 0;
     int64_t prof_valid = 0;
     rc = HIPK_OK;
     const int nt = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     while (cycles < maxiter && res_norm > atol_eff) {
-        hipk_gm_cycle_init_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, incremental, ptol);
+        hipk_gm_cycle_init_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, incremental, ptol, big, m);
         int k_start = 0;
       enqueue:
         if (cyc) {
@@ -2173,12 +2272,13 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                 } else {
                     if (pass == 1) hipk_gm_decide_kernel<<<1, HIPK_THREADS, 0, stream>>>(scal, k, gm.g, part_qq, eps_t);
                     if (stream_k) {
-                        const int mg = gm.g * (k / 8 + 1);
-#define HIPK_MD(NC) hipk_gm_multidot_stream_kernel<T, NC><<<mg, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_md, gm.g, gm_nres)
-                        if (k == 0) HIPK_MD(1);
-                        else if (k == 1) HIPK_MD(2);
-                        else if (k < 4) HIPK_MD(4);
-                        else HIPK_MD(8);
+#define HIPK_MD(NC, GW) hipk_gm_multidot_stream_kernel<T, NC><<<gm.g * (k / GW + 1), HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_md, gm.g, gm_nres)
+                        if (k == 0) HIPK_MD(1, 8);
+                        else if (k == 1) HIPK_MD(2, 8);
+                        else if (k < 4) HIPK_MD(4, 8);
+                        else if (k < 8 || !md_wide) HIPK_MD(8, 8);
+                        else if (k < 16) HIPK_MD(16, 16);
+                        else HIPK_MD(32, 32);
 #undef HIPK_MD
                     }
                     else
@@ -2188,10 +2288,12 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                     if (stream_k && k < 8)
                         hipk_gm_update_stream_kernel<T, 8><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
                                                                                                part_qq, gm_nres);
-                    else if (stream_k)
-                        hipk_gm_update_stream_kernel<T, HIPK_GM_LDH><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
-                                                                                                         part_qq, gm_nres);
-                    else
+                    else if (stream_k) {
+#define HIPK_UP(KC) hipk_gm_update_stream_kernel<T, KC><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w, part_qq, gm_nres)
+                        if (k < 32) HIPK_UP(32);
+                        else HIPK_UP(256);
+#undef HIPK_UP
+                    } else
                         hipk_gm_update_kernel<T, false><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, scal, k, pass, V, ldv, w,
                                                                                            part_qq, part_md, gm.g);
                 }
@@ -2202,6 +2304,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            (big_n && hipMemcpyAsync(big_host.data(), big, big_n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
             hipStreamSynchronize(stream) != hipSuccess) {
             hipk_set_error("hipk_gmres_solve: HIP failure inside a restart cycle");
             rc = HIPK_ERR_HIP;
@@ -2239,19 +2342,30 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         matvecs += k;
         if (prof_valid == cycles * m) prof_valid += k;  // leading launches that did work
         if (hs->breakdown) happy = 1;
-        hipk_gm_y yy;
-        memset(&yy, 0, sizeof(yy));
+        hipk_gm_yN<HIPK_GM_MAXM_BIG + 1> yb;
+        memset(&yb, 0, sizeof(yb));
         if (k > 0) {
+            // the cycle's small arrays: the struct's own (ld 32) or the workspace block's host copy (hipk_gm_cycle_init_kernel's layout)
+            const int ldh = big_n ? hipk_gm_big_ld(m) : HIPK_GM_LDH;
+            const double *Hh = big_n ? big_host.data() : hs->H;
+            const double *Rh = big_n ? Hh + (size_t)(m + 2) * ldh : hs->R;
+            const double *bvh = big_n ? Rh + (size_t)ldh * ldh + 2 * ldh : hs->beta_vec;
             if (!incremental) {
-                hipk_lstsq_normal(hs->H, HIPK_GM_LDH, k, res_norm, yy.y);
+                hipk_lstsq_normal(Hh, ldh, k, res_norm, yb.y);
             } else {
                 for (int i = k - 1; i >= 0; --i) {  // solve_triangular, TSL:630
-                    double s = hs->beta_vec[i];
-                    for (int p = i + 1; p < k; ++p) s = fma(-hs->R[i * HIPK_GM_LDH + p], yy.y[p], s);
-                    yy.y[i] = s / hs->R[i * HIPK_GM_LDH + i];
+                    double s = bvh[i];
+                    for (int p = i + 1; p < k; ++p) s = fma(-Rh[i * ldh + p], yb.y[p], s);
+                    yb.y[i] = s / Rh[i * ldh + i];
                 }
             }
-            hipk_gm_xupdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, k, V, ldv, x, yy);
+            if (k <= HIPK_GM_LDH) {
+                hipk_gm_y yy;
+                memcpy(yy.y, yb.y, sizeof(yy.y));
+                hipk_gm_xupdate_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, k, V, ldv, x, yy);
+            } else {
+                hipk_gm_xupdate_kernel<T, HIPK_GM_MAXM_BIG + 1><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, k, V, ldv, x, yb);
+            }
         }
         if ((rc = hipk_launch_spmv(A, sr, stream)) != HIPK_OK) break;
         ++matvecs;
@@ -2319,8 +2433,8 @@ extern "C" int hipk_gmres_solve(hipk_csr_t A, const void *b, void *x, void *work
     HIPK_REQUIRE(A && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
     HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
     HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
-    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
-                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM_BIG, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 255] on the HIP path");
     HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
                  "Unsupported solve_method");
     HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,
@@ -2340,8 +2454,8 @@ extern "C" int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, 
     HIPK_REQUIRE(A && dinv && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
     HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
     HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
-    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
-                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM_BIG, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 255] on the HIP path");
     HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
                  "Unsupported solve_method");
     HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && hipk_aligned16(dinv) && (((uintptr_t)work) & 255u) == 0,
@@ -2362,8 +2476,8 @@ extern "C" int hipk_pgmres_solve_cb(hipk_csr_t A, hipk_precond_fn M, void *user,
     HIPK_REQUIRE(A && M && b && x && work && prm && st, HIPK_ERR_ARG, "null argument");
     HIPK_REQUIRE(A->n_rows == A->n_cols, HIPK_ERR_ARG, "linear operator must be a square matrix");
     HIPK_REQUIRE(A->n_rows > 0, HIPK_ERR_ARG, "empty system");
-    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM, HIPK_ERR_UNSUPPORTED,
-                 "restart must be in [1, 31] on the HIP path");
+    HIPK_REQUIRE(prm->restart >= 1 && prm->restart <= HIPK_GM_MAXM_BIG, HIPK_ERR_UNSUPPORTED,
+                 "restart must be in [1, 255] on the HIP path");
     HIPK_REQUIRE(prm->gmres_method == HIPK_GMRES_BATCHED || prm->gmres_method == HIPK_GMRES_INCREMENTAL, HIPK_ERR_ARG,
                  "Unsupported solve_method");
     HIPK_REQUIRE(hipk_aligned16(b) && hipk_aligned16(x) && (((uintptr_t)work) & 255u) == 0, HIPK_ERR_ALIGN,

@@ -524,31 +524,35 @@ def bicgstab(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[
 
 
 _warned_restart = False
+# the device-resident GMRES keeps its Hessenberg arrays in the handle's header up to restart 31 and in a workspace block sized for
+# the restart up to 255 (csrc/hipk_gmres.hip: HIPK_GM_MAXM_BIG); the reference accepts any restart (TSL:641-644)
+_HIP_MAX_RESTART = 255
 
 
 def _warn_restart_route(A, b, x0, restart) -> None:
-    """gmres(restart > 31) on a device matrix leaves the HIP path (routing rule below): say so once, loudly --
+    """gmres(restart > 255) on a device matrix leaves the HIP path (routing rule below): say so once, loudly --
     at N = 4 M the generic torch-op path is orders of magnitude slower."""
     global _warned_restart
-    if not _warned_restart and restart > 31 and _fast_ok(A, b, x0, None):
+    if not _warned_restart and restart > _HIP_MAX_RESTART and _fast_ok(A, b, x0, None):
         import warnings
         _warned_restart = True
-        warnings.warn(f"gmres(restart={restart}): the device-resident HIP GMRES keeps at most 31 basis vectors; "
-                      f"restart > 31 runs on the generic torch-op path (one host synchronisation per Arnoldi step, "
-                      f"much slower on large systems). Use restart <= 31 to stay on the MI355X kernels.",
+        warnings.warn(f"gmres(restart={restart}): the device-resident HIP GMRES keeps at most {_HIP_MAX_RESTART} basis vectors; "
+                      f"restart > {_HIP_MAX_RESTART} runs on the generic torch-op path (one host synchronisation per Arnoldi step, "
+                      f"much slower on large systems). Use restart <= {_HIP_MAX_RESTART} to stay on the MI355X kernels.",
                       RuntimeWarning, stacklevel=4)
 
 
 def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
-    # the device-resident GMRES keeps at most 31 basis vectors (H in a fixed device block); larger Krylov
+    # the device-resident GMRES keeps at most 255 basis vectors (restart <= 31: H in the header block and the small-system
+    # one-launch kernels; beyond: H in a workspace block, launch sequences); larger Krylov
     # spaces take the generic path (documented routing rule, not a fallback on failure; warned about once)
     _warn_restart_route(A, b, x0, restart)
-    if _fast_ok(A, b, x0, M) and 1 <= restart <= 31:
+    if _fast_ok(A, b, x0, M) and 1 <= restart <= _HIP_MAX_RESTART:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method)
-    if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31:
+    if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= _HIP_MAX_RESTART:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method,
                            jacobi=_jacobi_of(M))
-    if (M is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= 31
+    if (M is not None and _fast_ok(A, b, x0, None) and 1 <= restart <= _HIP_MAX_RESTART
             and os.environ.get('HIPK_CG_CALLABLE_M', '1') != '0'):
         if solve_method not in ('batched', 'incremental'):
             raise ValueError(f"Unsupported solve_method: {solve_method}")

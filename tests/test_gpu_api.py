@@ -230,10 +230,12 @@ def test_c_abi_error_paths(hipk):
     xs = torch.zeros(2, dtype=torch.float64, device=DEV)
     work = torch.empty(16, dtype=torch.uint8, device=DEV)
     assert L.hipk_cg_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), 16, ctypes.byref(prm), ctypes.byref(st), None) == -5  # workspace
-    prm.restart = 40
-    wb = L.hipk_gmres_work_bytes(2, 31, 1)
+    prm.restart = 256
+    wb = L.hipk_gmres_work_bytes(2, 255, 1)
     work = torch.empty(wb, dtype=torch.uint8, device=DEV)
-    assert L.hipk_gmres_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st), None) == -4  # restart > 31
+    assert L.hipk_gmres_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st), None) == -4  # restart > 255
+    prm.restart = 40
+    assert L.hipk_gmres_solve(h, b.data_ptr(), xs.data_ptr(), work.data_ptr(), 1024, ctypes.byref(prm), ctypes.byref(st), None) == -5  # workspace
     assert L.hipk_cg_solve(h, b.data_ptr(), b.data_ptr(), work.data_ptr(), wb, ctypes.byref(prm), ctypes.byref(st), None) == -1  # aliasing
     L.hipk_csr_destroy(h)
     # shape errors through the Python surface keep the reference's exception types
@@ -246,12 +248,18 @@ def test_c_abi_error_paths(hipk):
 
 
 def test_restart_above_31_uses_reference_semantics(hipk):
-    """The HIP GMRES holds at most 31 basis vectors; larger restarts must still work (generic path)."""
-    from pytorch_sparse_solver.module_a import gmres
+    """restart 32 ... 255 stays on the HIP kernels (H in a workspace block), beyond that the generic path: both must work."""
+    from pytorch_sparse_solver.module_a import get_last_stats, gmres
     A, g = _spd(60)
     b = torch.randn(60, dtype=torch.float64, generator=g).to(DEV)
-    x, info = gmres(A, b, tol=1e-10, restart=40)
-    assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-8
+    for restart in (40, 300):
+        x, info = gmres(A, b, tol=1e-10, restart=restart)
+        assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-8
+    # restart = n (full GMRES) and restart > n on a small device system
+    for restart in (60, 100, 255):
+        for method in ("batched", "incremental"):
+            x, info = gmres(A, b, tol=1e-10, restart=restart, solve_method=method)
+            assert info == 0 and (torch.norm(b - A @ x) / torch.norm(b)).item() < 1e-8
 
 
 @pytest.mark.gpu
