@@ -69,12 +69,17 @@ def free_port():
 def self_launch(args):
     """`python bench.py --gpus N` as a plain process: run the N ranks as CHILD processes (torch.distributed.run) and relay
     rank 0's JSON line.  Nothing in this parent has touched the GPU (no torch.cuda call, torch not even imported)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        sys.stderr.write(proc.stderr.decode(errors="replace"))
+        # the port found free can be taken by the time the rendezvous store binds it: that one failure is retried
+        if proc.returncode == 0 or b"EADDRINUSE" not in proc.stderr:
+            break
     line = None
     for ln in proc.stdout.decode(errors="replace").splitlines():
         ln = ln.strip()
@@ -217,23 +222,30 @@ def main():
     cold_first_solve_ms = None
     if use_dist:
         import torch.distributed as dist
-        from pytorch_sparse_solver.distributed import DistPoissonProblem, dist_cg
+        from pytorch_sparse_solver import RowBlockCSR
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29581")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the row-partitioned solver is reached through the reference's call surface: cg(A, b, tol=...) (TSL:1019) with this
+        # rank's ROW BLOCK of the global matrix as the operand and its slice of b
         if strong:
-            prob = DistPoissonProblem(nx_global=nx, ny=nx, rank=rank, world=world, device=dev)
+            gx = nx
             workload = f"poisson5pt_{nx}x{nx}_N={nx * nx}_rowpart_{world}ranks_strong_cg_tol{args.tol:g}_b=ones"
         else:
-            prob = DistPoissonProblem(nx_per_rank=nx, ny=nx, rank=rank, world=world, device=dev)
+            gx = nx * world
             workload = f"poisson5pt_{nx * world}x{nx}_rowpart_{world}ranks_weak_cg_tol{args.tol:g}_b=ones"
+        A_rb = RowBlockCSR.poisson5(gx, nx, device=dev)
+        r0, r1 = RowBlockCSR.row_range(gx * nx)
+        b_loc = torch.ones(r1 - r0, dtype=torch.float64, device=dev)
+        prob = A_rb.problem(b_loc)      # halo plan, device matrix, communicator (the ranks agree on it here, before any solve)
 
         def barrier():
             dist.barrier()
 
         def one_solve():
-            return dist_cg(prob, tol=args.tol)
+            x, info = cg(A_rb, b_loc, tol=args.tol)
+            return x, info, get_last_stats()
         n_rows_rank, nnz_rank, spmv_bytes = prob.n_local, prob.nnz_local, prob.spmv_bytes
     else:
         A = create_poisson_2d_csr(nx, nx, device=dev)
@@ -261,27 +273,7 @@ def main():
         workload = f"poisson5pt_{nx}x{nx}_N={nx * nx}_cg_tol{args.tol:g}_b=ones" + ("_strong_1rank" if strong else "")
 
     for w in range(args.warmup):
-        if use_dist and w == 0:
-            # first solve of a multi-rank run: if the C-driven loop / the direct RCCL communicator fails on ANY rank, all ranks
-            # agree to continue on the Python loop with torch.distributed collectives (slower per iteration, same bits) instead
-            # of losing the run; the choice is reported in config.collectives
-            import torch.distributed as dist
-            failed = 0
-            try:
-                one_solve()
-            except Exception as e:  # noqa: BLE001
-                failed = 1
-                print(f"[bench rank {rank}] row-partitioned solve failed on the direct-RCCL path: {e}", file=sys.stderr, flush=True)
-            flag = torch.tensor([failed], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                os.environ["HIPK_DIST_NATIVE"] = "0"
-                if prob.comm is not None:
-                    prob.comm = None
-                    prob.comm_kind = "torch.distributed (fallback after a failure of the direct-RCCL path)"
-                one_solve()
-            continue
-        one_solve()
+        one_solve()     # a rank that fails raises: its process exits non-zero and the launcher tears the job down
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -510,7 +502,7 @@ def main():
             "config": {"workload": workload, "rows_global": n_global, "rows_per_gpu": n_rows_rank, "nnz_per_gpu": nnz_rank,
                        "iterations_per_solve": st.iterations, "info": info,
                        "relres": st.residual_norm / st.b_norm,
-                       "step": "one full cg() solve" + ("" if use_dist else " via the public API"),
+                       "step": "one full cg() solve via the public API" + (" (RowBlockCSR operand: this rank's rows)" if use_dist else ""),
                        "handle_creation_ms_outside_timed_region": handle_ms,
                        "cold_first_solve_ms": cold_first_solve_ms,
                        "rccl_ranks": world if use_dist else None,

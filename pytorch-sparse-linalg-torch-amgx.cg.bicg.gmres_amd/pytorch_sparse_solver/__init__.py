@@ -32,3 +32,11 @@ __all__ = [
     'create_tridiagonal_sparse_coo', 'create_poisson_2d_sparse_coo',
     'compute_residual', 'compute_relative_residual',
 ]
+
+
+def __getattr__(name):
+    # not part of the reference's import surface: the row-partitioned operand (one process per GPU), imported on first use
+    if name == 'RowBlockCSR':
+        from .distributed import RowBlockCSR
+        return RowBlockCSR
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -340,6 +340,7 @@ class DistStats:
     residual_norm: float
     x_norm: float
     threshold: float
+    method: str = ""
 
 
 class DistProblem:
@@ -367,12 +368,39 @@ class DistProblem:
         import os
         want = os.environ.get("HIPK_DIST_COMM", "rccl")
         if want == "rccl" and isinstance(ops, HipOps) and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            # The choice between the direct communicator (C-driven loops) and torch.distributed collectives (Python loop) is
+            # made HERE, once, by all ranks together and before any solve: each rank creates its communicator and runs one
+            # tiny all-gather through it, then the ranks agree (MIN over a torch.distributed all-reduce) -- a rank whose
+            # communicator failed must not leave its peers inside an RCCL call of a solve.  After this point an
+            # error return of hipk_dist_*_solve on one rank is fatal for the group: the rank raises, its process exits
+            # non-zero and the launcher (torch.distributed.run) tears the job down.
+            ok, why = 1, ""
             try:
                 self.comm = RcclComm(part.rank, part.world, ops.device, group)
+                probe_src = torch.full((1,), float(part.rank), dtype=torch.float64, device=ops.device)
+                probe_dst = torch.empty(part.world, dtype=torch.float64, device=ops.device)
+                self.comm.all_gather(probe_dst, probe_src)
+                torch.cuda.synchronize(ops.device)
+                if probe_dst.tolist() != [float(r) for r in range(part.world)]:
+                    raise RuntimeError(f"probe all-gather returned {probe_dst.tolist()}")
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
+            if part.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=ops.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                all_ok = int(flag.item())
+            else:
+                all_ok = ok
+            if all_ok:
                 self.comm_kind = "rccl-direct"
-            except Exception as e:  # stay functional on the well-trodden torch.distributed path
+            else:  # stay functional on the well-trodden torch.distributed path, on EVERY rank
                 import warnings
-                warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed collectives")
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm = None
+                self.comm_kind = "torch.distributed (the direct RCCL communicator failed on a rank)"
+                warnings.warn(f"direct RCCL communicator unavailable on a rank ({why or 'another rank'}); "
+                              f"all ranks use torch.distributed collectives")
         # opt-in: device mailboxes instead of RCCL for the C-driven loop's two exchanges (experimental, see P2PComm)
         self.p2p = None
         if want == "p2p" and isinstance(ops, HipOps) and (part.world == 1 or dist.is_initialized()):
@@ -609,6 +637,114 @@ def _agree_stop(prob, scal) -> int:
     (more ranks than chunks) take it from the others."""
     s = prob.ops.read_scal(scal)["stop_it"] if prob.n_local else (1 << 62)
     return prob.agree_min(s)
+
+
+class RowBlockCSR:
+    """This rank's ROW BLOCK of a global square CSR matrix -- the operand that puts the row-partitioned solvers behind the
+    reference's call surface (TSL:1019-1021, 1091-1093, 641-644; `SparseSolver.solve`, solver.py:256-379):
+
+        dist.init_process_group("nccl", ...)                       # one process per GPU
+        r0, r1 = RowBlockCSR.row_range(n_global)                    # the rows this rank owns
+        A = RowBlockCSR(crow_local, col_global, values, n_global)   # rows r0 .. r1 of the global matrix, GLOBAL column ids
+        x_local, info = cg(A, b[r0:r1], tol=1e-6)                   # or bicgstab / gmres / SparseSolver().solve(A, b_local, ...)
+
+    Every rank makes the same call with its block; `b`, `x0` and the returned `x` are the rank's slices of the global vectors;
+    `info` is the same on every rank.  Rows are split on reduction-chunk boundaries of the GLOBAL problem (`RowPartition`), so
+    the iterates are bitwise those of the single-device solve.  The halo plan, the device matrix (coded SpMV form included) and
+    the communicator are built on the first solve and reused by later ones (repeated solves with one matrix: the LDC caller).
+    `M` (preconditioners), PyTrees, complex operands and autograd are not available on this operand (ValueError)."""
+    _hipk_row_block = True
+
+    def __init__(self, crow_local: torch.Tensor, col_global: torch.Tensor, values: torch.Tensor, n_global: int, *,
+                 group=None, ops=None, problem_cls=None, force_ch: int = 0):
+        if group is None and not dist.is_initialized():
+            rank, world = 0, 1
+        else:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.part = RowPartition(int(n_global), world, rank, force_ch)
+        if crow_local.numel() != self.part.n_local + 1:
+            raise ValueError(f"RowBlockCSR: rank {rank} of {world} owns rows [{self.part.row0}, {self.part.row1}) of the "
+                             f"{n_global} x {n_global} system (RowBlockCSR.row_range), i.e. {self.part.n_local + 1} row pointers; "
+                             f"got {crow_local.numel()}")
+        if col_global.numel() != values.numel():
+            raise ValueError("RowBlockCSR: col_global and values must have the same length")
+        if values.dtype != torch.float64:
+            raise ValueError("RowBlockCSR: fp64 values (the reference's working precision, TSL:979-980)")
+        self.crow = (crow_local - crow_local[0]) if crow_local.numel() else crow_local
+        self.col, self.val = col_global, values
+        self.shape = (int(n_global), int(n_global))
+        self.dtype, self.device = values.dtype, values.device
+        self.group = group
+        self._ops, self._problem_cls, self._prob = ops, problem_cls, None
+        self.last_stats: Optional[DistStats] = None
+
+    # ---- which rows a rank owns
+    @staticmethod
+    def row_range(n_global: int, group=None, rank: Optional[int] = None, world: Optional[int] = None, force_ch: int = 0):
+        """(row_begin, row_end) of this rank's block (reduction-chunk aligned; a trailing rank may own no rows)."""
+        if rank is None or world is None:
+            rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        p = RowPartition(int(n_global), world, rank, force_ch)
+        return p.row0, p.row1
+
+    @classmethod
+    def from_global_csr(cls, A: torch.Tensor, **kw):
+        """Slice this rank's rows out of a replicated global CSR tensor (convenience; a large system is assembled per rank)."""
+        if A.layout != torch.sparse_csr or A.shape[0] != A.shape[1]:
+            raise ValueError("RowBlockCSR.from_global_csr needs a square sparse CSR tensor")
+        r0, r1 = cls.row_range(A.shape[0], kw.get("group"), force_ch=kw.get("force_ch", 0))
+        crow, col, val = A.crow_indices(), A.col_indices(), A.values()
+        j0, j1 = int(crow[r0]), int(crow[r1])
+        return cls((crow[r0:r1 + 1] - j0).clone(), col[j0:j1].clone(), val[j0:j1].clone(), A.shape[0], **kw)
+
+    # ---- the solve behind cg / bicgstab / gmres
+    def problem(self, b_local: torch.Tensor) -> "DistProblem":
+        if self._prob is None:
+            ops = self._ops
+            if ops is None:
+                if not self.val.is_cuda:
+                    raise ValueError("RowBlockCSR: the row-partitioned solvers run the HIP kernels -- give CUDA/ROCm tensors "
+                                     "(one process per GPU, backend 'nccl'); CPU tensors need an explicit `ops` backend (tests)")
+                ops = HipOps(self.val.device)
+            cls = self._problem_cls or DistProblem
+            self._prob = cls(self.crow, self.col, self.val, b_local, self.part, ops, self.group)
+        self._prob.b = b_local.contiguous()
+        return self._prob
+
+    def solve(self, method: str, b_local, x0_local=None, *, tol=1e-5, atol=0.0, maxiter=None, restart=20, solve_method="batched"):
+        if not isinstance(b_local, torch.Tensor) or b_local.ndim != 1 or b_local.numel() != self.part.n_local:
+            raise ValueError(f"RowBlockCSR: b must be this rank's slice of the right-hand side ({self.part.n_local} entries, rows "
+                             f"[{self.part.row0}, {self.part.row1}))")
+        if x0_local is not None and (not isinstance(x0_local, torch.Tensor) or x0_local.shape != b_local.shape):
+            raise ValueError(f"arrays in x0 and b must have matching shapes: {getattr(x0_local, 'shape', None)} vs {b_local.shape}")
+        if b_local.device != self.val.device:
+            raise ValueError("RowBlockCSR: b lives on another device than the matrix block")
+        prob = self.problem(b_local.detach().to(torch.float64))
+        x0 = None if x0_local is None else x0_local.detach().to(torch.float64)
+        if method == "cg":
+            x, info, st = dist_cg(prob, x0, tol=tol, atol=atol, maxiter=maxiter)
+        elif method == "bicgstab":
+            x, info, st = dist_bicgstab(prob, x0, tol=tol, atol=atol, maxiter=maxiter)
+        elif method == "gmres":
+            x, info, st = dist_gmres(prob, x0, tol=tol, atol=atol, restart=restart, maxiter=maxiter, solve_method=solve_method)
+        else:
+            raise ValueError(f"Method '{method}' not available on a RowBlockCSR operand. Use: ['cg', 'bicgstab', 'gmres']")
+        st.method = method
+        self.last_stats = st
+        return x.clone(), int(info), st
+
+    def relative_residual(self) -> float:
+        """||b - A x|| / ||b|| of the GLOBAL system for the last solve's x (its true-residual epilogue, TSL:1007-1014 / 766-773)."""
+        st = self.last_stats
+        return float("nan") if st is None else (st.residual_norm / st.b_norm if st.b_norm > 0 else float("inf"))
+
+    @classmethod
+    def poisson5(cls, nx: int, ny: int, *, device=None, **kw):
+        """bench.py workload: this rank's rows of the 5-point Poisson matrix on an nx x ny grid (row k = i * ny + j)."""
+        from .utils.matrix_utils import stencil5_csr_components
+        r0, r1 = cls.row_range(nx * ny, kw.get("group"), force_ch=kw.get("force_ch", 0))
+        crow, col, val = stencil5_csr_components(nx, ny, 4.0, -1.0, -1.0, -1.0, -1.0, row_begin=r0, row_end=r1, device=device)
+        return cls(crow, col, val, nx * ny, **kw)
 
 
 class DistPoissonProblem(DistProblem):

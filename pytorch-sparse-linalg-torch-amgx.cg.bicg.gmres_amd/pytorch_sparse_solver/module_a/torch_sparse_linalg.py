@@ -437,6 +437,23 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
     return P.unravel(x), info
 
 
+def _is_row_block(A) -> bool:
+    """A `distributed.RowBlockCSR` operand: this rank's rows of a global system (one process per GPU)."""
+    return getattr(A, '_hipk_row_block', False) is True
+
+
+def _dist_solve(kind: str, A, b, x0, tol, atol, maxiter, M, restart=20, solve_method='batched'):
+    """cg / bicgstab / gmres on a RowBlockCSR operand: the row-partitioned solvers (distributed.py, csrc/hipk_dist.hip) behind the
+    reference's call surface.  Returns this rank's slice of x and the (rank-independent) info."""
+    if M is not None and M is not _identity:
+        raise ValueError(f"{kind}: preconditioners are not available on a RowBlockCSR (row-partitioned) operand")
+    if kind == 'gmres' and solve_method not in ('batched', 'incremental'):
+        raise ValueError(f"Unsupported solve_method: {solve_method}")
+    x, info, st = A.solve(kind, b, x0, tol=tol, atol=atol, maxiter=maxiter, restart=restart, solve_method=solve_method)
+    _set_stats(st)
+    return x, info
+
+
 def _use_implicit_diff(A: Any, b: Any) -> bool:
     return (isinstance(A, torch.Tensor) and isinstance(b, torch.Tensor) and A.ndim == 2
             and (A.requires_grad or b.requires_grad))
@@ -496,7 +513,10 @@ def cg(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[Any] =
     """Conjugate gradients for hermitian positive definite `A` (TSL:1019-1088).
 
     Returns `(x, info)`; info = 0 iff ||b - A x|| <= max(tol ||b||, atol) for the returned x.
+    `A` may be a `RowBlockCSR` (this rank's rows of a global system inside a process group): `b`, `x0`, `x` are then the rank's slices.
     """
+    if _is_row_block(A):
+        return _dist_solve('cg', A, b, x0, tol, atol, maxiter, M)
     diff = _use_implicit_diff(A, b)
     A_, b_ = (A.detach(), b.detach()) if diff else (A, b)
     x, info = _isolve('cg', A_, b_, x0, tol, atol, maxiter, M)
@@ -511,7 +531,9 @@ def cg(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[Any] =
 def bicgstab(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[Any] = None,
              *, tol: float = 1e-5, atol: float = 0.0, maxiter: Optional[int] = None,
              M: Optional[Callable[[Any], Any]] = None) -> Tuple[Any, Optional[int]]:
-    """BiCGStab for general square `A` (TSL:1091-1154). Returns `(x, info)`."""
+    """BiCGStab for general square `A` (TSL:1091-1154). Returns `(x, info)`.  `A` may be a `RowBlockCSR` (see `cg`)."""
+    if _is_row_block(A):
+        return _dist_solve('bicgstab', A, b, x0, tol, atol, maxiter, M)
     diff = _use_implicit_diff(A, b)
     A_, b_ = (A.detach(), b.detach()) if diff else (A, b)
     x, info = _isolve('bicgstab', A_, b_, x0, tol, atol, maxiter, M)
@@ -591,7 +613,9 @@ def gmres(A: Union[torch.Tensor, Callable[[Any], Any]], b: Any, x0: Optional[Any
           solve_method: str = 'batched') -> Tuple[Any, Optional[int]]:
     """Restarted GMRES (TSL:641-784). `maxiter` counts restart cycles; `solve_method` is
     'batched' (least squares by normal equations at the end of a cycle) or 'incremental'
-    (Givens QR with early exit inside a cycle). Returns `(x, info)`."""
+    (Givens QR with early exit inside a cycle). Returns `(x, info)`.  `A` may be a `RowBlockCSR` (see `cg`; restart <= 31 there)."""
+    if _is_row_block(A):
+        return _dist_solve('gmres', A, b, x0, tol, atol, maxiter, M, restart=restart, solve_method=solve_method)
     diff = _use_implicit_diff(A, b)
     A_, b_ = (A.detach(), b.detach()) if diff else (A, b)
     x, info = _gmres_impl(A_, b_, x0, tol, atol, restart, maxiter, M, solve_method)

@@ -124,6 +124,8 @@ class SparseSolver:
 
     @staticmethod
     def _relative_residual(A, x, b) -> float:
+        if getattr(A, '_hipk_row_block', False):   # RowBlockCSR: ||b - A x|| / ||b|| of the GLOBAL system, from the solve's epilogue
+            return A.relative_residual()
         if callable(A):
             Ax = A(x)
         elif A.is_cuda and A.layout in (torch.sparse_csr, torch.strided, torch.sparse_coo) and x.ndim == 1 \

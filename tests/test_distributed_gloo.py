@@ -21,23 +21,26 @@ def _free_port():
 
 def _run(world, kind, nx, ny, tol, maxiter, tmp_path, mode="cpu", solver="cg"):
     out = str(tmp_path / f"res_{world}_{kind}.json")
-    port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), kind, str(nx), str(ny),
-                                       str(tol), str(maxiter), out, mode, solver], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT))
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(o.decode(errors="replace"))
+    for _attempt in range(3):   # a port found free can be taken before the store binds it (EADDRINUSE): try another one
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), kind, str(nx), str(ny),
+                                           str(tol), str(maxiter), out, mode, solver], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT))
+        logs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            logs.append(o.decode(errors="replace"))
+        if all(p.returncode == 0 for p in procs) or not any("EADDRINUSE" in lg for lg in logs):
+            break
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     with open(out) as f:
         return json.load(f)
@@ -179,8 +182,11 @@ print(json.dumps({"gm_equal": bool(torch.equal(xg, xgr)), "gm_info": [info_g, in
                   "bi_equal": bool(torch.equal(xb, xbr)), "bi_info": [info_b, info_br], "bi_it": [stb.iterations, sb.iterations]}))
 dist.destroy_process_group()
 ''' % (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd"))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    for _ in range(3):     # the port found free can be taken by the time the store binds it (EADDRINUSE): take another one
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break
     assert p.returncode == 0, p.stdout + p.stderr
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["equal"] and r["info"] == r["info_r"] == 0 and r["it"] == r["it_r"] and r["res"] == r["res_r"], r

@@ -2,7 +2,7 @@
 # round 3, call 1: GPU suite on the rebuilt library (kernel durations now from start/stop events bound to the dispatch), bench.py,
 # and rocprofv3 --kernel-trace --stats of the same bench command to check that its averages equal the in-loop figures
 set -o pipefail
-O=gpurun_out/r03c3
+O=gpurun_out/r03c4
 mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.txt
@@ -12,7 +12,7 @@ timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench r
 grep -q "bench rc=0" $O/status.txt || { tail -20 $O/bench.err; exit 1; }
 python3 - <<'PY'
 import json
-d = json.load(open("gpurun_out/r03c3/bench.json"))
+d = json.load(open("gpurun_out/r03c4/bench.json"))
 print("iter us", d["roofline"]["iteration_us_sum_of_kernels"], d["roofline"]["iteration_us_from_timed_region"]); print("value", d["value"], "ms_per_step", d["ms_per_step"], "cold", d["config"].get("cold_first_solve_ms"))
 for k in d["kernels"]:
     print(k["key"], round(k["avg_launch_us"], 2), "us chain,", round(k["dispatch_span_us"], 2), "span", round(k["frac_of_hbm_peak"], 3))
