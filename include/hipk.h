@@ -218,6 +218,18 @@ int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, vo
 size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype);
 int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
                          const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* ---- MATRIX-FREE operators (the reference's `_normalize_matvec` takes a callable for all three solvers, TSL:176-208).
+ * hipk_op_create makes a handle WITHOUT a matrix: every product y = A x of a solve is `op(user, x_dev, y_dev)`, which enqueues
+ * y = A(x) (vectors of `dtype`, n elements) on the solve's stream and returns 0.  The residual form b - A x, the row scaling of
+ * the Jacobi forms and the fused dots of the SpMV kernels follow in one epilogue kernel with the SAME reduction spec ("tiled dot"),
+ * so hipk_cg_solve / hipk_bicgstab_solve / hipk_gmres_solve (and the hipk_p* forms) run unchanged on such a handle -- device
+ * stop word, one host synchronisation per GMRES cycle and none inside CG / BiCGStab -- and, when `op` computes this library's
+ * SpMV of a matrix, return that matrix's solve bit for bit.  The host calls `op` when it ENQUEUES an iteration (a few ahead of the
+ * device): it must not synchronise, and it may be called for a few iterations past the stop (their results are never read).
+ * The one-launch small-system kernels need the matrix and are not taken.  Destroy with hipk_csr_destroy. */
+typedef int (*hipk_op_fn)(void *user, const void *x_dev, void *y_dev);
+int hipk_op_create(hipk_csr_t *out, int64_t n, int dtype, hipk_op_fn op, void *user, hipk_stream_t stream);
+
 /* BiCGStab with the CALLER's preconditioner: M(user, in_dev, out_dev) enqueues out = M(in) (vectors of the handle's
  * dtype, n elements) on `stream` and returns 0; it is called for p and s of every iteration (TSL:908, 922) and once
  * for the final residual (TSL:1007).  Workspace as hipk_pbicgstab_work_bytes.  With M = diag(dinv) the iterates equal

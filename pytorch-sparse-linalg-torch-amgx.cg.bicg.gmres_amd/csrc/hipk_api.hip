@@ -437,6 +437,66 @@ extern "C" int hipk_csr_create_ex(hipk_csr_t *out, int64_t n_rows, int64_t n_col
     return HIPK_OK;
 }
 
+extern "C" int hipk_op_create(hipk_csr_t *out, int64_t n, int dtype, hipk_op_fn op, void *user, hipk_stream_t stream_) {
+    (void)stream_;
+    HIPK_REQUIRE(out != nullptr, HIPK_ERR_ARG, "out is null");
+    *out = nullptr;
+    HIPK_REQUIRE(op != nullptr, HIPK_ERR_ARG, "operator callback is null");
+    HIPK_REQUIRE(n > 0 && n < INT32_MAX, HIPK_ERR_ARG, "n out of range");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype must be f32/f64");
+    hipk_csr_s *h = new hipk_csr_s();
+    memset(h, 0, sizeof(*h));
+    h->n_rows = h->n_cols = n;
+    h->dtype = dtype;
+    h->geom = hipk_make_geom(n);
+    h->op_cb = op;
+    h->op_user = user;
+    h->max_row_len = INT32_MAX;   // nothing that holds matrix rows in registers / LDS applies
+    h->max_tile_nnz = INT32_MAX;
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tile_part, sizeof(double) * 8 * (size_t)((n + 255) / 256 + 1));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_poll, 16 * sizeof(int64_t), hipHostMallocDefault);
+    {
+        hipDeviceProp_t prop;
+        h->n_cu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+    }
+    if (e != hipSuccess) {
+        hipk_set_error("hipk_op_create: %s", hipGetErrorString(e));
+        hipk_csr_destroy(h);
+        return HIPK_ERR_HIP;
+    }
+    *out = h;
+    return HIPK_OK;
+}
+
+// epilogue of a matrix-free product (y already holds A x): residual form, row scaling, the SpMV kernels' fused dots as
+// per-wavefront tile sums (the "tiled dot" of the spec, as hipk_rowdot_kernel forms them for the row-per-wavefront path)
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_op_epilogue_kernel(hipk_spmv_args a) {
+    if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x;
+    const int64_t r = (int64_t)tile * HIPK_TILE + t;
+    double d0 = 0.0, d1 = 0.0;
+    if (r < a.n) {
+        T out = ((const T *)a.y)[r];
+        if (a.mode & HIPK_SPMV_RESID) out = ((const T *)a.bsub)[r] - out;
+        if (a.mode & HIPK_SPMV_SCALE) out = ((const T *)a.dscale)[r] * out;
+        if (a.mode & (HIPK_SPMV_RESID | HIPK_SPMV_SCALE)) ((T *)a.y)[r] = out;
+        if (a.mode & HIPK_SPMV_DOT_W) d0 = (double)((const T *)a.w)[r] * (double)out;
+        if (a.mode & HIPK_SPMV_DOT_YY) d1 = (double)out * (double)out;
+    }
+    if (a.mode & HIPK_SPMV_DOT_W) {
+        d0 = hipk_wave_sum(d0);
+        if (lane == 0) a.tpart0[(size_t)tile * 4 + wave] = d0;
+    }
+    if (a.mode & HIPK_SPMV_DOT_YY) {
+        d1 = hipk_wave_sum(d1);
+        if (lane == 0) a.tpart1[(size_t)tile * 4 + wave] = d1;
+    }
+}
+
 extern "C" int hipk_csr_destroy(hipk_csr_t h) {
     if (!h) return HIPK_OK;
     if (h->crow) (void)hipFree(h->crow);
@@ -494,6 +554,25 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
     const int grid = ((ntiles + 7) >> 3) << 3;
     a.tpart0 = h->tile_part;
     a.tpart1 = h->tile_part + 4 * (size_t)ntiles;
+    if (h->op_cb != nullptr) {   // matrix-free operator (hipk_op_create): the caller's product, then the epilogue + combine
+        HIPK_NOTE_KERNEL("%s", "operator callback + hipk_op_epilogue_kernel");
+        if (h->op_cb(h->op_user, a.x, a.y) != 0) {
+            hipk_set_error("the operator callback of a matrix-free handle failed");
+            return HIPK_ERR_ARG;
+        }
+        if (a.mode != 0) {
+            if (h->dtype == HIPK_F64)
+                hipk_launch_timed(prof, HIPK_K_SPMV, hipk_op_epilogue_kernel<double>, ntiles, HIPK_THREADS, 0, stream, a);
+            else
+                hipk_launch_timed(prof, HIPK_K_SPMV, hipk_op_epilogue_kernel<float>, ntiles, HIPK_THREADS, 0, stream, a);
+            if (!a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY)))
+                hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream,
+                                  (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,
+                                  a.part0, a.part1, ntiles, a.ch / 256, a.g, a.stop_it, a.it);
+        }
+        HIPK_CHECK_HIP(hipGetLastError());
+        return HIPK_OK;
+    }
     // long-row matrices (mean row length >= 48, or rows that do not fit the LDS product buffer): row per wavefront
     const bool rowwave = h->n_rows > 0 && h->nnz / h->n_rows >= 48;
     if (!rowwave && h->n_huge > 0) {

@@ -107,6 +107,9 @@ struct hipk_csr_s {
     int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)
     int n_cu;               // compute units of the device
     int sell_chunked;       // 1: the persistent kernel may take one reduction chunk per workgroup (no combine launch)
+    // matrix-free operator (hipk_op_create): every product is op_cb(op_user, x, y) + an epilogue kernel; no CSR arrays
+    int (*op_cb)(void *user, const void *x_dev, void *y_dev);
+    void *op_user;
 };
 
 #ifdef __HIPCC__

@@ -25,7 +25,7 @@ GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
 
 # every symbol include/hipk.h declares (tests/test_abi.py checks the export list)
 SYMBOLS = [
-    "hipk_version", "hipk_build_id", "hipk_last_error", "hipk_device_count",
+    "hipk_version", "hipk_build_id", "hipk_op_create", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
     "hipk_csr_spmv_path", "hipk_last_spmv_kernel", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
@@ -126,8 +126,9 @@ class DistPlan(ctypes.Structure):
                 ("send_first", ctypes.POINTER(ctypes.c_int64))]
 
 
-# hipk_precond_fn (include/hipk.h): int M(void *user, const void *in_dev, void *out_dev)
+# hipk_precond_fn / hipk_op_fn (include/hipk.h): int f(void *user, const void *in_dev, void *out_dev)
 PRECOND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+OP_FN = PRECOND_FN
 
 
 _lib = None
@@ -161,6 +162,7 @@ def lib():
     L.hipk_device_count.restype = i32
     L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]
     L.hipk_csr_destroy.argtypes = [vp]
+    L.hipk_op_create.argtypes = [ctypes.POINTER(vp), i64, i32, OP_FN, vp, vp]
     for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes, L.hipk_csr_format_bytes):
         f.argtypes = [vp]
         f.restype = i64
@@ -543,6 +545,8 @@ def block_jacobi_apply(binv: torch.Tensor, block_size: int, v: torch.Tensor) -> 
 def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Params, work_bytes: int) -> SolveStats:
     L = lib()
     work = torch.empty(work_bytes, dtype=torch.uint8, device=h.device)
+    if hasattr(h, "regions"):   # OpHandle: the operator callback resolves raw pointers against these tensors
+        h.regions.append(work)
     st = Stats()
     fn = getattr(L, f"hipk_{method}_solve")
     with h._lock, torch.cuda.device(h.device):
@@ -598,6 +602,8 @@ def solve_pcg(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Tensor
     name = {"cg": "pcg", "bicgstab": "pbicgstab"}[method]
     wb = int(getattr(L, f"hipk_{name}_work_bytes")(h.n, _dtype_code(h.dtype)))
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
+    if hasattr(h, "regions"):   # OpHandle: the operator callback resolves raw pointers against these tensors
+        h.regions.append(work)
     st = Stats()
     with h._lock, torch.cuda.device(h.device):
         rc = getattr(L, f"hipk_{name}_solve")(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
@@ -626,6 +632,8 @@ def solve_pgmres(h: CsrHandle, dinv: torch.Tensor, b: torch.Tensor, x: torch.Ten
     L = lib()
     wb = int(L.hipk_gmres_work_bytes(h.n, int(restart), _dtype_code(h.dtype)))
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
+    if hasattr(h, "regions"):   # OpHandle: the operator callback resolves raw pointers against these tensors
+        h.regions.append(work)
     st = Stats()
     with h._lock, torch.cuda.device(h.device):
         rc = L.hipk_pgmres_solve(h.ptr, dinv.data_ptr(), b.data_ptr(), x.data_ptr(), work.data_ptr(), wb,
@@ -762,6 +770,101 @@ def solve_cg_stepwise(h: Optional[CsrHandle], A_fn, M, b: torch.Tensor, x: torch
                       solve_ms=e0.elapsed_time(e1), spmv_ms_avg=0.0, spmv_profiled=0)
 
 
+class OpHandle:
+    """hipk_op_create: a handle WITHOUT a matrix -- every product of a solve is the caller's `fn(v) -> A v` (device code on
+    the current stream), followed by the library's epilogue kernel (residual form, fused dots).  It quacks like a CsrHandle
+    for `solve` / `solve_pcg` / `_solve_with_callback` (ptr, n, shape, dtype, device, _lock).  The C loop hands raw device
+    pointers to the callback; they are resolved against the tensors registered in `regions` (the solve's workspace, b, x)."""
+
+    def __init__(self, fn, n: int, dtype: torch.dtype, device):
+        self.fn, self.n, self.shape, self.dtype, self.device = fn, int(n), (int(n), int(n)), dtype, torch.device(device)
+        self.regions = []
+        self.errors = []
+        self.calls = 0
+        self._lock = _SolveLock()
+        self._nbytes = self.n * torch.empty(0, dtype=dtype).element_size()
+        self._cb = OP_FN(self._call)      # keep the thunk alive as long as the handle
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib().hipk_op_create(ctypes.byref(self._h), self.n, _dtype_code(dtype), self._cb, None, _stream(self.device)),
+                   "hipk_op_create")
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def _view(self, ptr):
+        ptr = int(ptr)
+        for t in self.regions:
+            off = ptr - t.data_ptr()
+            if 0 <= off and off + self._nbytes <= t.numel() * t.element_size():
+                flat = t.view(torch.uint8) if t.dtype != torch.uint8 else t
+                return flat[off:off + self._nbytes].view(self.dtype)
+        raise HipkError("operator callback: pointer outside the solve's workspace, b and x")
+
+    def _call(self, _user, x_ptr, y_ptr):
+        try:
+            vin, vout = self._view(x_ptr), self._view(y_ptr)
+            y = self.fn(vin)
+            if not isinstance(y, torch.Tensor) or y.shape != vin.shape:
+                raise ValueError("the operator must map a vector to a vector of the same shape")
+            vout.copy_(y)
+            self.calls += 1
+            return 0
+        except BaseException as e:  # never let an exception unwind through the C frames
+            self.errors.append(e)
+            return 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hipk_csr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_matrix_free(kind: str, A_fn, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float, maxiter: Optional[int],
+                      restart: int = 20, solve_method: str = "batched", M=None, dinv: Optional[torch.Tensor] = None) -> SolveStats:
+    """cg / bicgstab / gmres with a MATRIX-FREE operator (`_normalize_matvec` takes a callable for all three solvers,
+    TSL:176-208) on the device-resident C loops: `A_fn` is called where the loops launch their SpMV (hipk_op_create), the fused
+    vector kernels, the device stop word and the pacing are the matrix path's.  M: None, a callable (bicgstab / gmres: the
+    *_solve_cb loops) or `dinv` for the Jacobi forms.  `x` holds x0 on entry and the solution on return."""
+    assert b.is_cuda and b.is_contiguous() and x.is_contiguous() and x.dtype == b.dtype and x.shape == b.shape and b.ndim == 1
+    h = OpHandle(A_fn, b.numel(), b.dtype, b.device)
+    try:
+        # what the callback's pointers may point into: b, x and the workspace (the solve functions register theirs)
+        h.regions = [b, x]
+        if dinv is not None:
+            if kind == "gmres":
+                st = solve_pgmres(h, dinv, b, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart, solve_method=solve_method)
+            else:
+                st = solve_pcg(h, dinv, b, x, tol=tol, atol=atol, maxiter=maxiter, method=kind)
+        elif M is not None:
+            if kind == "cg":
+                raise HipkError("solve_matrix_free: cg with a callable M runs on solve_cg_stepwise")
+            st = _solve_with_callback(kind, h, M, b, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                                      solve_method=solve_method)
+        else:
+            st = solve(kind, h, b, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart, solve_method=solve_method)
+        if h.errors:
+            torch.cuda.synchronize(b.device)
+            raise h.errors[0]
+        st.method = f"{kind}_matrix_free" + ("_jacobi" if dinv is not None else "_callable_M" if M is not None else "")
+        return st
+    except HipkError:
+        if h.errors:
+            torch.cuda.synchronize(b.device)
+            raise h.errors[0]
+        raise
+    finally:
+        torch.cuda.synchronize(b.device)   # nothing of the solve may still read the handle's scratch
+        h.close()
+
+
 def solve_bicgstab_callable(h: CsrHandle, M, b: torch.Tensor, x: torch.Tensor, *, tol: float, atol: float,
                             maxiter: Optional[int], check_every: int = 0) -> SolveStats:
     """hipk_pbicgstab_solve_cb: the device-resident BiCGStab loop with a CALLABLE preconditioner (TSL:859-964 with M)."""
@@ -801,6 +904,8 @@ def _solve_with_callback(kind: str, h: CsrHandle, M, b: torch.Tensor, x: torch.T
         wb = int(L.hipk_pbicgstab_work_bytes(h.n, _dtype_code(h.dtype)))
         fn = L.hipk_pbicgstab_solve_cb
     work = torch.empty(wb, dtype=torch.uint8, device=h.device)
+    if hasattr(h, "regions"):   # OpHandle: the operator callback resolves raw pointers against these tensors
+        h.regions.append(work)
     base, nbytes = work.data_ptr(), h.n * work.new_empty(0, dtype=h.dtype).element_size()
     errors = []
 

@@ -190,6 +190,33 @@ def _fast_solve_matrix_free(A, b, x0, tol, atol, maxiter, M):
     return x, int(st.info)
 
 
+def _fast_solve_matrix_free_c(kind, A, b, x0, tol, atol, maxiter, M, restart=20, solve_method='batched'):
+    """cg() / bicgstab() / gmres() with a MATRIX-FREE operator on device vectors, on the device-resident C loops
+    (`_hipk.solve_matrix_free`: hipk_op_create + hipk_{cg,bicgstab,gmres}_solve and their preconditioned forms): no host
+    synchronisation inside CG / BiCGStab, one per GMRES cycle.  fp64 like the reference (TSL:979-980)."""
+    from .. import _hipk
+
+    if x0 is not None and x0.shape != b.shape:
+        raise ValueError(f'arrays in x0 and b must have matching shapes: {x0.shape} vs {b.shape}')
+    if kind == 'gmres' and solve_method not in ('batched', 'incremental'):
+        raise ValueError(f"Unsupported solve_method: {solve_method}")
+    bb = b.detach().to(torch.float64).contiguous()
+    x = torch.zeros_like(bb) if x0 is None else x0.detach().to(torch.float64).clone().contiguous()
+    A_fn = _normalize_matvec(A)
+    jac = _jacobi_of(M)
+    if jac is not None:
+        if jac.shape != (bb.numel(), bb.numel()):
+            raise ValueError(f'preconditioner shape {jac.shape} does not match the operator {(bb.numel(), bb.numel())}')
+        st = _hipk.solve_matrix_free(kind, A_fn, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                                     solve_method=solve_method, dinv=jac.dinv.detach().to(device=bb.device, dtype=torch.float64).contiguous())
+    else:
+        M_fn = None if (M is None or M is _identity) else _normalize_matvec(M)
+        st = _hipk.solve_matrix_free(kind, A_fn, bb, x, tol=tol, atol=atol, maxiter=maxiter, restart=restart,
+                                     solve_method=solve_method, M=M_fn)
+    _set_stats(st)
+    return x, int(st.info)
+
+
 def _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M, restart=20, solve_method='batched'):
     """cg() / bicgstab() / gmres() with an arbitrary preconditioner `M` (callable or matrix) and a device CSR/dense `A`:
     the fused kernels run the iteration, `M` is called between them on the same stream (`_hipk.solve_cg_callable` through
@@ -419,9 +446,14 @@ def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter, jacobi=_jacobi_of(M))
     if M is not None and _fast_ok(A, b, x0, None) and os.environ.get('HIPK_CG_CALLABLE_M', '1') != '0':
         return _fast_solve_callable(kind, A, b, x0, tol, atol, maxiter, M)   # any other M: fused kernels around the callable
-    if (kind == 'cg' and callable(A) and not isinstance(A, torch.Tensor) and _device_vectors(b, x0)
+    if (callable(A) and not isinstance(A, torch.Tensor) and _device_vectors(b, x0)
             and os.environ.get('HIPK_CG_MATRIX_FREE', '1') != '0'):
-        return _fast_solve_matrix_free(A, b, x0, tol, atol, maxiter, M)     # matrix-free operator between the fused kernels
+        # matrix-free operator (TSL:176-208 takes a callable for every solver): the device-resident C loops call `A` where they
+        # launch their SpMV (hipk_op_create); cg with a callable M keeps the host-driven step loop (HIPK_CG_MATRIX_FREE=step: always)
+        if (kind == 'cg' and M is not None and M is not _identity and _jacobi_of(M) is None) \
+                or (kind == 'cg' and os.environ.get('HIPK_CG_MATRIX_FREE') == 'step'):
+            return _fast_solve_matrix_free(A, b, x0, tol, atol, maxiter, M)
+        return _fast_solve_matrix_free_c(kind, A, b, x0, tol, atol, maxiter, M)
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size
@@ -579,6 +611,9 @@ def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
         if solve_method not in ('batched', 'incremental'):
             raise ValueError(f"Unsupported solve_method: {solve_method}")
         return _fast_solve_callable('gmres', A, b, x0, tol, atol, maxiter, M, restart=restart, solve_method=solve_method)
+    if (callable(A) and not isinstance(A, torch.Tensor) and _device_vectors(b, x0) and 1 <= restart <= _HIP_MAX_RESTART
+            and os.environ.get('HIPK_CG_MATRIX_FREE', '1') != '0'):
+        return _fast_solve_matrix_free_c('gmres', A, b, x0, tol, atol, maxiter, M, restart=restart, solve_method=solve_method)
     P = _Flat(A, b, x0, M)
     if maxiter is None:
         maxiter = 10 * P.size
