@@ -42,6 +42,7 @@ NX = 2000
 # per-kernel HBM traffic from committed rocprofv3 --pmc passes (tools/prof_bench.sh + tools/pmc_to_json.py): NOT measured
 # in this run (PMC needs rocprofv3 attached); stamped with the commit it was taken at and dropped when the kernel differs
 PMC_FILES = ("r03_pmc_kernels.json",)
+STATS_FILE = "r03_bench_kernel_stats.json"   # tools/kernel_stats_to_json.py: rocprofv3 --kernel-trace --stats of this command
 
 
 def parse():
@@ -300,15 +301,27 @@ def main():
     spmv_standalone = None
     kernels = None
     spmv_report = None
-    TIMING = ("every launch of 256 profiled CG iterations carries start/stop events bound to its dispatch (hipExtLaunchKernel); "
-              "avg_launch_us = stop of the launch - stop of the launch before it on the stream = the time the kernel occupies "
-              "the stream (the three kernels add up to the iteration time); nothing subtracted; dispatch_span_us = the launch's "
-              "own stop - start, for reference; rocprofv3 --kernel-trace averages of the same command: profiles/")
+    TIMING = ("avg_launch_us = stop - start of start/stop events bound to the kernel's dispatch (hipExtLaunchKernel), averaged over "
+              "the launches of 256 CG iterations inside the solver loop; RAW, nothing subtracted: the start stamp is taken when the "
+              "dispatch is picked up, 0.6-1.5 us before the first wave while the previous kernel drains, so these figures are "
+              "conservative by 4-9 % on the 16-25 us kernels and < 1 % on the N = 64 M ones (csrc/hipk_solve.h); rocprofv3_avg_us / "
+              "frac_rocprofv3 = the average of `rocprofv3 --kernel-trace --stats` on the same command, from the committed profile of "
+              "the SAME library build (profiles/" + (STATS_FILE) + "), null when the build differs")
     if not use_dist:
         n = nx * nx
         sv = 8
         build_id = _hipk.lib().hipk_build_id().decode()
         pmc_name, pmc_doc, pmc_dropped = load_pmc(build_id)
+        try:
+            prof_doc = json.load(open(os.path.join(ROOT, "profiles", STATS_FILE)))
+        except Exception:
+            prof_doc = {}
+        prof_kernels = prof_doc.get("kernels", {}) if prof_doc.get("build_id") == build_id else {}
+
+        def rocprof_us(kernel_ran):
+            """rocprofv3's average duration of this kernel instantiation in the committed profile of THIS build, or None."""
+            e = prof_kernels.get(kernel_ran.split(" (")[0].replace(" ", ""))
+            return None if e is None else e["avg_us"]
 
         def traffic_of(section, key, kernel_ran):
             """PMC traffic of the committed profile of THIS build, only when it was taken on the same kernel instantiation."""
@@ -323,7 +336,7 @@ def main():
         def in_loop(which, handle, rhs):
             xx = torch.zeros_like(rhs)
             pst = _hipk.solve("cg", handle, rhs, xx, tol=args.tol, atol=0.0, maxiter=256, profile=which)
-            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled, pst.dispatch_span_ms_avg * 1e3
+            return pst.spmv_ms_avg * 1e3, pst.spmv_profiled
 
         def cg_legs(handle, rhs, nn, section, bound):
             """The three kernels of the CG iteration on `handle`: name, algorithmic bytes, in-loop duration."""
@@ -349,9 +362,10 @@ def main():
                      "read r, p, x; write p, x = 40 n")]
             out = []
             for key, which, name, nbytes, what in legs:
-                us, cnt, span = in_loop(which, handle, rhs)
+                us, cnt = in_loop(which, handle, rhs)
+                pus_ = rocprof_us(name)
                 k = {"key": key, "kernel": name, "bound": bound, "avg_launch_us": us, "launches_timed": cnt,
-                     "dispatch_span_us": span,
+                     "rocprofv3_avg_us": pus_, "frac_rocprofv3": None if pus_ is None else nbytes / pus_ / 1e3 / HBM_PEAK_GBPS,
                      "algorithmic_bytes_per_launch": nbytes, "bytes_are": what,
                      "achieved_GBps": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBPS,
                      "traffic": traffic_of(section, key, name)}
@@ -360,7 +374,7 @@ def main():
                     k["csr_formula_bytes"] = sb
                 if key == "cg_direction" and flat:
                     k["scalars_launch_us"] = in_loop(4, handle, rhs)[0]
-                    k["avg_launch_us_is"] = "the flat-grid launch alone; the step's two launches take avg_launch_us + scalars_launch_us"
+                    k["avg_launch_us_is"] = "the flat-grid launch alone; the step's two launches: avg_launch_us + scalars_launch_us"
                 out.append(k)
             return out
 
@@ -368,7 +382,7 @@ def main():
             return {"bound": k["bound"], "kernel": k["kernel"] + ", timed inside the CG loop", "achieved": k["achieved_GBps"],
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": k["traffic"],
                     "avg_launch_us": k["avg_launch_us"], "launches_timed": k["launches_timed"],
-                    "dispatch_span_us": k["dispatch_span_us"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "bytes_are": k["bytes_are"], "why": why}
+                    "rocprofv3_avg_us": k["rocprofv3_avg_us"], "frac_rocprofv3": k["frac_rocprofv3"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "bytes_are": k["bytes_are"], "why": why}
 
         path = h.path()
         fbytes = h.format_bytes()
@@ -379,9 +393,12 @@ def main():
         dom = max(kernels, key=lambda k: k["avg_launch_us"])
         roof = roof_of(dom, "longest kernel of the headline (N = 4 M) CG iteration")
         roof["timing"] = TIMING
-        # cross-check: the three chain figures against the iteration time of the timed region (wall clock / iterations)
-        roof["iteration_us_sum_of_kernels"] = sum(k["avg_launch_us"] for k in kernels)
+        # cross-check: the iteration time of the timed region (wall clock / iterations) against the sums of the three kernels
         roof["iteration_us_from_timed_region"] = dt / max(iters_total, 1) * 1e6
+        roof["iteration_us_sum_of_event_figures"] = sum(k["avg_launch_us"] for k in kernels)
+        roof["iteration_us_sum_of_rocprofv3_averages"] = (sum(k["rocprofv3_avg_us"] for k in kernels)
+                                                          if all(k["rocprofv3_avg_us"] is not None for k in kernels) else None)
+        roof["rocprofv3_profile"] = f"profiles/{STATS_FILE}" if prof_kernels else None
         roof["traffic_from_build"] = build_id if dom["traffic"] is not None else None
         roof["traffic_source"] = (f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, same library build)"
                                   if dom["traffic"] is not None else None)
@@ -417,7 +434,7 @@ def main():
         if coded:
             h.set_path(plain_only=True)
             try:
-                pus, pcnt, pspan = in_loop(1, h, b)
+                pus, pcnt = in_loop(1, h, b)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 _, _, pst2 = one_solve()
@@ -437,7 +454,8 @@ def main():
                                               "of the same matrix with the coded form switched off",
                     "achieved": spmv_bytes / pus / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": spmv_bytes / pus / 1e3 / HBM_PEAK_GBPS, "traffic": traffic_of("kernels", "spmv_plain", pname),
-                    "avg_launch_us": pus, "launches_timed": pcnt, "dispatch_span_us": pspan,
+                    "avg_launch_us": pus, "launches_timed": pcnt, "rocprofv3_avg_us": rocprof_us(pname),
+                    "frac_rocprofv3": None if rocprof_us(pname) is None else spmv_bytes / rocprof_us(pname) / 1e3 / HBM_PEAK_GBPS,
                     "algorithmic_bytes_per_launch": spmv_bytes, "bytes_are": "SURVEY 8d: nnz*12 + (n+1)*4 + 2n*8",
                     "why": "the north star's kernel (target >= 0.70); cg_iters_per_sec on these kernels: "
                            f"{pst2.iterations / pdt:.0f}"}
@@ -505,6 +523,8 @@ def main():
                        "step": "one full cg() solve via the public API" + (" (RowBlockCSR operand: this rank's rows)" if use_dist else ""),
                        "handle_creation_ms_outside_timed_region": handle_ms,
                        "cold_first_solve_ms": cold_first_solve_ms,
+                       "placement_probe_GBps": getattr(st, "placement_GBps", None) or None,
+                       "placement_allocations_drawn": getattr(st, "placement_tries", None) or None,
                        "rccl_ranks": world if use_dist else None,
                        "collectives": getattr(prob, "comm_kind", None) if use_dist else None},
             "spmv_standalone": spmv_standalone,

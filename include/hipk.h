@@ -82,13 +82,13 @@ typedef struct {
     double threshold;       /* the value residual_norm was compared against                         */
     double recurrence_rs;   /* last recurrence <r,r> (CG: gamma)                                    */
     double solve_ms;        /* device time of the whole solve, HIP events on `stream`               */
-    double spmv_ms_avg;     /* average duration of the kernel params.profile selects.  CG: stop event of the launch minus stop
-                               event of the launch before it on the stream (every launch of the profiled iterations carries
-                               events bound to its dispatch, hipExtLaunchKernel): the time the kernel occupies the stream; the
-                               figures of an iteration's kernels add up to the iteration time.  BiCGStab / GMRES (SpMV launches
-                               only): the launch's own stop - start.  Nothing is subtracted. */
+    double spmv_ms_avg;     /* average of stop - start over the launches params.profile selects (start/stop events bound to the
+                               dispatch, hipExtLaunchKernel); RAW: nothing subtracted.  The start stamp is taken when the dispatch
+                               is picked up, 0.6-1.5 us before its first wave when the previous kernel is still draining
+                               (csrc/hipk_solve.h has the comparison with rocprofv3's averages). */
     int64_t spmv_profiled;  /* number of SpMV launches in that average                              */
-    double dispatch_span_ms_avg; /* stop - start of the selected launches' own events (version 200: event_overhead_ms) */
+    double dispatch_span_ms_avg; /* the same figure (in the diagnostic chain mode spmv_ms_avg is stop-to-stop instead; version 200:
+                                    event_overhead_ms) */
 } hipk_stats;
 
 int hipk_version(void);
@@ -218,6 +218,12 @@ int hipk_pgmres_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, vo
 size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype);
 int hipk_pbicgstab_solve(hipk_csr_t A, const void *dinv, const void *b, void *x, void *work, size_t work_bytes,
                          const hipk_params *prm, hipk_stats *st, hipk_stream_t stream);
+/* Placement probe for systems whose vectors live in HBM (N >> 8 M rows): the memory shape of the CG direction step (reads r, p, x;
+ * writes p, x) on the three vectors, storing back the bits it loaded (safe on live data); *us_out = the fastest of `reps` (<= 16)
+ * timed passes in microseconds.  40 n bytes (fp64) per pass.  On MI355X such a step runs at one of two discrete speeds depending on
+ * where the allocation landed physically; the Python host re-draws the work allocation when it reads the slow one (_hipk.py). */
+int hipk_placement_probe(int64_t n, const void *r, void *p, void *x, int dtype, int reps, double *us_out, hipk_stream_t stream);
+
 /* ---- MATRIX-FREE operators (the reference's `_normalize_matvec` takes a callable for all three solvers, TSL:176-208).
  * hipk_op_create makes a handle WITHOUT a matrix: every product y = A x of a solve is `op(user, x_dev, y_dev)`, which enqueues
  * y = A(x) (vectors of `dtype`, n elements) on the solve's stream and returns 0.  The residual form b - A x, the row scaling of
@@ -379,7 +385,8 @@ int hipk_p2p_create(hipk_p2p_t *out, int rank, int world, size_t max_count);
 int hipk_p2p_export(hipk_p2p_t c, void *handle64);
 int hipk_p2p_connect(hipk_p2p_t c, const void *handles /* world x 64 bytes */);
 int hipk_p2p_destroy(hipk_p2p_t c);
-int hipk_p2p_error(hipk_p2p_t c); /* 1: a wait gave up (a peer never published); results of that call are void */
+int hipk_p2p_error(hipk_p2p_t c); /* 1: a wait gave up (a peer never published) since the last query -- the results of the calls in
+                                     between are void; the query clears the flag */
 int hipk_p2p_group_start(void);
 int hipk_p2p_group_end(void);
 int hipk_p2p_all_gather(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);

@@ -527,6 +527,7 @@ extern "C" int hipk_csr_set_path(hipk_csr_t h, int mode) {
     HIPK_REQUIRE(h != nullptr, HIPK_ERR_ARG, "null handle");
     HIPK_REQUIRE(mode == 0 || mode == 1, HIPK_ERR_ARG, "mode must be 0 (auto) or 1 (plain CSR kernels only)");
     h->path_override = mode;
+    h->n_plans = 0;
     return HIPK_OK;
 }
 extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
@@ -626,130 +627,155 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
             // exact tile size for the common stencil widths, run-time size otherwise
             const int tpc = a.ch / 256;
             void (*kern)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_LOOP_U(T, C, V, U)                                                                                      \
-    (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V, U> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V, U> \
-     : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V, U> : hipk_spmv_sell_loop_kernel<T, 0, C, V, U>)
-#define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
-#define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
-            kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
-            const char *tname = h->dtype == HIPK_F64 ? "double" : "float";
-            const int uw = (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8) ? h->sell_w : 0;
-            const char *uni = h->tile_ucode ? "true" : "false", *vls = h->coded_layout == 3 ? "true" : "false";
-            HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,false,%s,%s>", tname, uw, vls, uni);
-            int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
-            const int slots = h->n_cu * occ;
-            // one workgroup per reduction chunk when the chunks about fill the machine in one round
-            // (default: the chunks fill at least half of the slots; a quarter where the two-rows-per-lane kernel applies --
-            // N = 1.96 M Poisson: 28.2 -> 30.2 k CG it/s, no gain below a quarter)
-            static const bool chunked_env = getenv("HIPK_SPMV_SELL_CHUNKED") != nullptr;
-            const bool wide_ok = h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles && h->coded_layout == 2 &&
-                                 (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8);
-            const int cfac = (!chunked_env && wide_ok && h->sell_chunked == 2) ? 4 : h->sell_chunked;
-            const bool chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && cfac * a.g >= slots;
             int lgrid = 0;
-            static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
-            const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;  // read per launch: in-process A/B (tools/gmres_variants.py)
-            constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
-            // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel; fp64, most tiles uniform), mode bits compiled in for
-            // the CG loop's form, the Arnoldi step's, BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927), plain y = A x
-            auto pick_wide = [&](int st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {  // st = the kernel's WALK
-                void (*pk)(hipk_spmv_args) = nullptr;
-#define HIPK_PICK_WIDE_S(M, S) \
-    (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M, S> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M, S> : hipk_spmv_sell_wide_kernel<4, M, S>)
-#define HIPK_PICK_WIDE(M) (st == 1 ? HIPK_PICK_WIDE_S(M, 1) : HIPK_PICK_WIDE_S(M, 0))
-                pk = HIPK_PICK_WIDE(-1);
-                if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
-                if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
-                if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
-                if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
-#undef HIPK_PICK_WIDE
-#undef HIPK_PICK_WIDE_S
-                snprintf(pname, cap, "hipk_spmv_sell_wide_kernel<%d,%d,%d>", h->sell_w,  // the template arguments, as a profiler prints them
-                         (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1, st);
-                return pk;
-            };
-            // grouped walk of that kernel (WALK = 1: one workgroup per 4 consecutive tiles, tile sums through the combine kernel).
-            // Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned system, which cannot fill the chip
-            // with a workgroup per chunk and used to fall to the one-row-per-lane kernel (4 M rows with the chunk size of a
-            // 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) -- and (b) where a chunk holds 64 tiles
-            // and more (N > 16 M on one device; per CG iteration 515 -> 483 us at N = 32 M, 1106 -> 980 us at N = 64 M, where a
-            // chunk-walking workgroup fetched x three times) -- and, with four tiles per group, from 16 tiles per chunk: N = 8 M
-            // 118.8 -> 117.1 us, N = 16 M equal, a rank's block of a 2-rank weak-scaling run (4 M rows, chunk 4096) 67.6 -> 66.5;
-            // slower at N = 4 M (8 tiles per chunk, 56.6 -> 58.7: one more launch): not taken there.
-            // HIPK_SPMV_SELL_STRIDED=0|1 forces (read per launch: in-process A/B, tools/walk_probe.py)
-            bool strided = false;
-            if (wide_ok && !no_wide && h->sell_chunked != 0) {
-                const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
-                if (se ? atoi(se) != 0 : tpc >= (chunked ? 16 : 32)) {
-                    char pname[96];
-                    kern = pick_wide(1, pname, sizeof(pname));
-                    lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
-                    strided = true;
-                    HIPK_NOTE_KERNEL("%s", pname);
-                }
-            }
-            // the same walk for the offset-coded form (value planes: variable-coefficient stencils), on the one-row-per-lane chunk
-            // kernel with a grid of groups (hipk_spmv_args::group_tiles), from 32 tiles per chunk (N >= 16 M): CG per iteration
-            // 336 -> 327 us at N = 16 M, 731 -> 704 at 32 M, 1573 -> 1418-1503 at 64 M (SpMV 873 -> 716 us).  NOT for pair codes
-            // in fp32 storage, where the two-tiles-per-trip chunk kernel stays ahead (N = 64 M: 539 vs 562 us per iteration); the
-            // switch forces it for any layout (tests, A/B)
-            a.group_tiles = 0;
-            if (!strided && h->sell_chunked != 0) {
-                const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
-                if (se ? atoi(se) != 0 : (h->coded_layout == 3 && tpc >= 32)) {
-                    kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
-                    a.group_tiles = HIPK_SELL_GROUP;
-                    lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
-                    strided = true;
-                    HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>/groups", tname, uw, vls, uni);
-                }
-            }
-            if (strided) {
-                // kern, lgrid: set above
-            } else if (chunked) {
-                kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
-                lgrid = hipk_xcd_grid(a.g);
-                HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>", tname, uw, vls, uni);
-                char pname[96];
-                // pair codes with an exact tile size: two tiles per loop trip (hipk_spmv_sell_pair_kernel)
-                static const bool no_pair = getenv("HIPK_SPMV_SELL_NO_PAIR") != nullptr;
-                if (!no_pair && h->coded_layout == 2 && (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8)) {
-#define HIPK_PICK_PAIR_U(T, U) \
-    (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
-#define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
-                    void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
-                    int pmode = -1;
-                    // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
-                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && (a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode)
-                        pmode = a.mode;
-                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !no_mode)
-                        pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
-                                           : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
-                    // the Arnoldi step's form (w = A v with ||w||^2, TSL:351-352)
-                    if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_YY && !no_mode)
-                        pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
-                                           : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
-                    snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
-                    if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles)
-                        pk = pick_wide(0, pname, sizeof(pname));
-                    int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
-                        (pocc * h->n_cu >= a.g || pocc >= occ)) {
-                        kern = pk;
+            bool chunked = false, strided = false;
+            static const bool no_plan_cache = getenv("HIPK_SPMV_NO_PLAN_CACHE") != nullptr;
+            const hipk_spmv_plan *pl = nullptr;
+            for (int i = 0; i < h->n_plans && !no_plan_cache; ++i)
+                if (h->plans[i].mode == a.mode && h->plans[i].ch == a.ch && h->plans[i].g == a.g) pl = &h->plans[i];
+            if (pl != nullptr) {
+                kern = (void (*)(hipk_spmv_args))pl->kern;
+                lgrid = pl->lgrid;
+                chunked = pl->chunked;
+                strided = pl->strided;
+                a.group_tiles = pl->group_tiles;
+                memcpy(g_spmv_kernel, pl->name, sizeof(g_spmv_kernel));
+            } else {
+    #define HIPK_PICK_LOOP_U(T, C, V, U)                                                                                      \
+        (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V, U> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V, U> \
+         : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V, U> : hipk_spmv_sell_loop_kernel<T, 0, C, V, U>)
+    #define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
+    #define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
+                kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
+                const char *tname = h->dtype == HIPK_F64 ? "double" : "float";
+                const int uw = (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8) ? h->sell_w : 0;
+                const char *uni = h->tile_ucode ? "true" : "false", *vls = h->coded_layout == 3 ? "true" : "false";
+                HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,false,%s,%s>", tname, uw, vls, uni);
+                int occ = 0;  // resident workgroups per CU of this instantiation (register bound)
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, HIPK_THREADS, 0) != hipSuccess || occ < 1) occ = 4;
+                const int slots = h->n_cu * occ;
+                // one workgroup per reduction chunk when the chunks about fill the machine in one round
+                // (default: the chunks fill at least half of the slots; a quarter where the two-rows-per-lane kernel applies --
+                // N = 1.96 M Poisson: 28.2 -> 30.2 k CG it/s, no gain below a quarter)
+                static const bool chunked_env = getenv("HIPK_SPMV_SELL_CHUNKED") != nullptr;
+                const bool wide_ok = h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles && h->coded_layout == 2 &&
+                                     (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8);
+                const int cfac = (!chunked_env && wide_ok && h->sell_chunked == 2) ? 4 : h->sell_chunked;
+                chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && cfac * a.g >= slots;
+                static const bool no_mode = getenv("HIPK_SPMV_SELL_NO_MODE") != nullptr;
+                const bool no_wide = getenv("HIPK_SPMV_SELL_NO_WIDE") != nullptr;  // read per launch: in-process A/B (tools/gmres_variants.py)
+                constexpr int both = HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY;
+                // uniform tiles two rows per lane (hipk_spmv_sell_wide_kernel; fp64, most tiles uniform), mode bits compiled in for
+                // the CG loop's form, the Arnoldi step's, BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927), plain y = A x
+                auto pick_wide = [&](int st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {  // st = the kernel's WALK
+                    void (*pk)(hipk_spmv_args) = nullptr;
+    #define HIPK_PICK_WIDE_S(M, S) \
+        (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M, S> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M, S> : hipk_spmv_sell_wide_kernel<4, M, S>)
+    #define HIPK_PICK_WIDE(M) (st == 1 ? HIPK_PICK_WIDE_S(M, 1) : HIPK_PICK_WIDE_S(M, 0))
+                    pk = HIPK_PICK_WIDE(-1);
+                    if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
+                    if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
+                    if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
+                    if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
+    #undef HIPK_PICK_WIDE
+    #undef HIPK_PICK_WIDE_S
+                    snprintf(pname, cap, "hipk_spmv_sell_wide_kernel<%d,%d,%d>", h->sell_w,  // the template arguments, as a profiler prints them
+                             (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1, st);
+                    return pk;
+                };
+                // grouped walk of that kernel (WALK = 1: one workgroup per 4 consecutive tiles, tile sums through the combine kernel).
+                // Taken (a) for a row block of FEW chunks of many tiles -- a rank of a row-partitioned system, which cannot fill the chip
+                // with a workgroup per chunk and used to fall to the one-row-per-lane kernel (4 M rows with the chunk size of a
+                // 4- / 8-rank weak-scaling run: 70.0 -> 65.4 / 72.5 -> 68.2 us per CG iteration) -- and (b) where a chunk holds 64 tiles
+                // and more (N > 16 M on one device; per CG iteration 515 -> 483 us at N = 32 M, 1106 -> 980 us at N = 64 M, where a
+                // chunk-walking workgroup fetched x three times) -- and, with four tiles per group, from 16 tiles per chunk: N = 8 M
+                // 118.8 -> 117.1 us, N = 16 M equal, a rank's block of a 2-rank weak-scaling run (4 M rows, chunk 4096) 67.6 -> 66.5;
+                // slower at N = 4 M (8 tiles per chunk, 56.6 -> 58.7: one more launch): not taken there.
+                // HIPK_SPMV_SELL_STRIDED=0|1 forces (read per launch: in-process A/B, tools/walk_probe.py)
+                if (wide_ok && !no_wide && h->sell_chunked != 0) {
+                    const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
+                    if (se ? atoi(se) != 0 : tpc >= (chunked ? 16 : 32)) {
+                        char pname[96];
+                        kern = pick_wide(1, pname, sizeof(pname));
+                        lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
+                        strided = true;
                         HIPK_NOTE_KERNEL("%s", pname);
                     }
-#undef HIPK_PICK_PAIR
-#undef HIPK_PICK_PAIR_U
                 }
-            } else {
-                lgrid = slots * h->sell_loop;
-                if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
-                lgrid = ((lgrid + 7) >> 3) << 3;
+                // the same walk for the offset-coded form (value planes: variable-coefficient stencils), on the one-row-per-lane chunk
+                // kernel with a grid of groups (hipk_spmv_args::group_tiles), from 32 tiles per chunk (N >= 16 M): CG per iteration
+                // 336 -> 327 us at N = 16 M, 731 -> 704 at 32 M, 1573 -> 1418-1503 at 64 M (SpMV 873 -> 716 us).  NOT for pair codes
+                // in fp32 storage, where the two-tiles-per-trip chunk kernel stays ahead (N = 64 M: 539 vs 562 us per iteration); the
+                // switch forces it for any layout (tests, A/B)
+                a.group_tiles = 0;
+                if (!strided && h->sell_chunked != 0) {
+                    const char *se = getenv("HIPK_SPMV_SELL_STRIDED");
+                    if (se ? atoi(se) != 0 : (h->coded_layout == 3 && tpc >= 32)) {
+                        kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
+                        a.group_tiles = HIPK_SELL_GROUP;
+                        lgrid = hipk_xcd_grid((ntiles + HIPK_SELL_GROUP - 1) / HIPK_SELL_GROUP);
+                        strided = true;
+                        HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>/groups", tname, uw, vls, uni);
+                    }
+                }
+                if (strided) {
+                    // kern, lgrid: set above
+                } else if (chunked) {
+                    kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, true) : HIPK_PICK_LOOP(float, true);
+                    lgrid = hipk_xcd_grid(a.g);
+                    HIPK_NOTE_KERNEL("hipk_spmv_sell_loop_kernel<%s,%d,true,%s,%s>", tname, uw, vls, uni);
+                    char pname[96];
+                    // pair codes with an exact tile size: two tiles per loop trip (hipk_spmv_sell_pair_kernel)
+                    static const bool no_pair = getenv("HIPK_SPMV_SELL_NO_PAIR") != nullptr;
+                    if (!no_pair && h->coded_layout == 2 && (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8)) {
+    #define HIPK_PICK_PAIR_U(T, U) \
+        (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
+    #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
+                        void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
+                        int pmode = -1;
+                        // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
+                        if (h->dtype == HIPK_F64 && h->sell_w == 5 && (a.mode == HIPK_SPMV_DOT_W || a.mode == HIPK_SPMV_DOT_YY) && !no_mode)
+                            pmode = a.mode;
+                        if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_W && !no_mode)
+                            pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_W>
+                                               : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_W>;
+                        // the Arnoldi step's form (w = A v with ||w||^2, TSL:351-352)
+                        if (h->dtype == HIPK_F64 && h->sell_w == 5 && a.mode == HIPK_SPMV_DOT_YY && !no_mode)
+                            pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
+                                               : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
+                        snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
+                        if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles)
+                            pk = pick_wide(0, pname, sizeof(pname));
+                        int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&
+                            (pocc * h->n_cu >= a.g || pocc >= occ)) {
+                            kern = pk;
+                            HIPK_NOTE_KERNEL("%s", pname);
+                        }
+    #undef HIPK_PICK_PAIR
+    #undef HIPK_PICK_PAIR_U
+                    }
+                } else {
+                    lgrid = slots * h->sell_loop;
+                    if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
+                    lgrid = ((lgrid + 7) >> 3) << 3;
+                }
+    #undef HIPK_PICK_LOOP
+    #undef HIPK_PICK_LOOP_V
+    #undef HIPK_PICK_LOOP_U
+                if (!no_plan_cache && h->n_plans < (int)(sizeof(h->plans) / sizeof(h->plans[0]))) {
+                    hipk_spmv_plan &np = h->plans[h->n_plans++];
+                    np.mode = a.mode;
+                    np.ch = a.ch;
+                    np.g = a.g;
+                    np.kern = (void *)kern;
+                    np.lgrid = lgrid;
+                    np.group_tiles = a.group_tiles;
+                    np.chunked = chunked;
+                    np.strided = strided;
+                    memcpy(np.name, g_spmv_kernel, sizeof(np.name));
+                }
             }
-#undef HIPK_PICK_LOOP
-#undef HIPK_PICK_LOOP_V
-#undef HIPK_PICK_LOOP_U
             hipk_launch_timed(prof, HIPK_K_SPMV, kern, lgrid, HIPK_THREADS, 0, stream, a);
             if ((!chunked || strided) && !a.skip_combine && (a.mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
                 hipk_launch_timed(prof, HIPK_K_AUX, hipk_tile_combine_kernel, (a.g + 3) / 4, HIPK_THREADS, 0, stream, (a.mode & HIPK_SPMV_DOT_W) ? a.tpart0 : nullptr, (a.mode & HIPK_SPMV_DOT_YY) ? a.tpart1 : nullptr,

@@ -258,6 +258,89 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_flat_kernel(in
     }
 }
 
+// ---- placement probe (include/hipk.h: hipk_placement_probe).  At N = 64 M the direction step above runs at one of two discrete
+// speeds -- 5.85 or 4.9 TB/s -- depending on where the three vectors landed PHYSICALLY (profiles/r02_axpy_realloc_64m.txt: the same
+// kernel at the same virtual addresses, re-allocated; vectors in separate allocations were slow every time, vectors in ONE
+// allocation fast in about half of the draws).  This kernel has the step's memory shape (reads r, p, x non-temporal, writes p and
+// x) and stores back the bits it loaded, so it can run on live vectors; the host times it and re-draws the allocation when it
+// reads the slow level.
+__device__ __forceinline__ bool hipk_value_bits_eq(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+__device__ __forceinline__ bool hipk_value_bits_eq(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_probe3_kernel(int64_t n, const T *__restrict__ r, T *__restrict__ p, T *__restrict__ x,
+                                                                   T never) {
+    constexpr int VEC = hipk_vec<T>::VEC;
+    constexpr int STEPS = HIPK_BASE_CHUNK / (VEC * HIPK_THREADS);
+    const int64_t base = (int64_t)blockIdx.x * HIPK_BASE_CHUNK + (int64_t)VEC * threadIdx.x;
+    T rv[STEPS][VEC], pv[STEPS][VEC], xv[STEPS][VEC];
+    int nvs[STEPS];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const int64_t i = base + (int64_t)k * VEC * HIPK_THREADS;
+        nvs[k] = (i < n) ? ((n - i < VEC) ? (int)(n - i) : VEC) : 0;
+        if (nvs[k] > 0) {
+            hipk_ld_nt_vec<T>(r, i, nvs[k], rv[k]);
+            hipk_ld_nt_vec<T>((const T *)p, i, nvs[k], pv[k]);
+            hipk_ld_nt_vec<T>((const T *)x, i, nvs[k], xv[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        if (nvs[k] > 0) {
+            const int64_t i = base + (int64_t)k * VEC * HIPK_THREADS;
+            // `never` is a NaN with a payload no computation produces: the comparison keeps the loads of r alive, the stores put
+            // back what was loaded
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (hipk_value_bits_eq(rv[k][e], never)) pv[k][e] = rv[k][e];
+            hipk_st_nt_vec<T>(x, i, nvs[k], xv[k]);
+            hipk_st<T>(p, i, nvs[k], pv[k]);
+        }
+    }
+}
+
+extern "C" int hipk_placement_probe(int64_t n, const void *r, void *p, void *x, int dtype, int reps, double *us_out,
+                                    hipk_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPK_REQUIRE(n > 0 && r && p && x && us_out, HIPK_ERR_ARG, "null argument");
+    HIPK_REQUIRE(dtype == HIPK_F64 || dtype == HIPK_F32, HIPK_ERR_UNSUPPORTED, "dtype must be f32/f64");
+    HIPK_REQUIRE(hipk_aligned16(r) && hipk_aligned16(p) && hipk_aligned16(x), HIPK_ERR_ALIGN, "vectors must be 16-byte aligned");
+    if (reps < 1) reps = 1;
+    if (reps > 16) reps = 16;
+    const unsigned grid = (unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK);
+    hipk_event_pair ev[16];
+    for (int i = 0; i < reps; ++i) HIPK_CHECK_HIP(ev[i].create());
+    // one untimed pass (first touch, TLB), then `reps` passes each with events bound to its dispatch (hipk_solve.h)
+    for (int i = -1; i < reps; ++i) {
+        void *argv[5];
+        double nan64;
+        float nan32;
+        const unsigned long long b64 = 0x7FF8DEADBEEF1234ull;
+        const unsigned b32 = 0x7FC0BEEFu;
+        memcpy(&nan64, &b64, 8);
+        memcpy(&nan32, &b32, 4);
+        argv[0] = (void *)&n;
+        argv[1] = (void *)&r;
+        argv[2] = (void *)&p;
+        argv[3] = (void *)&x;
+        argv[4] = dtype == HIPK_F64 ? (void *)&nan64 : (void *)&nan32;
+        const void *fn = dtype == HIPK_F64 ? (const void *)hipk_probe3_kernel<double> : (const void *)hipk_probe3_kernel<float>;
+        if (i < 0)
+            HIPK_CHECK_HIP(hipLaunchKernel(fn, dim3(grid), dim3(HIPK_THREADS), argv, 0, stream));
+        else
+            HIPK_CHECK_HIP(hipExtLaunchKernel(fn, dim3(grid), dim3(HIPK_THREADS), argv, 0, stream, ev[i].a, ev[i].b, 0));
+    }
+    HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+    double best = 1e300;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        HIPK_CHECK_HIP(hipEventElapsedTime(&ms, ev[i].a, ev[i].b));
+        if ((double)ms * 1e3 < best) best = (double)ms * 1e3;
+    }
+    *us_out = best;
+    return HIPK_OK;
+}
+
 // x += alpha p alone (TSL:847): the row-partitioned solver runs it on a side stream while the <r,r> / halo collective of the
 // iteration is in flight; alpha from the same partials and the same gamma as the update and direction kernels (same bits)
 template <typename T>
@@ -582,7 +665,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
 
     hipk_event_pair whole;
     HIPK_CHECK_HIP(whole.create());
-    hipk_spmv_profiler prof(prm->profile, /*chain=*/true);   // every launch of the profiled iterations is timed (hipk_solve.h)
+    hipk_spmv_profiler prof(prm->profile);   // only launches of the selected kind carry events (hipk_solve.h: chain mode perturbs)
     HIPK_CHECK_HIP(hipEventRecord(whole.a, stream));
 
     hipk_spmv_args sa;

@@ -72,6 +72,18 @@ static inline hipk_geom hipk_make_geom(int64_t n) {
 }
 
 // ---------------------------------------------------------------- CSR handle
+// what hipk_launch_spmv resolved for one (mode, chunk size, chunk count) of a sliced-ELL handle: kernel instantiation, grid, walk.
+// Resolved once (environment switches, two occupancy queries, the kernel's name) and reused by every later launch (ADVICE r2:
+// that host work sat on the per-iteration path of the launch-bound sizes); hipk_csr_set_path drops the plans,
+// HIPK_SPMV_NO_PLAN_CACHE=1 resolves per launch again (in-process A/B probes that flip the switches between launches)
+struct hipk_spmv_plan {
+    int mode, ch, g;
+    void *kern;
+    int lgrid, group_tiles;
+    bool chunked, strided;
+    char name[96];
+};
+
 struct hipk_csr_s {
     int64_t n_rows, n_cols, nnz;
     int dtype;        // hipk_dtype
@@ -110,6 +122,8 @@ struct hipk_csr_s {
     // matrix-free operator (hipk_op_create): every product is op_cb(op_user, x, y) + an epilogue kernel; no CSR arrays
     int (*op_cb)(void *user, const void *x_dev, void *y_dev);
     void *op_user;
+    mutable hipk_spmv_plan plans[12];
+    mutable int n_plans;
 };
 
 #ifdef __HIPCC__

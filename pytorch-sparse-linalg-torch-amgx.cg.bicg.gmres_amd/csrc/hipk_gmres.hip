@@ -85,6 +85,8 @@ struct hipk_gm_scal {
                             // host finishes this cycle (general solve, TSL:424-428)
     int rep_breakdown;      // a breakdown (TSL:387) happened in one of the launch's cycles
     hipk_gm_view v;         // see above (set by hipk_gm_cycle_init_kernel)
+    double vnorm;           // hipk_gm_hcol_kernel -> hipk_gm_scale_kernel: ||q|| of the step ...
+    int32_t vuse, pad3;     // ... and whether it passed the threshold (else v_{k+1} = 0)
 };
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
@@ -707,6 +709,112 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_normalize_kernel(
             if (stop) scal->stop_step = k + 1;
         }
     }
+}
+
+// Large systems: the normalise step as TWO launches.  hipk_gm_normalize_kernel above makes every workgroup fold the 2 x g chunk
+// partials (31 KB from L2 at N = 4 M) before it may scale its 16 KB of w: 64 MB in 16.8 us = 3.8 TB/s, 0.48 of peak, the kernel of
+// the GMRES cycle furthest below its roofline.  Here ONE workgroup folds them once, takes the CGS2 guard, thresholds
+// the norm and does the H-column / Givens bookkeeping (hipk_gm_hcol_kernel: the same folds, the same bits); a flat grid then
+// scales w by the published norm with nothing in front of its loads (hipk_gm_scale_kernel).
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_hcol_kernel(int g, hipk_gm_scal *__restrict__ scal, int k,
+                                                                    const double *__restrict__ part_qq,
+                                                                    const double *__restrict__ part_ww, double eps, int guard,
+                                                                    int f32) {
+    if (k >= scal->stop_step) return;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    double qq, ww;
+    hipk_reduce_parts2(part_qq, part_ww, g, qq, ww, sbuf);
+    const hipk_gm_view v = scal->v;
+    if (guard) {   // speculation miss: see hipk_gm_normalize_kernel
+        double qnorm;
+        if (hipk_gm_want_pass2(scal, k, qq, eps, &qnorm, v.rvec)) {
+            if (threadIdx.x == 0) {
+                scal->redo = 1;
+                scal->redo_step = k;
+                scal->stop_step = k;   // the scale kernel of this step (and everything after it) returns: nothing is stored
+            }
+            return;
+        }
+    }
+    double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
+    double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
+    if (!(norm0 > eps)) norm0 = 0.0;
+    const double thr = eps * norm0;
+    const bool use = norm1 > thr;
+    double *H = v.H;
+    const int ldh = v.ldh;
+    const int t = threadIdx.x;
+    __shared__ double hc[HIPK_GM_MAXM_BIG + 2], gvs[2 * (HIPK_GM_MAXM_BIG + 1)];
+    if (t <= k) {
+        const double rj = v.rvec[t];
+        H[t * ldh + k] = rj;
+        hc[t] = rj;
+    }
+    if (scal->incremental)
+        for (int i = t; i < 2 * k; i += HIPK_THREADS) gvs[i] = v.gv[i];
+    __syncthreads();
+    if (t == 0) {
+        scal->vnorm = f32 ? (double)(float)norm1 : norm1;   // the divisor the scale kernel uses: (T)norm1
+        scal->vuse = use ? 1 : 0;
+        if (!use) norm1 = 0.0;
+        H[(k + 1) * ldh + k] = norm1;
+        hc[k + 1] = norm1;
+        scal->steps_done = k + 1;
+        bool stop = false;
+        if (norm1 == 0.0) {  // TSL:387
+            scal->breakdown = 1;
+            stop = true;
+        }
+        if (scal->incremental) {
+            for (int i = 0; i < k; ++i) {
+                const double cs = gvs[2 * i], sn = gvs[2 * i + 1];
+                const double p0 = cs * hc[i], p1 = sn * hc[i + 1];
+                const double t0 = p0 - p1;
+                const double p2 = sn * hc[i], p3 = cs * hc[i + 1];
+                hc[i + 1] = p2 + p3;
+                hc[i] = t0;
+            }
+            double cs, sn;
+            hipk_givens(hc[k], hc[k + 1], cs, sn);
+            v.gv[2 * k] = cs;
+            v.gv[2 * k + 1] = sn;
+            {
+                const double p0 = cs * hc[k], p1 = sn * hc[k + 1];
+                hc[k] = p0 - p1;
+            }
+            hc[k + 1] = 0.0;
+            for (int j = 0; j <= k; ++j) v.R[j * ldh + k] = hc[j];
+            double *bv = v.beta_vec;
+            const double p0 = cs * bv[k], p1 = sn * bv[k + 1];
+            const double t0 = p0 - p1;
+            const double p2 = sn * bv[k], p3 = cs * bv[k + 1];
+            bv[k + 1] = p2 + p3;
+            bv[k] = t0;
+            const double err = fabs(bv[k + 1]);
+            scal->err = err;
+            if (!(err > scal->ptol)) stop = true;  // TSL:591
+        }
+        if (stop) scal->stop_step = k + 1;
+    }
+}
+
+// v_{k+1} = q / ||q|| (zero when the norm did not pass the threshold): flat grid, 2048 elements per workgroup, w requested before
+// the stop word and the norm are read
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_scale_kernel(int64_t n, const hipk_gm_scal *__restrict__ scal, int k,
+                                                                     T *__restrict__ w) {
+    hipk_pre<T, 1> pre;
+    pre.issue(n, HIPK_BASE_CHUNK, blockIdx.x, {(const T *)w});
+    if (k >= scal->stop_step) return;
+    const T nrm = (T)scal->vnorm;
+    const bool use = scal->vuse != 0;
+    pre.run([&](int64_t i, int nv, T(&v)[1][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T wv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wv[e] = use ? v[0][e] / nrm : (T)0;
+        hipk_st<T>(w, i, nv, wv);
+    });
 }
 
 // =====================================================================================================================
@@ -2179,7 +2287,13 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     bool cyc_local = !lds_spread && !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     const bool stream_k = !small && (m > HIPK_GM_MAXM || !getenv("HIPK_GMRES_NO_STREAM"));  // large systems: hipk_gm_*_stream_kernel
-    const bool md_wide = env_int("HIPK_GM_MD_WIDE", 1) != 0;   // multi-dot with up to 32 columns per workgroup (w read once), 0: groups of 8
+    // multi-dot with up to 32 columns per workgroup (w read ONCE per step; 0, the default: groups of 8, w re-read per group).  Same
+    // box, alternating, N = 4 M (profiles/r03_gmres_history.md): GMRES(30) 6.67-6.70 vs 6.64-6.66 ms per cycle, GMRES(50) 16.50 vs
+    // 16.38, GMRES(100) 60.1-60.2 vs 59.5-59.8 -- the re-reads of w are Infinity-Cache hits (FETCH_SIZE counts them: the 1.15 x of
+    // VERDICT r2), and 113 VGPRs (4 workgroups per CU) cost more than they did.  Kept for the counters, not taken.
+    const bool md_wide = env_int("HIPK_GM_MD_WIDE", 0) != 0;
+    // normalise step as hipk_gm_hcol_kernel + hipk_gm_scale_kernel (HIPK_GM_SPLIT_NORM=0: the one-kernel form)
+    const bool split_norm = !small && env_int("HIPK_GM_SPLIT_NORM", 1) != 0;
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
     // large systems: second-pass launches only at the steps where a second CGS pass is expected (step 0, then every step
     // that ever asked for one in this solve); a miss is caught on the device and the cycle re-enqueued from that step
@@ -2298,9 +2412,14 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                                                                                            part_qq, part_md, gm.g);
                 }
             }
-            hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(
-                n, gm.ch, gm.g, scal, k, w, part_qq, (small && !ext) ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t,
-                (small && !ext) ? nt : 0, npass == 1 ? 1 : 0);
+            if (split_norm) {   // large systems: one workgroup for the scalars, a flat grid for the scaling (see hipk_gm_hcol_kernel)
+                hipk_gm_hcol_kernel<<<1, HIPK_THREADS, 0, stream>>>(gm.g, scal, k, part_qq, part_ww, eps_t, npass == 1 ? 1 : 0,
+                                                                   sizeof(T) == 4 ? 1 : 0);
+                hipk_gm_scale_kernel<T><<<(unsigned)((n + HIPK_BASE_CHUNK - 1) / HIPK_BASE_CHUNK), HIPK_THREADS, 0, stream>>>(n, scal, k, w);
+            } else
+                hipk_gm_normalize_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(
+                    n, gm.ch, gm.g, scal, k, w, part_qq, (small && !ext) ? A->tile_part + 4 * (size_t)nt : part_ww, eps_t,
+                    (small && !ext) ? nt : 0, npass == 1 ? 1 : 0);
         }
         if (rc != HIPK_OK) break;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hs, scal, sizeof(*hs), hipMemcpyDeviceToHost, stream) != hipSuccess ||

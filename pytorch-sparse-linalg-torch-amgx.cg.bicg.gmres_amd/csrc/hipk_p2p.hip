@@ -150,11 +150,14 @@ extern "C" int hipk_p2p_destroy(hipk_p2p_t c) {
     return HIPK_OK;
 }
 
-// 1 when a collect block gave up waiting since the last query (the results of that call are garbage)
+// 1 when a collect block gave up waiting since the LAST QUERY (the results of the calls in between are garbage).  Reading clears
+// the flag (it used to stay set, so one timed-out exchange failed every later solve on the same mailboxes); the
+// hipMemcpy / hipMemset pair runs on the null stream, i.e. after everything enqueued so far.
 extern "C" int hipk_p2p_error(hipk_p2p_t c) {
     if (!c) return 0;
     int v = 0;
     if (hipMemcpy(&v, c->err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (v != 0 && hipMemset(c->err_dev, 0, sizeof(int)) != hipSuccess) return 1;
     return v;
 }
 

@@ -24,14 +24,17 @@ struct hipk_event_pair {
 };
 
 // Kernel durations for bench.py (params.profile = the KIND of kernel to report: 1 SpMV, 2 CG update, 3 CG direction, 4 the
-// scalars launch of the flat direction step).  Timed launches go through hipExtLaunchKernel with a start and a stop event bound
-// to that dispatch; nothing is calibrated or subtracted (until version 200 hipEventRecord pairs bracketed the launches and an
-// estimated pair overhead of 3.4-3.8 us was subtracted: 0.876 printed where the profiler said 0.846).  Two figures per kind:
-//  * SPAN  = stop - start of the launch's own events;
-//  * CHAIN (CG loop: EVERY launch of the profiled iterations is timed) = stop of the launch - stop of the launch before it on the
-//    stream: the time the kernel occupies the stream, dispatch hand-over included.  The chain figures of an iteration's kernels add
-//    up to the iteration time by construction, and they are what agrees with `rocprofv3 --kernel-trace` averages (whose sum over
-//    the iteration's kernels also equals the measured iteration time); the span starts 0.6-1.5 us earlier (5 us under the tracer).
+// scalars launch of the flat direction step).  The selected launches go through hipExtLaunchKernel with a start and a stop event
+// bound to that dispatch; the figure is stop - start, RAW: nothing is calibrated or subtracted (until version 200 hipEventRecord
+// pairs bracketed the launches and an estimated pair overhead of 3.4-3.8 us was subtracted: 0.876 printed where the profiler said
+// 0.846).  What it measures (same box, N = 4 M CG loop, against `rocprofv3 --kernel-trace` averages of the same command):
+//   only the selected kind timed (the default)   direction 25.2 / update 17.5 / coded SpMV 16.5 us   profiler 23.7 / 16.0 / 15.9
+//   every launch of the iteration timed (chain)  23.2 / 15.5 / 14.7 us, and the iteration stretches from 56.1 to 69.2 us
+// i.e. the start stamp is taken when the dispatch is picked up, up to ~1.5 us before its first wave runs when the previous kernel
+// is still draining; with events on every dispatch the kernels no longer overlap their neighbours' tails (shorter spans, 4-5 us of
+// idle between them).  The raw single-kind figure is therefore CONSERVATIVE by 0.6-1.5 us (4-9 % on these 16-25 us kernels, < 1 %
+// on the N = 64 M ones); bench.py prints it and, beside it, the rocprofv3 average of the committed profile of the same build.
+// `chain` (all launches timed; stats.spmv_ms_avg = stop-to-stop) is kept for such experiments only.
 struct hipk_spmv_profiler {
     static constexpr int kMax = 256;        // launches of the selected kind
     static constexpr int kSlots = 5 * kMax; // all timed launches (chain mode: a CG iteration has 3-4)

@@ -25,7 +25,7 @@ GMRES_BATCHED, GMRES_INCREMENTAL = 0, 1
 
 # every symbol include/hipk.h declares (tests/test_abi.py checks the export list)
 SYMBOLS = [
-    "hipk_version", "hipk_build_id", "hipk_op_create", "hipk_last_error", "hipk_device_count",
+    "hipk_version", "hipk_build_id", "hipk_op_create", "hipk_placement_probe", "hipk_last_error", "hipk_device_count",
     "hipk_csr_create", "hipk_csr_destroy", "hipk_csr_rows", "hipk_csr_nnz", "hipk_csr_spmv_bytes",
     "hipk_csr_spmv_path", "hipk_last_spmv_kernel", "hipk_csr_set_path", "hipk_csr_format_bytes",
     "hipk_csr_transpose_work_bytes", "hipk_csr_transpose",
@@ -97,6 +97,8 @@ class SolveStats:
     spmv_ms_avg: float
     spmv_profiled: int
     dispatch_span_ms_avg: float = 0.0
+    placement_GBps: float = 0.0    # large systems: what the placement probe read on the allocation the solve ran in (0: not probed)
+    placement_tries: int = 0       #   allocations drawn (1: the first one was at the fast level or probing is off)
 
 
 class HipkError(RuntimeError):
@@ -163,6 +165,7 @@ def lib():
     L.hipk_csr_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, i32, vp, i32, vp]
     L.hipk_csr_destroy.argtypes = [vp]
     L.hipk_op_create.argtypes = [ctypes.POINTER(vp), i64, i32, OP_FN, vp, vp]
+    L.hipk_placement_probe.argtypes = [i64, vp, vp, vp, i32, i32, ctypes.POINTER(ctypes.c_double), vp]
     for f in (L.hipk_csr_rows, L.hipk_csr_nnz, L.hipk_csr_spmv_bytes, L.hipk_csr_format_bytes):
         f.argtypes = [vp]
         f.restype = i64
@@ -542,18 +545,64 @@ def block_jacobi_apply(binv: torch.Tensor, block_size: int, v: torch.Tensor) -> 
 
 
 # -------------------------------------------------------------------- whole solves
+# Systems whose vectors live in HBM (a vector beyond the 256 MiB Infinity Cache): the CG vector kernels run at one of two discrete
+# speeds depending on where r, p and x landed PHYSICALLY -- vectors in separate allocations were at the slow level every time,
+# vectors in ONE allocation at the fast one in about half of the draws (profiles/r02_axpy_realloc_64m.txt).  So x joins the work
+# buffer's allocation, a probe with the direction step's memory shape (hipk_placement_probe, ~0.5 ms per pass at N = 64 M) reads the
+# level, and a slow draw is replaced by a fresh allocation (the earlier ones are held until the choice is made, so that the
+# allocator has to map new pages), at most HIPK_PLACEMENT_TRIES (4) in all; the best one is kept.  HIPK_PLACEMENT_PROBE=0: off.
+_PLACEMENT_MIN_VECTOR_BYTES = 256 << 20
+_PLACEMENT_FAST_GBPS = 5400.0   # between the two levels (5.85 and 4.9 TB/s on the 40 n bytes of a pass)
+
+
+def _placed_cg_work(h, x: torch.Tensor, work_bytes: int):
+    """(buffer, work view, x view, probe GB/s, tries) for a large CG solve, or None when the system is small / probing is off."""
+    item = x.element_size()
+    n = x.numel()
+    if n * item <= _PLACEMENT_MIN_VECTOR_BYTES or os.environ.get("HIPK_PLACEMENT_PROBE", "1") == "0" or hasattr(h, "regions"):
+        return None
+    L = lib()
+    vec = (n * item + 255) // 256 * 256
+    tries = max(1, int(os.environ.get("HIPK_PLACEMENT_TRIES", "4")))
+    r_off = 256 + int(L.hipk_scratch_bytes())          # hipk_cg_solve's layout: header, partials, r, p, Ap (csrc/hipk_cg.hip)
+    held, best = [], None
+    us = ctypes.c_double()
+    for t in range(tries):
+        buf = torch.empty(work_bytes + vec, dtype=torch.uint8, device=x.device)
+        held.append(buf)
+        xin = buf[work_bytes:work_bytes + n * item].view(x.dtype)
+        xin.copy_(x)
+        _check(L.hipk_placement_probe(n, buf.data_ptr() + r_off, buf.data_ptr() + r_off + vec, xin.data_ptr(), _dtype_code(x.dtype),
+                                      3, ctypes.byref(us), _stream(x.device)), "hipk_placement_probe")
+        rate = 5 * n * item / us.value / 1e3
+        if best is None or rate > best[3]:
+            best = (buf, buf[:work_bytes], xin, rate, t + 1)
+        if rate >= _PLACEMENT_FAST_GBPS:
+            break
+    return best[0], best[1], best[2], best[3], len(held)
+
+
 def _solve(method: str, h: CsrHandle, b: torch.Tensor, x: torch.Tensor, prm: Params, work_bytes: int) -> SolveStats:
     L = lib()
-    work = torch.empty(work_bytes, dtype=torch.uint8, device=h.device)
+    placed = None
+    with torch.cuda.device(h.device):
+        if method == "cg":
+            placed = _placed_cg_work(h, x, work_bytes)
+    if placed is not None:
+        _buf, work, x_run, probe_gbps, probe_tries = placed
+    else:
+        work, x_run, probe_gbps, probe_tries = torch.empty(work_bytes, dtype=torch.uint8, device=h.device), x, 0.0, 0
     if hasattr(h, "regions"):   # OpHandle: the operator callback resolves raw pointers against these tensors
         h.regions.append(work)
     st = Stats()
     fn = getattr(L, f"hipk_{method}_solve")
     with h._lock, torch.cuda.device(h.device):
-        rc = fn(h.ptr, b.data_ptr(), x.data_ptr(), work.data_ptr(), work_bytes, ctypes.byref(prm), ctypes.byref(st),
+        rc = fn(h.ptr, b.data_ptr(), x_run.data_ptr(), work.data_ptr(), work_bytes, ctypes.byref(prm), ctypes.byref(st),
                 _stream(h.device))
     _check(rc, f"hipk_{method}_solve")
-    return SolveStats(method=method, iterations=st.iterations, matvecs=st.matvecs, info=st.info,
+    if x_run is not x:
+        x.copy_(x_run)
+    return SolveStats(placement_GBps=probe_gbps, placement_tries=probe_tries, method=method, iterations=st.iterations, matvecs=st.matvecs, info=st.info,
                       breakdown=st.breakdown, b_norm=st.b_norm, residual_norm=st.residual_norm, x_norm=st.x_norm,
                       threshold=st.threshold, recurrence_rs=st.recurrence_rs, solve_ms=st.solve_ms,
                       spmv_ms_avg=st.spmv_ms_avg, spmv_profiled=st.spmv_profiled,
