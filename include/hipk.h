@@ -323,6 +323,9 @@ typedef struct {
     int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
     int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
     void *comm;
+    void *fused;   /* NULL, or a hipk_p2p_t created with a fused area (hipk_p2p_create2): hipk_dist_cg_solve then folds the two
+                      exchanges of an iteration into its update / direction kernels (csrc/hipk_fx.h) -- no collective launch inside
+                      the loop; the entry points above still serve the set-up and the final residual */
 } hipk_rccl;
 
 /* One rank's view of the partition (pytorch_sparse_solver/distributed.py: RowPartition + HaloPlan). */
@@ -341,6 +344,8 @@ typedef struct {
     int32_t reserved;
     const int32_t *send_idx_dev;  /* [n_send] local row of each packed entry                              */
     const int32_t *ghost_src_dev; /* [n_ghost] halo_mode 0: position of each halo entry in the gathered slabs */
+    const int32_t *send_off_dev;  /* device, [world + 1] or NULL: bounds of each destination's group in send_idx_dev (fused exchanges) */
+    const int64_t *dest_off_dev;  /* device, [world] or NULL: where this rank's group starts in each destination's ghost tail     */
     const int32_t *send_counts;   /* host, [world]: entries sent to each rank                             */
     const int32_t *recv_counts;   /* host, [world]: halo entries received from each rank (in rank order)  */
     const int64_t *send_first;    /* host, [world] or NULL: halo_mode 1, >= 0 where the entries for that rank are the
@@ -382,6 +387,10 @@ int hipk_dist_gmres_solve(hipk_csr_t A_local, const hipk_dist_plan *plan, const 
  * leave hipk_rccl.send/.recv NULL and hipk_dist_plan.halo_mode 0.  max_count = the largest `count` of any call. */
 typedef struct hipk_p2p_s *hipk_p2p_t;
 int hipk_p2p_create(hipk_p2p_t *out, int rank, int world, size_t max_count);
+/* ... with a FUSED AREA for a partition of fx_per chunks per rank and at most fx_ghost_cap ghost entries on any rank (the same two
+ * numbers on every rank): per-source sequence flags, the gathered partial arrays and the ghost tail of both exchanges of a CG
+ * iteration, written by the peers' update / direction kernels themselves (csrc/hipk_fx.h; hipk_rccl.fused). */
+int hipk_p2p_create2(hipk_p2p_t *out, int rank, int world, size_t max_count, int fx_per, int fx_ghost_cap);
 int hipk_p2p_export(hipk_p2p_t c, void *handle64);
 int hipk_p2p_connect(hipk_p2p_t c, const void *handles /* world x 64 bytes */);
 int hipk_p2p_destroy(hipk_p2p_t c);

@@ -641,11 +641,11 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 a.group_tiles = pl->group_tiles;
                 memcpy(g_spmv_kernel, pl->name, sizeof(g_spmv_kernel));
             } else {
-    #define HIPK_PICK_LOOP_U(T, C, V, U)                                                                                      \
+#define HIPK_PICK_LOOP_U(T, C, V, U)                                                                                      \
         (h->sell_w == 5 ? hipk_spmv_sell_loop_kernel<T, 5, C, V, U> : h->sell_w == 8 ? hipk_spmv_sell_loop_kernel<T, 8, C, V, U> \
          : h->sell_w == 4 ? hipk_spmv_sell_loop_kernel<T, 4, C, V, U> : hipk_spmv_sell_loop_kernel<T, 0, C, V, U>)
-    #define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
-    #define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
+#define HIPK_PICK_LOOP_V(T, C, V) (h->tile_ucode ? HIPK_PICK_LOOP_U(T, C, V, true) : HIPK_PICK_LOOP_U(T, C, V, false))
+#define HIPK_PICK_LOOP(T, C) (h->coded_layout == 3 ? HIPK_PICK_LOOP_V(T, C, true) : HIPK_PICK_LOOP_V(T, C, false))
                 kern = (h->dtype == HIPK_F64) ? HIPK_PICK_LOOP(double, false) : HIPK_PICK_LOOP(float, false);
                 const char *tname = h->dtype == HIPK_F64 ? "double" : "float";
                 const int uw = (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8) ? h->sell_w : 0;
@@ -669,16 +669,16 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 // the CG loop's form, the Arnoldi step's, BiCGStab's t = A s with <t, s> and <t, t> (TSL:925-927), plain y = A x
                 auto pick_wide = [&](int st, char *pname, size_t cap) -> void (*)(hipk_spmv_args) {  // st = the kernel's WALK
                     void (*pk)(hipk_spmv_args) = nullptr;
-    #define HIPK_PICK_WIDE_S(M, S) \
+#define HIPK_PICK_WIDE_S(M, S) \
         (h->sell_w == 5 ? hipk_spmv_sell_wide_kernel<5, M, S> : h->sell_w == 8 ? hipk_spmv_sell_wide_kernel<8, M, S> : hipk_spmv_sell_wide_kernel<4, M, S>)
-    #define HIPK_PICK_WIDE(M) (st == 1 ? HIPK_PICK_WIDE_S(M, 1) : HIPK_PICK_WIDE_S(M, 0))
+#define HIPK_PICK_WIDE(M) (st == 1 ? HIPK_PICK_WIDE_S(M, 1) : HIPK_PICK_WIDE_S(M, 0))
                     pk = HIPK_PICK_WIDE(-1);
                     if (a.mode == HIPK_SPMV_DOT_W && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_W);
                     if (a.mode == HIPK_SPMV_DOT_YY && !no_mode) pk = HIPK_PICK_WIDE(HIPK_SPMV_DOT_YY);
                     if (a.mode == both && !no_mode) pk = HIPK_PICK_WIDE(both);
                     if (a.mode == 0 && !no_mode) pk = HIPK_PICK_WIDE(0);
-    #undef HIPK_PICK_WIDE
-    #undef HIPK_PICK_WIDE_S
+#undef HIPK_PICK_WIDE
+#undef HIPK_PICK_WIDE_S
                     snprintf(pname, cap, "hipk_spmv_sell_wide_kernel<%d,%d,%d>", h->sell_w,  // the template arguments, as a profiler prints them
                              (a.mode >= 0 && a.mode <= both && !no_mode) ? a.mode : -1, st);
                     return pk;
@@ -728,9 +728,9 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                     // pair codes with an exact tile size: two tiles per loop trip (hipk_spmv_sell_pair_kernel)
                     static const bool no_pair = getenv("HIPK_SPMV_SELL_NO_PAIR") != nullptr;
                     if (!no_pair && h->coded_layout == 2 && (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8)) {
-    #define HIPK_PICK_PAIR_U(T, U) \
+#define HIPK_PICK_PAIR_U(T, U) \
         (h->sell_w == 5 ? hipk_spmv_sell_pair_kernel<T, 5, U> : h->sell_w == 8 ? hipk_spmv_sell_pair_kernel<T, 8, U> : hipk_spmv_sell_pair_kernel<T, 4, U>)
-    #define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
+#define HIPK_PICK_PAIR(T) (h->tile_ucode ? HIPK_PICK_PAIR_U(T, true) : HIPK_PICK_PAIR_U(T, false))
                         void (*pk)(hipk_spmv_args) = (h->dtype == HIPK_F64) ? HIPK_PICK_PAIR(double) : HIPK_PICK_PAIR(float);
                         int pmode = -1;
                         // the CG loop's form (y = A x with <w, y>) of the 5-point fp64 stencil: mode bits compiled in
@@ -752,17 +752,17 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                             kern = pk;
                             HIPK_NOTE_KERNEL("%s", pname);
                         }
-    #undef HIPK_PICK_PAIR
-    #undef HIPK_PICK_PAIR_U
+#undef HIPK_PICK_PAIR
+#undef HIPK_PICK_PAIR_U
                     }
                 } else {
                     lgrid = slots * h->sell_loop;
                     if (lgrid > ((ntiles + 7) >> 3) << 3) lgrid = ((ntiles + 7) >> 3) << 3;
                     lgrid = ((lgrid + 7) >> 3) << 3;
                 }
-    #undef HIPK_PICK_LOOP
-    #undef HIPK_PICK_LOOP_V
-    #undef HIPK_PICK_LOOP_U
+#undef HIPK_PICK_LOOP
+#undef HIPK_PICK_LOOP_V
+#undef HIPK_PICK_LOOP_U
                 if (!no_plan_cache && h->n_plans < (int)(sizeof(h->plans) / sizeof(h->plans[0]))) {
                     hipk_spmv_plan &np = h->plans[h->n_plans++];
                     np.mode = a.mode;

@@ -23,6 +23,7 @@
 #include "hipk_solve.h"
 #include "hipk_spmv.h"
 #include "hipk_handoff.h"
+#include "hipk_fx.h"
 
 // progress / placement block of the one-launch loops (hipk_cg_solve_lds_kernel), zeroed before each launch
 struct hipk_lds_ctl {
@@ -191,6 +192,111 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
         if (done) scal->stop_it = it + 1;
         hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
     }
+}
+
+// ---- row-partitioned CG with the exchanges folded into the kernels (hipk_fx.h; hipk_dist.hip drives them) -----------------
+// The update / direction kernels above with an exchange in front: workgroups 0 .. world-1 publish this rank's partials (and, in
+// the direction kernel, the boundary entries of r) into the peers' mailboxes, every workgroup waits for all sources and folds the
+// gathered partials straight from its own mailbox.  grid = max(chunks, world): surplus workgroups only publish and wait.
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_fx_kernel(int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal,
+                                                                         int64_t it, const double *__restrict__ Ap, double *__restrict__ r,
+                                                                         double *__restrict__ part_rr, hipk_fx fx) {
+    typedef double T;
+    const int c = blockIdx.x;
+    hipk_pre<T, 2, false> pre;
+    pre.issue(n, ch, c, {Ap, (const T *)r});
+    if (it >= scal->stop_it) return;   // the same word on every rank (same partials, same fold): all ranks skip together
+    __shared__ double sbuf[HIPK_THREADS];
+    __shared__ int fx_ok;
+    hipk_fx_publish(fx);
+    if (!hipk_fx_wait(fx, &fx_ok)) return;
+    const double pAp = hipk_reduce_parts(hipk_fx_parts(fx), g, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T alpha = (T)(gamma / pAp);  // TSL:846
+    double acc = 0.0;
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m1 = alpha * v[0][k];
+            rv[k] = v[1][k] - m1;  // TSL:848
+            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);  // TSL:850
+        }
+        hipk_st<T>(r, i, nv, rv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0 && (int64_t)c * ch < n) part_rr[c] = acc;
+}
+
+// n = n_ext (own rows + ghost tail), n_own = own rows.  The ghost entries of r arrive with the exchange: the workgroups whose chunk
+// reaches into the tail copy them from the mailbox into r BEFORE they request their operands; everybody else requests first.
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_fx_kernel(int64_t n, int64_t n_own, int ch, int g,
+                                                                            hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
+                                                                            double *__restrict__ r, double *__restrict__ p,
+                                                                            double *__restrict__ x, hipk_fx fx) {
+    typedef double T;
+    const int c = blockIdx.x;
+    const bool tail = (int64_t)(c + 1) * ch > n_own && (int64_t)c * ch < n;
+    __shared__ double sbuf[2 * HIPK_THREADS];
+    __shared__ int fx_ok;
+    hipk_pre<T, 2, false> pre;
+    if (!tail) pre.issue(n, ch, c, {(const T *)r, (const T *)p});
+    if (it >= scal->stop_it) return;
+    hipk_fx_publish(fx);
+    if (!hipk_fx_wait(fx, &fx_ok)) return;
+    if (tail) {
+        const double *halo = hipk_fx_halo(fx);
+        const int64_t lo = ((int64_t)c * ch > n_own ? (int64_t)c * ch : n_own), hi = ((int64_t)(c + 1) * ch < n ? (int64_t)(c + 1) * ch : n);
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) r[i] = halo[i - n_own];
+        __syncthreads();
+        pre.issue(n, ch, c, {(const T *)r, (const T *)p});
+    }
+    double pAp, rr;
+    hipk_reduce_parts2(hipk_fx_parts_of(fx, 0), hipk_fx_parts(fx), g, pAp, rr, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_fx_kernel derived
+    const T beta = (T)(rr / gamma);    // TSL:851
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T xv[VEC], pv[VEC];
+        hipk_ld<T>((const T *)x, i, nv, xv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * v[1][k];
+            xv[k] = xv[k] + m0;  // TSL:847 (with the p of this iteration, before it is replaced)
+            const T m = beta * v[1][k];
+            pv[k] = v[0][k] + m;  // TSL:852
+        }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(p, i, nv, pv);
+    });
+    if (c == 0 && threadIdx.x == 0) {
+        scal->gamma[(it + 1) & 1] = rr;  // TSL:853
+        const bool done = (it + 1 >= maxiter || rr <= scal->atol2);  // TSL:841 for the NEXT pass
+        if (done) scal->stop_it = it + 1;
+        hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | (it + 1)) : (it + 1));
+    }
+}
+
+// hipk_dist.hip's entry points to them (fp64; fx->seq / ch / kind / parts / vec filled by the caller per exchange)
+int hipk_cg_update_fx(int64_t n_local, int chunk_rows, int g_red, const void *scal_dev, int64_t it, const void *Ap, void *r,
+                      double *part_rr_out, const hipk_fx *fx, hipStream_t stream) {
+    int grid = (int)((n_local + chunk_rows - 1) / chunk_rows);
+    if (grid < fx->world) grid = fx->world;
+    hipk_cg_update_fx_kernel<<<grid, HIPK_THREADS, 0, stream>>>(n_local, chunk_rows, g_red, (const hipk_cg_scal *)scal_dev, it,
+                                                               (const double *)Ap, (double *)r, part_rr_out, *fx);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
+}
+int hipk_cg_direction_fx(int64_t n_ext, int64_t n_local, int chunk_rows, int g_red, void *scal_dev, int64_t it, int64_t maxiter, void *r,
+                         void *p, void *x, const hipk_fx *fx, hipStream_t stream) {
+    int grid = (int)((n_ext + chunk_rows - 1) / chunk_rows);
+    if (grid < fx->world) grid = fx->world;
+    hipk_cg_direction_fx_kernel<<<grid, HIPK_THREADS, 0, stream>>>(n_ext, n_local, chunk_rows, g_red, (hipk_cg_scal *)scal_dev, it, maxiter,
+                                                                  (double *)r, (double *)p, (double *)x, *fx);
+    HIPK_CHECK_HIP(hipGetLastError());
+    return HIPK_OK;
 }
 
 // Streaming policy on one device (vectors in HBM: N >> 8 M rows): the direction step as TWO launches -- alpha, beta, the next gamma

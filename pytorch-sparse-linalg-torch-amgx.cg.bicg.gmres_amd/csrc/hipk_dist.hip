@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "hipk_common.h"
+#include "hipk_fx.h"
 #include "hipk_solve.h"
 
 static inline size_t hipk_al(size_t v) { return hipk_align_up(v, 256); }
@@ -217,8 +218,43 @@ extern "C" int hipk_dist_cg_solve(hipk_csr_t A, const hipk_dist_plan *pl, const 
             if (b) (void)hipEventDestroy(b);
         }
     } side_release{side, ev_upd, ev_x};
+    // FUSED exchanges (hipk_fx.h): with a mailbox communicator that carries a fused area (hipk_rccl.fused) the two exchanges of an
+    // iteration are made by the update / direction kernels themselves -- three launches per iteration, as on one device.
+    // HIPK_DIST_FUSED=0 keeps the collective entry points.
+    hipk_fx fx;
+    unsigned long long fx_seq0 = 0;
+    const char *fx_env = getenv("HIPK_DIST_FUSED");
+    bool fused = cc->fused != nullptr && !(fx_env && fx_env[0] == '0') && !overlap && (W == 1 || (pl->send_off_dev && pl->dest_off_dev)) &&
+                 hipk_p2p_fx_begin((hipk_p2p_s *)cc->fused, per, pl->n_ghost, &fx, &fx_seq0) != 0;
+    if (fused) {
+        fx.send_idx = pl->send_idx_dev;
+        fx.send_off = pl->send_off_dev;
+        fx.dest_off = (const long long *)pl->dest_off_dev;
+        fx.n_ghost = pl->n_ghost;
+    }
+    struct fx_guard {   // every exit path tells the communicator how many exchanges were issued
+        const hipk_rccl *cc;
+        const bool &on;
+        const int64_t &it;
+        ~fx_guard() {
+            if (on) hipk_p2p_fx_end((hipk_p2p_s *)cc->fused, (unsigned long long)it);
+        }
+    } fx_release{cc, fused, it};
     while (it < maxiter) {
         const int64_t end = (it + batch < maxiter) ? it + batch : maxiter;
+        for (; fused && it < end; ++it) {
+            HIPK_TRY(hipk_spmv_ex(A, p, Ap, MODE_DOT_W, p, nullptr, part_loc, spare, stop_dev, it, stream));
+            fx.seq = fx_seq0 + (unsigned long long)it;
+            fx.ch = (int)(it & 1);
+            fx.kind = 0;
+            fx.parts = part_loc;     // <p,Ap> partials of this rank's chunks (the SpMV's)
+            fx.vec = nullptr;
+            HIPK_TRY(hipk_cg_update_fx(n, ch, G, scal, it, Ap, r, spare, &fx, stream));
+            fx.kind = 1;
+            fx.parts = spare;        // <r,r> partials (the update kernel's)
+            fx.vec = r;
+            HIPK_TRY(hipk_cg_direction_fx(n_ext, n, ch, G, scal, it, maxiter, r, p, x, &fx, stream));
+        }
         for (; it < end; ++it) {
             HIPK_TRY(hipk_spmv_ex(A, p, Ap, MODE_DOT_W, p, nullptr, part_loc, spare, stop_dev, it, stream));
             HIPK_TRY(gather_parts(g_pAp));

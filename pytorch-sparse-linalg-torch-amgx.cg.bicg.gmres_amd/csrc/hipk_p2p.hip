@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "hipk_common.h"
+#include "hipk_fx.h"
 #include "hipk_solve.h"
 
 #define HIPK_P2P_MAX_WORLD 64
@@ -33,6 +34,10 @@ struct hipk_p2p_s {
     unsigned long long seq;  // calls made so far
     int *err_dev;            // set by a collect block whose spin bound was hit
     bool uncached;
+    // fused area (hipk_fx.h): exchanges folded into the CG kernels; fx_per == 0: none
+    size_t fx_off;
+    int fx_per, fx_ghost_cap;
+    unsigned long long fx_seq;   // exchanges of each kind made so far (sequence numbers grow over the solves of a communicator)
 };
 
 static inline size_t hipk_p2p_flags_bytes(int world) { return hipk_align_up(sizeof(unsigned long long) * 2 * (size_t)world, 256); }
@@ -83,14 +88,25 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_p2p_exchange_kernel(char *c
 }
 
 extern "C" int hipk_p2p_create(hipk_p2p_t *out, int rank, int world, size_t max_count) {
+    return hipk_p2p_create2(out, rank, world, max_count, 0, 0);
+}
+
+// fx_per > 0: the mailbox also carries the fused area of hipk_fx.h for a partition with `fx_per` chunks per rank and at most
+// `fx_ghost_cap` ghost entries on any rank (both must be the same on every rank: the offsets inside a peer's mailbox follow)
+extern "C" int hipk_p2p_create2(hipk_p2p_t *out, int rank, int world, size_t max_count, int fx_per, int fx_ghost_cap) {
     HIPK_REQUIRE(out && world >= 1 && world <= HIPK_P2P_MAX_WORLD && rank >= 0 && rank < world && max_count >= 1, HIPK_ERR_ARG,
                  "bad argument");
+    HIPK_REQUIRE(fx_per >= 0 && fx_ghost_cap >= 0, HIPK_ERR_ARG, "bad fused-area geometry");
     hipk_p2p_s *c = new hipk_p2p_s();
     memset(c, 0, sizeof(*c));
     c->rank = rank;
     c->world = world;
     c->max_count = max_count;
     c->bytes = hipk_p2p_bytes(world, max_count);
+    c->fx_off = c->bytes;
+    c->fx_per = fx_per;
+    c->fx_ghost_cap = fx_ghost_cap;
+    if (fx_per > 0) c->bytes += hipk_fx_bytes(world, fx_per, fx_ghost_cap);
     void *p = nullptr;
     // uncached (fine-grained) device memory: peer stores become visible without cache maintenance on the owner
     hipError_t e = hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached);
@@ -173,4 +189,27 @@ extern "C" int hipk_p2p_all_gather(const void *send, void *recv, size_t count, i
         c->peer_dev, c->rank, c->world, hipk_align_up(c->max_count * sizeof(double), 256), hipk_p2p_flags_bytes(c->world), ch, seq,
         (const double *)send, (double *)recv, count, c->err_dev);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+
+// ---- fused exchanges (hipk_fx.h): what hipk_dist.hip needs from the communicator
+// the constant part of the descriptor + the sequence number the solve's first exchange takes; 0 when the communicator has no fused
+// area for this geometry or its mailbox is not fine-grained memory (peer stores must be visible without cache maintenance)
+extern "C" int hipk_p2p_fx_begin(hipk_p2p_t c, int per, int n_ghost, hipk_fx *fx, unsigned long long *first_seq) {
+    if (!c || !fx || !first_seq || c->fx_per <= 0 || c->fx_per != per || n_ghost > c->fx_ghost_cap || !c->uncached) return 0;
+    memset(fx, 0, sizeof(*fx));
+    fx->peer = c->peer_dev;
+    fx->rank = c->rank;
+    fx->world = c->world;
+    fx->per = c->fx_per;
+    fx->ghost_cap = c->fx_ghost_cap;
+    fx->off_flags = c->fx_off;
+    fx->off_parts = c->fx_off + hipk_fx_flags_bytes(c->world);
+    fx->off_halo = fx->off_parts + hipk_fx_parts_bytes(c->world, c->fx_per);
+    fx->err = c->err_dev;
+    *first_seq = c->fx_seq + 1;
+    return 1;
+}
+extern "C" void hipk_p2p_fx_end(hipk_p2p_t c, unsigned long long exchanges_issued) {
+    if (c) c->fx_seq += exchanges_issued;
 }

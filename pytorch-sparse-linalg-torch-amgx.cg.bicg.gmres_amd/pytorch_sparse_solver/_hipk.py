@@ -43,7 +43,7 @@ SYMBOLS = [
     "hipk_dist_cg_work_bytes", "hipk_dist_cg_solve", "hipk_dist_bicgstab_work_bytes", "hipk_dist_bicgstab_solve",
     "hipk_dist_gmres_work_bytes", "hipk_dist_gmres_solve",
     # experimental mailbox exchange provider for that loop
-    "hipk_p2p_create", "hipk_p2p_export", "hipk_p2p_connect", "hipk_p2p_destroy", "hipk_p2p_error",
+    "hipk_p2p_create", "hipk_p2p_create2", "hipk_p2p_export", "hipk_p2p_connect", "hipk_p2p_destroy", "hipk_p2p_error",
     "hipk_p2p_group_start", "hipk_p2p_group_end", "hipk_p2p_all_gather",
 ]
 
@@ -115,7 +115,7 @@ COLL_SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size
 
 class Rccl(ctypes.Structure):
     _fields_ = [("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p), ("all_gather", ctypes.c_void_p),
-                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("comm", ctypes.c_void_p)]
+                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("comm", ctypes.c_void_p), ("fused", ctypes.c_void_p)]
 
 
 class DistPlan(ctypes.Structure):
@@ -124,6 +124,7 @@ class DistPlan(ctypes.Structure):
                 ("per", ctypes.c_int32), ("halo_mode", ctypes.c_int32), ("n_send", ctypes.c_int32),
                 ("n_ghost", ctypes.c_int32), ("slab", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("send_idx_dev", ctypes.c_void_p), ("ghost_src_dev", ctypes.c_void_p),
+                ("send_off_dev", ctypes.c_void_p), ("dest_off_dev", ctypes.c_void_p),
                 ("send_counts", ctypes.POINTER(ctypes.c_int32)), ("recv_counts", ctypes.POINTER(ctypes.c_int32)),
                 ("send_first", ctypes.POINTER(ctypes.c_int64))]
 
@@ -228,6 +229,7 @@ def lib():
     L.hipk_dist_gmres_solve.argtypes = [vp, ctypes.POINTER(DistPlan), ctypes.POINTER(Rccl), vp, vp, vp, ctypes.c_size_t,
                                         ctypes.POINTER(Params), ctypes.POINTER(Stats), vp]
     L.hipk_p2p_create.argtypes = [ctypes.POINTER(vp), i32, i32, ctypes.c_size_t]
+    L.hipk_p2p_create2.argtypes = [ctypes.POINTER(vp), i32, i32, ctypes.c_size_t, i32, i32]
     L.hipk_p2p_export.argtypes = [vp, ctypes.c_char_p]
     L.hipk_p2p_connect.argtypes = [vp, ctypes.c_char_p]
     L.hipk_p2p_destroy.argtypes = [vp]

@@ -116,6 +116,16 @@ class HaloPlan:
         my_off = torch.cumsum(torch.tensor([0] + self.send_splits[:-1], dtype=torch.int64, device=dev), 0)
         their_off = torch.empty_like(my_off)                          # their_off[o] = where my block starts in o's list
         dist.all_to_all_single(their_off, my_off, group=group)
+        # fused exchanges (csrc/hipk_fx.h): every owner stores my ghost entries straight into my ghost tail, so it must know
+        # where its group starts there -- and I, where mine starts in each destination's tail; the largest tail bounds the mailboxes
+        ghost_first = torch.cumsum(torch.tensor([0] + self.recv_splits[:-1], dtype=torch.int64, device=dev), 0)
+        dest_off = torch.empty_like(ghost_first)
+        dist.all_to_all_single(dest_off, ghost_first, group=group)
+        self.dest_off = dest_off.to(torch.int64)                       # [world]
+        self.send_off = torch.cumsum(torch.tensor([0] + self.send_splits, dtype=torch.int64, device=dev), 0).to(torch.int32)
+        t = torch.tensor([self.n_ghost], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self.ghost_cap = max(int(t.item()), 1)
         if self.n_ghost:
             first = torch.cumsum(torch.tensor([0] + self.recv_splits[:-1], dtype=torch.int64, device=dev), 0)
             idx_in_req = torch.arange(self.n_ghost, device=dev) - first[owners]
@@ -284,7 +294,7 @@ class RcclComm:
         from . import _hipk
         addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value   # noqa: E731
         return _hipk.Rccl(addr(self.L.ncclGroupStart), addr(self.L.ncclGroupEnd), addr(self.L.ncclAllGather),
-                          addr(self.L.ncclSend), addr(self.L.ncclRecv), self.comm.value)
+                          addr(self.L.ncclSend), addr(self.L.ncclRecv), self.comm.value, None)
 
     def close(self):
         if getattr(self, "comm", None):
@@ -297,13 +307,15 @@ class P2PComm:
     its peers through HIP IPC and an all-gather is one small kernel per rank instead of an RCCL collective launch.
     Only the C-driven loop uses it (all-gathered-slab halo); the IPC handles travel once through torch.distributed."""
 
-    def __init__(self, rank: int, world: int, device, max_count: int, group=None):
+    def __init__(self, rank: int, world: int, device, max_count: int, group=None, fx_per: int = 0, fx_ghost_cap: int = 0):
         from . import _hipk
         self.L = L = _hipk.lib()
         self.rank, self.world, self.device = rank, world, torch.device(device)
         self.ctx = ctypes.c_void_p()
+        self.fused = fx_per > 0     # the mailbox carries the fused area (csrc/hipk_fx.h): exchanges made by the CG kernels themselves
         with torch.cuda.device(self.device):
-            _hipk._check(L.hipk_p2p_create(ctypes.byref(self.ctx), rank, world, max(int(max_count), 1)), "hipk_p2p_create")
+            _hipk._check(L.hipk_p2p_create2(ctypes.byref(self.ctx), rank, world, max(int(max_count), 1), int(fx_per), int(fx_ghost_cap)),
+                         "hipk_p2p_create2")
             mine = ctypes.create_string_buffer(64)
             _hipk._check(L.hipk_p2p_export(self.ctx, mine), "hipk_p2p_export")
             box = [None] * world
@@ -320,7 +332,7 @@ class P2PComm:
         from . import _hipk
         addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value   # noqa: E731
         return _hipk.Rccl(addr(self.L.hipk_p2p_group_start), addr(self.L.hipk_p2p_group_end),
-                          addr(self.L.hipk_p2p_all_gather), None, None, self.ctx.value)
+                          addr(self.L.hipk_p2p_all_gather), None, None, self.ctx.value, self.ctx.value if self.fused else None)
 
     def failed(self) -> bool:
         return bool(self.L.hipk_p2p_error(self.ctx))
@@ -402,10 +414,15 @@ class DistProblem:
                 warnings.warn(f"direct RCCL communicator unavailable on a rank ({why or 'another rank'}); "
                               f"all ranks use torch.distributed collectives")
         # opt-in: device mailboxes instead of RCCL for the C-driven loop's two exchanges (experimental, see P2PComm)
+        # "fused": the mailboxes also carry the fused area -- the two exchanges of a CG iteration are made by its update /
+        # direction kernels themselves, no collective launch inside the loop (csrc/hipk_fx.h); set-up and the final residual go
+        # through the mailbox all-gather.  Built and tested with ranks sharing one GPU; over xGMI unmeasured, so RCCL stays default.
         self.p2p = None
-        if want == "p2p" and isinstance(ops, HipOps) and (part.world == 1 or dist.is_initialized()):
-            self.p2p = P2PComm(part.rank, part.world, ops.device, max(part.per, self.plan.slab), group)
-            self.comm_kind = "p2p-mailbox"
+        if want in ("p2p", "fused") and isinstance(ops, HipOps) and (part.world == 1 or dist.is_initialized()):
+            fx = want == "fused"
+            self.p2p = P2PComm(part.rank, part.world, ops.device, max(part.per, self.plan.slab), group,
+                               fx_per=part.per if fx else 0, fx_ghost_cap=self.plan.ghost_cap if fx else 0)
+            self.comm_kind = "p2p-mailbox, exchanges fused into the CG kernels" if fx else "p2p-mailbox"
 
     def coll_struct(self):
         """hipk_rccl for the C-driven loop, or None (then the Python loop with torch.distributed collectives runs)."""
@@ -492,6 +509,8 @@ def _dist_cg_native(prob: DistProblem, x0_local, tol, atol, maxiter, check_every
     plan.n_send, plan.n_ghost, plan.slab = pl.n_send, pl.n_ghost, pl.slab
     plan.send_idx_dev = pl.send_idx.data_ptr() if pl.n_send else None
     plan.ghost_src_dev = pl.ghost_src.data_ptr() if pl.n_ghost else None
+    send_off_d, dest_off_d = pl.send_off.to(dev).contiguous(), pl.dest_off.to(dev).contiguous()   # fused exchanges (kept alive below)
+    plan.send_off_dev, plan.dest_off_dev = send_off_d.data_ptr(), dest_off_d.data_ptr()
     sc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.send_splits])
     rc = (ctypes.c_int32 * part.world)(*[int(v) for v in pl.recv_splits])
     plan.send_counts, plan.recv_counts = sc, rc

@@ -160,8 +160,9 @@ class MailboxNative(HostStagedProblem):
 
 def main():
     kind, nx, ny, tol, maxiter, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag", "native_p2p", "native_side")
-    mailbox = len(sys.argv) > 7 and sys.argv[7] == "native_p2p"
+    use_hip = len(sys.argv) > 7 and sys.argv[7] in ("hip", "native", "native_ag", "native_p2p", "native_side", "native_fused")
+    mailbox = len(sys.argv) > 7 and sys.argv[7] in ("native_p2p", "native_fused")
+    fused = len(sys.argv) > 7 and sys.argv[7] == "native_fused"   # exchanges made by the CG kernels themselves (csrc/hipk_fx.h)
     native = len(sys.argv) > 7 and sys.argv[7].startswith("native")
     if len(sys.argv) > 7 and sys.argv[7] == "native_side":
         os.environ["HIPK_DIST_OVERLAP"] = "1"      # x += alpha p on a side stream beside the second collective
@@ -196,7 +197,8 @@ def main():
         prob.comm = None
         if mailbox:
             from pytorch_sparse_solver.distributed import P2PComm
-            prob.p2p = P2PComm(rank, world, dev, max(part.per, plan.slab))
+            prob.p2p = P2PComm(rank, world, dev, max(part.per, plan.slab), fx_per=part.per if fused else 0,
+                               fx_ghost_cap=plan.ghost_cap if fused else 0)
     else:
         prob = DistProblem(lc, lcol, lval, lb, part, OracleOps())
     if native:

@@ -112,6 +112,31 @@ def test_dist_cg_c_driven_loop_device_mailboxes(world, kind, nx, ny, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nx,ny,maxiter", [(2, "poisson", 96, 64, -1), (3, "poisson", 96, 64, -1), (2, "random_spd", 80, 77, -1),
+                                                      (3, "random_spd", 80, 77, -1), (2, "poisson", 4, 8000, -1), (3, "poisson", 5, 8000, -1),
+                                                      (2, "poisson", 96, 64, 9)])
+def test_dist_cg_exchanges_fused_into_the_kernels(world, kind, nx, ny, maxiter, tmp_path):
+    """no collective launch inside the CG loop -- the update / direction kernels publish this rank's partials
+    (and the boundary entries of r) into the peers' IPC-mapped mailboxes and wait for the peers' (csrc/hipk_fx.h).  Ranks share
+    cuda:0, so kernels of different processes really wait on each other's stores.  One chunk per rank (grid smaller than the world:
+    surplus publisher workgroups), scattered ghosts from several owners, 8000-wide grid lines with block boundaries inside them, a
+    maxiter cut-off.  Bitwise equal to the single-rank oracle solve."""
+    r = _run(world, kind, nx, ny, 1e-8 if maxiter < 0 else 1e-12, maxiter, tmp_path, mode="native_fused")
+    assert r["bitwise_equal"], r
+    assert set(r["info"]) == {r["ref_info"]} and set(r["iterations"]) == {r["ref_iterations"]}
+    assert set(r["residual_norm"]) == {r["ref_residual_norm"]}
+
+
+@pytest.mark.gpu
+def test_dist_cg_fused_exchanges_on_large_row_blocks(tmp_path):
+    """Row blocks of the size a GPU really gets (1536 x 1500 grid, 1.15 M rows per rank = 563 chunks, two ranks sharing cuda:0):
+    the fused update / direction kernels as full grids, 40 iterations, bitwise equal to the single-rank oracle solve."""
+    r = _run(2, "poisson", 1536, 1500, 1e-12, 40, tmp_path, mode="native_fused")
+    assert r["bitwise_equal"], {k: v for k, v in r.items() if k != "residual_norm"}
+    assert set(r["iterations"]) == {40} == {r["ref_iterations"]}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,nx,ny,mode,maxiter", [(2, "convdiff", 96, 64, "native", -1), (3, "convdiff", 96, 64, "native_ag", -1),
                                                            (2, "random_spd", 80, 77, "native", -1), (2, "convdiff", 4, 8000, "native", -1),
                                                            (2, "convdiff", 96, 64, "native_p2p", -1), (2, "convdiff", 96, 64, "native", 9)])

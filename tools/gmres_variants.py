@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GMRES(30) at N = 4M: A/B of the large-system kernel variants (env switches of hipk_gmres_solve_t) in one process.
 Prints ms per restart cycle and checks that every variant returns the same bits."""
+import os as _os; _os.environ.setdefault("HIPK_SPMV_NO_PLAN_CACHE", "1")  # this probe flips SpMV switches between launches
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd")]

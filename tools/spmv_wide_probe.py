@@ -2,6 +2,7 @@
 """Coded SpMV on the N = 4M Poisson matrix with the uniform tiles taken two rows per lane (hipk_spmv_sell_wide_kernel) or
 one row per lane (HIPK_SPMV_SELL_NO_WIDE=1, read once per process): stand-alone SpMV, SpMV inside the CG loop, CG it/s,
 GMRES(30) cycle.  Run once per setting."""
+import os as _os; _os.environ.setdefault("HIPK_SPMV_NO_PLAN_CACHE", "1")  # this probe flips SpMV switches between launches
 import json
 import os
 import sys

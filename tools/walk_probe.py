@@ -5,6 +5,7 @@ walking its own chunk (HIPK_SPMV_SELL_STRIDED=0) against one workgroup per group
 library's own choice (unset), in ONE process (the switch is read per launch); stand-alone SpMV, SpMV inside the CG loop, CG
 time per iteration, x of 200 iterations bitwise equal.  HIPK_SPMV_SELL_CHUNKED=0 in the environment measures the
 one-row-per-lane persistent kernel instead."""
+import os as _os; _os.environ.setdefault("HIPK_SPMV_NO_PLAN_CACHE", "1")  # this probe flips SpMV switches between launches
 import hashlib
 import json
 import os
