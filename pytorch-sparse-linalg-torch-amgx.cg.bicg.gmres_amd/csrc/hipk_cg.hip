@@ -209,8 +209,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_fx_kernel(int64_t
     __shared__ double sbuf[HIPK_THREADS];
     __shared__ int fx_ok;
     hipk_fx_publish(fx);
-    if (!hipk_fx_wait(fx, &fx_ok)) return;
-    const double pAp = hipk_reduce_parts(hipk_fx_parts(fx), g, sbuf);
+    if (c == 0) hipk_fx_collect(fx, g, sbuf, &fx_ok);
+    hipk_fx_await(fx);
+    const double pAp = hipk_fx_scalar(fx, 0);
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846
     double acc = 0.0;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_fx_kernel(int64_t
 }
 
 // n = n_ext (own rows + ghost tail), n_own = own rows.  The ghost entries of r arrive with the exchange: the workgroups whose chunk
-// reaches into the tail copy them from the mailbox into r BEFORE they request their operands; everybody else requests first.
+// reaches into the tail copy their part from the mailbox into r BEFORE they request their operands; everybody else requests first.
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_fx_kernel(int64_t n, int64_t n_own, int ch, int g,
                                                                             hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
                                                                             double *__restrict__ r, double *__restrict__ p,
@@ -238,22 +239,23 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_fx_kernel(int6
     typedef double T;
     const int c = blockIdx.x;
     const bool tail = (int64_t)(c + 1) * ch > n_own && (int64_t)c * ch < n;
-    __shared__ double sbuf[2 * HIPK_THREADS];
+    __shared__ double sbuf[HIPK_THREADS];
     __shared__ int fx_ok;
     hipk_pre<T, 2, false> pre;
     if (!tail) pre.issue(n, ch, c, {(const T *)r, (const T *)p});
     if (it >= scal->stop_it) return;
     hipk_fx_publish(fx);
-    if (!hipk_fx_wait(fx, &fx_ok)) return;
+    if (c == 0) hipk_fx_collect(fx, g, sbuf, &fx_ok);
+    hipk_fx_await(fx);
     if (tail) {
+        __threadfence_system();
         const double *halo = hipk_fx_halo(fx);
         const int64_t lo = ((int64_t)c * ch > n_own ? (int64_t)c * ch : n_own), hi = ((int64_t)(c + 1) * ch < n ? (int64_t)(c + 1) * ch : n);
         for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) r[i] = halo[i - n_own];
         __syncthreads();
         pre.issue(n, ch, c, {(const T *)r, (const T *)p});
     }
-    double pAp, rr;
-    hipk_reduce_parts2(hipk_fx_parts_of(fx, 0), hipk_fx_parts(fx), g, pAp, rr, sbuf);
+    const double pAp = hipk_fx_scalar(fx, 0), rr = hipk_fx_scalar(fx, 1);
     const double gamma = scal->gamma[it & 1];
     const T alpha = (T)(gamma / pAp);  // TSL:846, the same bits hipk_cg_update_fx_kernel derived
     const T beta = (T)(rr / gamma);    // TSL:851

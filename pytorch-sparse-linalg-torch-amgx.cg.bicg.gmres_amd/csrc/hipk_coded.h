@@ -974,10 +974,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
     doff[t] = dofs;
-    // NO barrier here (round 3): the uniform tiles below take the few dictionary entries they need straight from memory with
-    // scalar loads (uniform addresses), so a wavefront starts on its tiles as soon as its own `ucode` word is back instead of
-    // waiting for the slowest wavefront's dictionary load and a workgroup barrier; the per-lane tiles, which look the dictionary up
-    // per lane in LDS, run AFTER the uniform ones, behind the barrier that then costs nothing.
+    __syncthreads();
 
     // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's (and t_first + 64 + i's for chunks of more
     // than 64 tiles), a tile's word is read into scalar registers with v_readlane (no memory round trip per tile)
@@ -1075,11 +1072,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
                 const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
-                const int ci = __builtin_amdgcn_readfirstlane(ck == HIPK_SELL_PAD ? 0 : (int)ck);
-                // uniform index -> scalar loads from the dictionary in memory (n_codes >= 1: entry 0 exists)
-                sbo[k] = (long long)__builtin_amdgcn_readfirstlane(g_doff[ci]) * (long long)sizeof(T);
+                const int ci = ck == HIPK_SELL_PAD ? 0 : (int)ck;
+                sbo[k] = (long long)__builtin_amdgcn_readfirstlane(doff[ci]) * (long long)sizeof(T);
                 if (ck != HIPK_SELL_PAD && sbo[k] == 0) kc = k;
-                const double v = g_dval[ci];
+                const double v = dval[ci];
                 sv[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
                                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
             }
@@ -1143,17 +1139,16 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
         }
     };
 
-    // ---- the uniform tiles of this wavefront pair's parity first (no LDS dictionary, no barrier)
+    // ---- the tiles whose rows differ first, whole workgroup
+    for (int i = 0; i < cnt; ++i) {
+        if (tile_ucode_of(i) != 0ull) continue;
+        per_lane_tile(t_first + i, i);
+    }
+    // ---- the uniform tiles of this wavefront pair's parity
     for (int i = wp; i < cnt; i += 2) {
         const unsigned long long uc = tile_ucode_of(i);
         if (uc == 0ull) continue;
         uniform_tile(t_first + i, i, uc);
-    }
-    // ---- then the tiles whose rows differ, whole workgroup, behind the barrier that publishes the LDS dictionary
-    __syncthreads();
-    for (int i = 0; i < cnt; ++i) {
-        if (tile_ucode_of(i) != 0ull) continue;
-        per_lane_tile(t_first + i, i);
     }
     if (!STRIDED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();

@@ -8,13 +8,17 @@
 //     AREA: per kind of exchange (0 = <p,Ap>, 1 = <r,r> + halo) and channel (iteration parity) one sequence flag per source
 //     rank, a partials array laid out exactly like the global chunk-partial array the kernels fold (rank s owns entries
 //     s * per ...), and -- kind 1 -- a halo array laid out exactly like the rank's ghost tail;
-//   * the CONSUMER kernel of the exchange (update / direction, FX instantiations in hipk_cg.hip) starts with: workgroups
-//     0 .. world-1 PUBLISH -- workgroup q stores this rank's partials (written by the previous kernel on the stream) and the
-//     boundary entries of r that rank q's rows reference into q's mailbox with system-scope stores, fences, then stores the
-//     exchange's sequence number into its flag there -- then EVERY workgroup polls the `world` flags of its own mailbox (one
-//     lane per source, bounded) and folds the partials straight from the mailbox.  Publishers never wait before they have
-//     published and have the lowest workgroup indices (dispatched first), so the scheme cannot dead-lock on a grid of more
-//     workgroups than the chip holds.
+//   * the CONSUMER kernel of the exchange (update / direction, FX kernels in hipk_cg.hip) starts with: workgroups 0 .. world-1
+//     PUBLISH -- workgroup q stores this rank's partials (written by the previous kernel on the stream) and the boundary
+//     entries of r that rank q's rows reference into q's mailbox with system-scope stores, fences, then stores the exchange's
+//     sequence number into its flag there.  Workgroup 0 is also the COLLECTOR: it polls the `world` flags of its own mailbox
+//     (one lane per source, bounded), folds the gathered partials -- the spec's fold, once -- and hands the SCALAR to the other
+//     workgroups through a word of ordinary device memory (agent-scope store + sequence flag); they poll that flag and read
+//     the scalar.  (First version: every workgroup polled the mailbox and folded from it -- 1954 workgroups x 31 KB of
+//     fine-grained-memory reads cost 200 us per kernel at 4 M rows, 487 instead of 57 us per iteration at world 1.)
+//     The workgroups whose chunk reaches into the ghost tail copy their part of the halo from the mailbox into r after the
+//     flag.  Publishers and the collector never wait before they have published and have the lowest workgroup indices
+//     (dispatched first), so the scheme cannot dead-lock on a grid of more workgroups than the chip holds.
 // Ordering across iterations: a rank can be at most one exchange of a kind ahead of a peer (it cannot pass the wait of
 // exchange k+1 without the peer's publication k+1, made after the peer consumed k), so two channels suffice.  Sequence
 // numbers grow monotonically over the solves of a communicator.  Same partials, same fold, same bits as the single-device solve.
@@ -30,8 +34,10 @@ struct hipk_fx {
     int *err;                 // set when a wait gives up
     const double *parts;      // my `per` partials (previous kernel's output)
     const double *vec;        // kind 1: the vector whose boundary entries the peers need
-    double *vec_tail;         // kind 1: where my own ghost entries go (vec + n_local)
     int n_ghost;
+    // hand-off from the collector workgroup to the others: ordinary device memory (the solve's workspace)
+    double *loc_val;              // [2 kinds][2 channels] folded scalars
+    unsigned long long *loc_flag; // [2 kinds] sequence number of the last exchange whose scalar is in loc_val
     const int *send_idx;      // device: my local rows grouped by destination rank
     const int *send_off;      // device [world + 1]: bounds of each destination's group in send_idx
     const long long *dest_off;  // device [world]: where my group starts in each destination's ghost tail
@@ -90,9 +96,9 @@ __device__ __forceinline__ void hipk_fx_publish(const hipk_fx &fx) {
     }
 }
 
-// every workgroup: wait until all `world` sources have published this exchange (lane s polls source s; bounded).
-// Returns false when a source never arrived (the error word is set; the caller leaves its operands untouched).
-__device__ __forceinline__ bool hipk_fx_wait(const hipk_fx &fx, int *lds_ok) {
+// workgroup 0 (all its threads): wait until all `world` sources have published this exchange (lane s polls source s; bounded), fold
+// the gathered partials with the spec's fold and publish the scalar to the other workgroups.  sbuf: HIPK_THREADS doubles.
+__device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double *sbuf, int *lds_ok) {
     if (threadIdx.x == 0) *lds_ok = 1;
     __syncthreads();
     if ((int)threadIdx.x < fx.world) {
@@ -110,6 +116,32 @@ __device__ __forceinline__ bool hipk_fx_wait(const hipk_fx &fx, int *lds_ok) {
     }
     __syncthreads();
     __threadfence_system();
-    return *lds_ok != 0;
+    const double v = hipk_reduce_parts(hipk_fx_parts(fx), g, sbuf);   // the only reads of the mailbox's partials on this rank
+    if (threadIdx.x == 0) {
+        __hip_atomic_store((unsigned long long *)&fx.loc_val[fx.kind * 2 + fx.ch], (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a failed wait publishes the flag too (the others must not spin for ever); the error word voids the solve
+        __hip_atomic_store(&fx.loc_flag[fx.kind], fx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// every workgroup: wait for the collector's flag, return the folded scalar of `kind` (this exchange's or an earlier one of the
+// same channel).  All threads must call it.
+__device__ __forceinline__ void hipk_fx_await(const hipk_fx &fx) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&fx.loc_flag[fx.kind], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < fx.seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                atomicExch(fx.err, 1);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double hipk_fx_scalar(const hipk_fx &fx, int kind) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)&fx.loc_val[kind * 2 + fx.ch], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
 }
 #endif
