@@ -888,3 +888,20 @@ extern "C" int hipk_spmv_ex(hipk_csr_t h, const void *x, void *y, int mode, cons
     a.it = it;
     return hipk_launch_spmv(h, a, (hipStream_t)stream);
 }
+
+#ifdef HIPK_GM_STAMPS
+// diagnostic twin only: the per-wavefront phase stamps of the last hipk_spmv_sell_wide_kernel launch (hipk_coded.h)
+extern "C" int hipk_debug_wide_stamps(unsigned long long *out, size_t count) {
+    const size_t have = sizeof(hipk_wide_stamps) / sizeof(unsigned long long);
+    HIPK_CHECK_HIP(hipDeviceSynchronize());
+    HIPK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk_wide_stamps), sizeof(unsigned long long) * (count < have ? count : have)));
+    return HIPK_OK;
+}
+extern "C" int hipk_debug_wide_stamps_clear(void) {
+    HIPK_CHECK_HIP(hipDeviceSynchronize());
+    void *p = nullptr;
+    HIPK_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(hipk_wide_stamps)));
+    HIPK_CHECK_HIP(hipMemset(p, 0, sizeof(hipk_wide_stamps)));
+    return HIPK_OK;
+}
+#endif

@@ -248,8 +248,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_fx_kernel(int6
     if (c == 0) hipk_fx_collect(fx, g, sbuf, &fx_ok);
     hipk_fx_await(fx);
     if (tail) {
-        __threadfence_system();
-        const double *halo = hipk_fx_halo(fx);
+        const double *halo = hipk_fx_halo(fx);   // fine-grained memory: read from memory, after the collector's flag
         const int64_t lo = ((int64_t)c * ch > n_own ? (int64_t)c * ch : n_own), hi = ((int64_t)(c + 1) * ch < n ? (int64_t)(c + 1) * ch : n);
         for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) r[i] = halo[i - n_own];
         __syncthreads();

@@ -926,6 +926,19 @@ __device__ __forceinline__ double hipk_half_tree2(double2 d) {  // sums of rows 
 //     ticket counter: it starts workgroups in ascending order as slots free up, so with short groups the tiles in flight in an XCD
 //     are one compact front whatever the drift, and the re-reads of x[row +- nx] come from workgroups in flight at the same time
 //     (the shape that works at N = 4 M, where a chunk IS 8 tiles): 0.53 GB fetched, 397 -> 273 us in the CG loop.
+// Diagnostic twin (make stamps, -DHIPK_GM_STAMPS): every wavefront of the kernel below records the constant 100 MHz clock
+// (s_memrealtime: comparable across compute units) at its phase boundaries; tools/spmv_stamps_probe.py prints where the time goes.
+#ifdef HIPK_GM_STAMPS
+#define HIPK_WIDE_NSTAMP 8
+__device__ unsigned long long hipk_wide_stamps[2048 * 4 * HIPK_WIDE_NSTAMP];
+#define HIPK_WSTAMP(k)                                                                                                   \
+    do {                                                                                                                 \
+        if (lane == 0 && blockIdx.x < 2048)                                                                              \
+            hipk_wide_stamps[((size_t)blockIdx.x * 4 + wave) * HIPK_WIDE_NSTAMP + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define HIPK_WSTAMP(k)
+#endif
 template <int UNITS, int MODE = -1, int WALK = 0>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
     typedef double T;
@@ -962,6 +975,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     const int *__restrict__ g_doff = a.dict_off;
     const T *__restrict__ g_dval = (const T *)a.dict_val;
 
+    HIPK_WSTAMP(0);
     unsigned long long uc_mine = 0ull, uc_more = 0ull;  // requested first: complete before the dictionary reaches LDS (loads
     if (lane < cnt) uc_mine = ucode[t_first + lane];                                                 // return in order)
     if (!STRIDED && tpc > 64 && lane + 64 < cnt) uc_more = ucode[t_first + 64 + lane];
@@ -974,7 +988,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
     if (a.stop_it != nullptr && a.it >= *a.stop_it) return;
     dval[t] = dv;  // slots >= n_codes, in particular HIPK_SELL_PAD: offset 0, value 0
     doff[t] = dofs;
+    HIPK_WSTAMP(1);
     __syncthreads();
+    HIPK_WSTAMP(2);
 
     // the chunk's `ucode` words: lane i of every wavefront holds tile t_first + i's (and t_first + 64 + i's for chunks of more
     // than 64 tiles), a tile's word is read into scalar registers with v_readlane (no memory round trip per tile)
@@ -1144,14 +1160,20 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
         if (tile_ucode_of(i) != 0ull) continue;
         per_lane_tile(t_first + i, i);
     }
+    HIPK_WSTAMP(3);
     // ---- the uniform tiles of this wavefront pair's parity
     for (int i = wp; i < cnt; i += 2) {
         const unsigned long long uc = tile_ucode_of(i);
         if (uc == 0ull) continue;
         uniform_tile(t_first + i, i, uc);
+#ifdef HIPK_GM_STAMPS
+        if (i == wp) HIPK_WSTAMP(4);   // after the first uniform tile
+#endif
     }
+    HIPK_WSTAMP(5);
     if (!STRIDED && (mode & (HIPK_SPMV_DOT_W | HIPK_SPMV_DOT_YY))) {
         __syncthreads();
+        HIPK_WSTAMP(6);
         if (wave == 0) {
             if (mode & HIPK_SPMV_DOT_W) {
                 const double r = hipk_wave_fold(wsum0, cnt, lane);
@@ -1163,5 +1185,6 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_
             }
         }
     }
+    HIPK_WSTAMP(7);
 }
 #endif

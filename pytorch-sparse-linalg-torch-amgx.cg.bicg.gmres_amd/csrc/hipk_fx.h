@@ -105,7 +105,7 @@ __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double
         const unsigned long long *flag =
             (const unsigned long long *)(fx.peer[fx.rank] + fx.off_flags) + (size_t)(fx.kind * 2 + fx.ch) * fx.world + threadIdx.x;
         unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < fx.seq) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < fx.seq) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) {   // seconds: a source never published -- report, do not hang
                 *lds_ok = 0;
@@ -115,13 +115,14 @@ __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double
         }
     }
     __syncthreads();
-    __threadfence_system();
+    // the mailbox is fine-grained (uncached) memory: the loads below go to memory, after the polls above have returned
     const double v = hipk_reduce_parts(hipk_fx_parts(fx), g, sbuf);   // the only reads of the mailbox's partials on this rank
     if (threadIdx.x == 0) {
         __hip_atomic_store((unsigned long long *)&fx.loc_val[fx.kind * 2 + fx.ch], (unsigned long long)__double_as_longlong(v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scalar has left before the flag goes
         // a failed wait publishes the flag too (the others must not spin for ever); the error word voids the solve
-        __hip_atomic_store(&fx.loc_flag[fx.kind], fx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fx.loc_flag[fx.kind], fx.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -130,7 +131,10 @@ __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double
 __device__ __forceinline__ void hipk_fx_await(const hipk_fx &fx) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(&fx.loc_flag[fx.kind], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < fx.seq) {
+        // RELAXED agent-scope loads (as hipk_handoff.h's hand-offs): an ACQUIRE here made every poll of every workgroup
+        // invalidate its L2 -- 605 us per iteration at 1954 workgroups.  The scalars are read with agent-scope loads as well,
+        // the collector drains its stores (s_waitcnt) between the scalar and the flag: no fence is needed on this side.
+        while (__hip_atomic_load(&fx.loc_flag[fx.kind], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fx.seq) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) {
                 atomicExch(fx.err, 1);
