@@ -48,7 +48,7 @@ static hipk_dist_layout hipk_dist_make_layout(const hipk_dist_plan *pl) {
     L.g_rr = take(W * per * 8);
     L.g_bb = take(W * per * 8);
     L.out4 = take(4 * 8);
-    L.fx_loc = take(8 * 8);   // fused exchanges: the collector's scalars [2][2] + sequence flags [2]
+    L.fx_loc = take(256 + 2 * 8 * 128);   // fused exchanges: the collector's scalars [2][2] + sequence flags [2][8 replicas x 128 B]
     L.send_buf = take((size_t)(pl->n_send > 0 ? pl->n_send : 1) * 8);
     L.slab_loc = take((size_t)(pl->slab > 0 ? pl->slab : 1) * 8);
     L.slab_all = take((size_t)(pl->slab > 0 ? pl->slab : 1) * W * 8);
@@ -233,7 +233,7 @@ extern "C" int hipk_dist_cg_solve(hipk_csr_t A, const hipk_dist_plan *pl, const 
         fx.dest_off = (const long long *)pl->dest_off_dev;
         fx.n_ghost = pl->n_ghost;
         fx.loc_val = (double *)(wk + L.fx_loc);
-        fx.loc_flag = (unsigned long long *)(wk + L.fx_loc) + 4;
+        fx.loc_flag = (unsigned long long *)(wk + L.fx_loc + 256);
         // (zeroed with the rest of the workspace header above: below every sequence number, which start at 1 and only grow)
     }
     struct fx_guard {   // every exit path tells the communicator how many exchanges were issued

@@ -37,7 +37,8 @@ struct hipk_fx {
     int n_ghost;
     // hand-off from the collector workgroup to the others: ordinary device memory (the solve's workspace)
     double *loc_val;              // [2 kinds][2 channels] folded scalars
-    unsigned long long *loc_flag; // [2 kinds] sequence number of the last exchange whose scalar is in loc_val
+    unsigned long long *loc_flag; // [2 kinds][8 replicas, 128 bytes apart]: sequence number of the last exchange whose scalar is in
+                                  // loc_val; workgroup b polls replica b % 8 (one line per XCD's workgroups instead of one for all)
     const int *send_idx;      // device: my local rows grouped by destination rank
     const int *send_off;      // device [world + 1]: bounds of each destination's group in send_idx
     const long long *dest_off;  // device [world]: where my group starts in each destination's ghost tail
@@ -122,7 +123,9 @@ __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scalar has left before the flag goes
         // a failed wait publishes the flag too (the others must not spin for ever); the error word voids the solve
-        __hip_atomic_store(&fx.loc_flag[fx.kind], fx.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 8) {
+        __hip_atomic_store(&fx.loc_flag[(fx.kind * 8 + threadIdx.x) * 16], fx.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -134,7 +137,8 @@ __device__ __forceinline__ void hipk_fx_await(const hipk_fx &fx) {
         // RELAXED agent-scope loads (as hipk_handoff.h's hand-offs): an ACQUIRE here made every poll of every workgroup
         // invalidate its L2 -- 605 us per iteration at 1954 workgroups.  The scalars are read with agent-scope loads as well,
         // the collector drains its stores (s_waitcnt) between the scalar and the flag: no fence is needed on this side.
-        while (__hip_atomic_load(&fx.loc_flag[fx.kind], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fx.seq) {
+        const unsigned long long *fl = &fx.loc_flag[(fx.kind * 8 + (blockIdx.x & 7)) * 16];
+        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fx.seq) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) {
                 atomicExch(fx.err, 1);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, call 8: per-phase stamps of the two-rows-per-lane coded SpMV (diagnostic twin)
 set -o pipefail
-O=gpurun_out/r03c8
+O=gpurun_out/r03c10
 mkdir -p $O
 export TMPDIR=/tmp
 L=$PWD/pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd/pytorch_sparse_solver/_lib

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, call 9: fused exchanges after the polling fix (parity subset, world-1 rehearsals), then the SpMV stamps
 set -o pipefail
-O=gpurun_out/r03c9
+O=gpurun_out/r03c10
 mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests/test_distributed_gloo.py -m gpu -x -q -k "fused" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.txt

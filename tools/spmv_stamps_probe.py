@@ -49,7 +49,17 @@ for rep in range(5):
           "per-lane tiles (grid-line ends)": us[:, :, 3] - us[:, :, 2], "first uniform tile": us[:, :, 4] - us[:, :, 3],
           "remaining uniform tiles": us[:, :, 5] - us[:, :, 4], "barrier before the fold": us[:, :, 6] - us[:, :, 5],
           "fold of the chunk partial": us[:, :, 7] - us[:, :, 6], "whole wavefront": us[:, :, 7] - us[:, :, 0]}
+    wg_start = us[:, :, 0].min(axis=1)
+    wg_end = us[:, :, 7].max(axis=1)
+    late = wg_start > 2.0
+    valid = (st[:, :, 4] != 0) & (st[:, :, 5] != 0)       # wavefronts that had a uniform tile of their parity
+    ph["remaining uniform tiles"] = (us[:, :, 5] - us[:, :, 4])[valid]
+    ph["first uniform tile"] = (us[:, :, 4] - us[:, :, 3])[valid]
     out = {"launch": rep, "workgroups": int(st.shape[0]), "kernel_span_us": float(us[:, :, 7].max()),
+           "workgroups_starting_after_2us": int(late.sum()), "their_start_us_min_median_max": [float(np.min(wg_start[late])), float(np.median(wg_start[late])), float(np.max(wg_start[late]))] if late.any() else None,
+           "end_of_the_on_time_workgroups_p50_p99_max_us": [float(np.percentile(wg_end[~late], q)) for q in (50, 99, 100)],
+           "workgroup_duration_on_time_vs_late_median_us": [float(np.median((wg_end - wg_start)[~late])), float(np.median((wg_end - wg_start)[late])) if late.any() else None],
+           "late_block_indices_sample": [int(i) for i in np.nonzero(late)[0][:24]],
            "start_p50_p90_max_us": [float(np.percentile(us[:, :, 0], q)) for q in (50, 90, 100)],
            "end_p10_p50_p90_us": [float(np.percentile(us[:, :, 7], q)) for q in (10, 50, 90)],
            "phases_median_p90_us": {k: [round(float(np.median(v)), 2), round(float(np.percentile(v, 90)), 2)] for k, v in ph.items()}}
