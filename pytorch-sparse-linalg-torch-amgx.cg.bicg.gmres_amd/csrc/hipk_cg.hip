@@ -198,7 +198,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
 // The update / direction kernels above with an exchange in front: workgroups 0 .. world-1 publish this rank's partials (and, in
 // the direction kernel, the boundary entries of r) into the peers' mailboxes, every workgroup waits for all sources and folds the
 // gathered partials straight from its own mailbox.  grid = max(chunks, world): surplus workgroups only publish and wait.
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_fx_kernel(int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal,
+__global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_cg_update_fx_kernel(int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal,
                                                                          int64_t it, const double *__restrict__ Ap, double *__restrict__ r,
                                                                          double *__restrict__ part_rr, hipk_fx fx) {
     typedef double T;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_update_fx_kernel(int64_t
 
 // n = n_ext (own rows + ghost tail), n_own = own rows.  The ghost entries of r arrive with the exchange: the workgroups whose chunk
 // reaches into the tail copy their part from the mailbox into r BEFORE they request their operands; everybody else requests first.
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_fx_kernel(int64_t n, int64_t n_own, int ch, int g,
+__global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 __attribute__((amdgpu_waves_per_eu(8, 8))) void hipk_cg_direction_fx_kernel(int64_t n, int64_t n_own, int ch, int g,
                                                                             hipk_cg_scal *__restrict__ scal, int64_t it, int64_t maxiter,
                                                                             double *__restrict__ r, double *__restrict__ p,
                                                                             double *__restrict__ x, hipk_fx fx) {

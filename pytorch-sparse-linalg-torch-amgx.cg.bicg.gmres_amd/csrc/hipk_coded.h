@@ -487,7 +487,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
 //   planes (plane k = the k-th entry of every row, coalesced, non-temporal): 9 instead of 12 bytes per entry and no
 //   row pointers, for stencils with variable coefficients.
 template <typename T, int UNITS, bool CHUNKED, bool VALS, bool UNI = false>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
+__global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_loop_kernel(hipk_spmv_args a) {
     constexpr int G0 = UNITS == 0 ? 2 : (UNITS + 3) / 4;  // groups of four codes held in registers (<= 2)
     static_assert(UNITS == 0 || UNITS <= 8, "exact instantiations cover up to 8 entries per row");
     const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
@@ -939,8 +939,11 @@ __device__ unsigned long long hipk_wide_stamps[2048 * 4 * HIPK_WIDE_NSTAMP];
 #else
 #define HIPK_WSTAMP(k)
 #endif
+// HIPK_SGPR80 (hipk_common.h): the 8-wide instantiations and the run-time-mode ones sat at 82-106 scalar registers (seven or six
+// workgroups per CU admitted); the stamps twin of the 5-wide one at 92 -- its first run showed workgroups 1792 .. 1953 starting 8 us
+// late, an artefact of the twin (the product kernel has 68).
 template <int UNITS, int MODE = -1, int WALK = 0>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
+__global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_kernel(hipk_spmv_args a) {
     typedef double T;
     constexpr bool STRIDED = WALK != 0;  // tile sums to the per-tile buffer, no in-kernel fold
     constexpr int G0 = (UNITS + 3) / 4;

@@ -473,7 +473,7 @@ __device__ __forceinline__ void hipk_block_sumN(double (&v)[NC], double *sbuf) {
 // bytes over a GMRES(30) cycle).  The column loads still go out in batches of eight (8 x 16 B per lane in flight) and the block
 // tree runs per batch of eight accumulators (16 KB of LDS whatever NC).  Per column the accumulation order is the spec's.
 template <typename T, int NC>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_gm_multidot_stream_kernel(
+__global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_gm_multidot_stream_kernel(
     int64_t n, int ch, hipk_gm_scal *__restrict__ scal, int k, int pass, const T *__restrict__ V, int64_t ldv,
     const T *__restrict__ w, double *__restrict__ part, int g, int nres) {
     if (k >= scal->stop_step) return;
