@@ -251,6 +251,26 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
                     e = hipMemcpyAsync(&h->n_uniform_tiles, ucount, sizeof(int), hipMemcpyDeviceToHost, stream);
                 if (e == hipSuccess)
                     e = hipMemcpyAsync(&h->uniform_units, ucount + 1, sizeof(int), hipMemcpyDeviceToHost, stream);
+                // masked tiles (hipk_tile_masked_kernel): pair codes in fp64 only (the two-rows-per-lane kernel's domain), code 254
+                // free for the marker; HIPK_SPMV_MASKED=0 skips the analysis
+                const char *menv = getenv("HIPK_SPMV_MASKED");
+                if (e == hipSuccess && !OFFS_ONLY && sizeof(T) == 8 && nc <= 254 && !(menv && menv[0] == '0')) {
+                    int *mcount = nullptr;
+                    e = hipMalloc((void **)&h->tile_wcode, sizeof(unsigned long long) * (size_t)ntiles + 2 * sizeof(int));
+                    if (e == hipSuccess) e = hipMalloc((void **)&h->row_mask, (size_t)ntiles * HIPK_TILE + 16);
+                    if (e == hipSuccess) {
+                        mcount = (int *)(h->tile_wcode + ntiles);
+                        e = hipMemsetAsync(mcount, 0, 2 * sizeof(int), stream);
+                    }
+                    if (e == hipSuccess) {
+                        hipk_tile_masked_kernel<<<(ntiles + 15) / 16, HIPK_THREADS, 0, stream>>>(h->code, h->tile_off, ntiles, h->n_rows,
+                                                                                     h->dict_off, h->tile_ucode, h->tile_wcode,
+                                                                                     h->row_mask, mcount);
+                        e = hipGetLastError();
+                    }
+                    if (e == hipSuccess) e = hipMemcpyAsync(&h->n_masked_tiles, mcount, sizeof(int), hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(&h->masked_units, mcount + 1, sizeof(int), hipMemcpyDeviceToHost, stream);
+                }
             }
         } else {
             (void)hipFree(tw);
@@ -281,6 +301,14 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
         h->n_uniform_tiles = 0;
         h->uniform_units = 0;
     }
+    if (h->tile_wcode && (fail || !h->tile_ucode || h->n_masked_tiles == 0)) {   // nothing gained: the kernels read tile_ucode
+        (void)hipFree(h->tile_wcode);
+        if (h->row_mask) (void)hipFree(h->row_mask);
+        h->tile_wcode = nullptr;
+        h->row_mask = nullptr;
+        h->n_masked_tiles = 0;
+        h->masked_units = 0;
+    }
     return hipSuccess;
 }
 
@@ -294,6 +322,12 @@ static void hipk_drop_coded(hipk_csr_s *h) {
     h->tile_ucode = nullptr;
     h->n_uniform_tiles = 0;
     h->uniform_units = 0;
+    if (h->tile_wcode) (void)hipFree(h->tile_wcode);
+    if (h->row_mask) (void)hipFree(h->row_mask);
+    h->tile_wcode = nullptr;
+    h->row_mask = nullptr;
+    h->n_masked_tiles = 0;
+    h->masked_units = 0;
     if (h->sell_vals) (void)hipFree(h->sell_vals);
     h->sell_vals = nullptr;
     h->tile_off = nullptr;
@@ -535,7 +569,9 @@ extern "C" int64_t hipk_csr_format_bytes(hipk_csr_t h) {
     const int64_t sv = (h->dtype == HIPK_F64) ? 8 : 4;
     // tiles whose rows share their code bytes: one 8-byte word per tile is read instead of their code planes
     const int64_t ntl = (h->n_rows + 255) / 256;
-    const int64_t uni = h->tile_ucode ? ntl * 8 - (int64_t)h->uniform_units * HIPK_TILE : 0;
+    // uniform tiles: one 8-byte word instead of their planes; masked tiles (two-rows-per-lane kernel): the word + 256 mask bytes
+    const int64_t uni = (h->tile_ucode ? ntl * 8 - (int64_t)h->uniform_units * HIPK_TILE : 0) +
+                        (h->tile_wcode ? (int64_t)h->n_masked_tiles * HIPK_TILE - (int64_t)h->masked_units * HIPK_TILE : 0);
     if (hipk_csr_spmv_path(h) == HIPK_PATH_OFFSET_CODED)  // code + value planes (+ plane offsets unless uniform) + x + y
         return h->sell_bytes * (1 + sv) + uni + (h->sell_w > 0 ? 0 : ntl * 8) + 2 * h->n_rows * sv;
     if (hipk_csr_spmv_path(h) == HIPK_PATH_CODED) {
@@ -622,6 +658,8 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         const bool sell = h->coded_layout >= 2;
         a.sell_vals = h->sell_vals;
         a.tile_ucode = h->tile_ucode;
+        a.tile_wcode = h->tile_wcode ? h->tile_wcode : h->tile_ucode;   // two-rows-per-lane kernel: uniform AND masked tiles
+        a.row_mask = h->row_mask;
         if (sell) {
             // persistent form: as many workgroups as can be resident (8 per CU), a multiple of 8 for the XCD mapping
             // exact tile size for the common stencil widths, run-time size otherwise
@@ -658,7 +696,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                 // (default: the chunks fill at least half of the slots; a quarter where the two-rows-per-lane kernel applies --
                 // N = 1.96 M Poisson: 28.2 -> 30.2 k CG it/s, no gain below a quarter)
                 static const bool chunked_env = getenv("HIPK_SPMV_SELL_CHUNKED") != nullptr;
-                const bool wide_ok = h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles && h->coded_layout == 2 &&
+                const bool wide_ok = h->dtype == HIPK_F64 && h->tile_ucode && 2 * (h->n_uniform_tiles + h->n_masked_tiles) >= ntiles && h->coded_layout == 2 &&
                                      (h->sell_w == 4 || h->sell_w == 5 || h->sell_w == 8);
                 const int cfac = (!chunked_env && wide_ok && h->sell_chunked == 2) ? 4 : h->sell_chunked;
                 chunked = h->sell_chunked != 0 && tpc <= HIPK_SELL_MAX_TPC && a.g <= slots && cfac * a.g >= slots;
@@ -744,7 +782,7 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
                             pk = h->tile_ucode ? hipk_spmv_sell_pair_kernel<double, 5, true, HIPK_SPMV_DOT_YY>
                                                : hipk_spmv_sell_pair_kernel<double, 5, false, HIPK_SPMV_DOT_YY>;
                         snprintf(pname, sizeof(pname), "hipk_spmv_sell_pair_kernel<%s,%d,%s,%d>", tname, h->sell_w, uni, pmode);
-                        if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * h->n_uniform_tiles >= ntiles)
+                        if (!no_wide && h->dtype == HIPK_F64 && h->tile_ucode && 2 * (h->n_uniform_tiles + h->n_masked_tiles) >= ntiles)
                             pk = pick_wide(0, pname, sizeof(pname));
                         int pocc = 0;  // the pair form holds more registers: take it only if the chunks still run as ONE round of workgroups
                         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, pk, HIPK_THREADS, 0) == hipSuccess &&

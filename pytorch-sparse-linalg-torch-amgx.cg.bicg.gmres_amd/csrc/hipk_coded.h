@@ -420,6 +420,100 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_uniform_kernel(const u
     }
 }
 
+// Masked tiles (round 3).  The stamps of the two-rows-per-lane kernel (profiles/r03_spmv_wide_stamps.md) show the tiles that
+// contain a grid-line end -- one in eight on the 2000-wide Poisson grid, taken one row per lane by the whole workgroup -- as what
+// spreads the workgroups' run times (median 10.5 us, last 15.2 us).  Their rows do not carry the same codes, but they differ only
+// by WHICH entries of one pattern they have (the row at a line's end lacks the east neighbour, the next one the west): each row's
+// code list is a SUBSEQUENCE of the tile's longest row's.  wcode[tile] = that pattern with byte 7 = HIPK_SELL_MASKED, mask[row] =
+// which of its entries the row has; the kernel forms all products of the pattern and SKIPS the absent ones with a select (same
+// products, same order of additions as the one-row-per-lane path: same bits).  Conditions: full tile, <= 7 entries per row,
+// every load of the pattern in range for every row pair (so not the tiles at the first / last grid line of the matrix).
+#define HIPK_SELL_MASKED 254u
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_tile_masked_kernel(const unsigned char *__restrict__ code,
+                                                                        const int *__restrict__ tile_off, int ntiles, int64_t n_rows,
+                                                                        const int *__restrict__ dict_off,
+                                                                        const unsigned long long *__restrict__ ucode,
+                                                                        unsigned long long *__restrict__ wcode,
+                                                                        unsigned char *__restrict__ mask, int *__restrict__ count) {
+    const int t = threadIdx.x;
+    __shared__ unsigned best[2];   // packed (length << 8 | 255 - t) of the longest row, its two code words below
+    __shared__ unsigned ucw[2];
+    int n_ok = 0, units_ok = 0;
+    for (int tl = blockIdx.x * 16; tl < ntiles && tl < blockIdx.x * 16 + 16; ++tl) {
+        const unsigned long long uc = ucode[tl];
+        if (uc != 0ull) {   // uniform: the same word, every entry present
+            if (t == 0) wcode[tl] = uc;
+            mask[(size_t)tl * HIPK_TILE + t] = 0xFF;
+            continue;
+        }
+        const int o0 = tile_off[tl], o1 = tile_off[tl + 1];
+        const int D = (o1 - o0) >> 2, Bp = (o1 - o0) & 3;
+        const unsigned char *tp = code + (size_t)o0 * HIPK_TILE;
+        unsigned c[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            unsigned w = 0xFFFFFFFFu;
+            if (g < D) {
+                w = ((const unsigned *)tp)[g * HIPK_TILE + t];
+            } else if (g == D) {
+                const unsigned char *bp = tp + (size_t)D * 1024 + t;
+                if (Bp >= 1) w = (w & 0xFFFFFF00u) | bp[0];
+                if (Bp >= 2) w = (w & 0xFFFF00FFu) | ((unsigned)bp[HIPK_TILE] << 8);
+            }
+            c[g] = w;
+        }
+        const int groups = D + (Bp > 0 ? 1 : 0);
+        int len = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (((c[k >> 2] >> ((k & 3) * 8)) & 0xFFu) != HIPK_SELL_PAD) len = k + 1;   // codes of a row are packed from entry 0
+        if (t == 0) best[0] = 0u;
+        __syncthreads();
+        atomicMax(&best[0], ((unsigned)len << 8) | (unsigned)(255 - t));
+        __syncthreads();
+        const int who = 255 - (int)(best[0] & 0xFFu), ulen = (int)(best[0] >> 8);
+        if (t == who) {
+            ucw[0] = c[0];
+            ucw[1] = c[1];
+        }
+        __syncthreads();
+        // greedy subsequence match of this row's codes against the pattern
+        unsigned m = 0u;
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned uk = (ucw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const unsigned cj = j < 8 ? ((c[j >> 2] >> ((j & 3) * 8)) & 0xFFu) : HIPK_SELL_PAD;
+            if (k < ulen && j < len && cj == uk) {
+                m |= 1u << k;
+                ++j;
+            }
+        }
+        int ok = (j == len) && groups >= 1 && groups <= 2 && ulen <= 7 && (int64_t)(tl + 1) * HIPK_TILE <= n_rows;
+        // every 16-byte load of the pattern in range for every row pair of the tile
+        if (t < ulen) {
+            const unsigned uk = (ucw[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
+            const int64_t off = dict_off[uk];
+            if ((int64_t)tl * HIPK_TILE + off < 0 || (int64_t)tl * HIPK_TILE + HIPK_TILE - 1 + off > n_rows - 1) ok = 0;
+        }
+        const int all = __syncthreads_and(ok);
+        mask[(size_t)tl * HIPK_TILE + t] = all ? (unsigned char)m : 0;
+        if (t == 0) {
+            wcode[tl] = all ? (((unsigned long long)ucw[0] | ((unsigned long long)ucw[1] << 32)) & 0x00FFFFFFFFFFFFFFull) |
+                                  ((unsigned long long)HIPK_SELL_MASKED << 56)
+                            : 0ull;
+            if (all) {
+                ++n_ok;
+                units_ok += o1 - o0;
+            }
+        }
+    }
+    if (t == 0 && n_ok > 0) {
+        atomicAdd(count, n_ok);
+        atomicAdd(count + 1, units_ok);
+    }
+}
+
 // code of row r, entry k -> its byte in r's tile (the planes are prefilled with HIPK_SELL_PAD)
 template <typename T, bool OFFS_ONLY>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_dict_encode_sell_kernel(
@@ -974,8 +1068,8 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
     T *__restrict__ y = (T *)a.y;
     const int mode = MODE >= 0 ? MODE : a.mode;
     const int n32 = (int)a.n;
-    const unsigned long long *__restrict__ ucode = a.tile_ucode;
-    const int *__restrict__ g_doff = a.dict_off;
+    const unsigned long long *__restrict__ ucode = a.tile_wcode;   // uniform and masked tiles (the launcher passes tile_ucode
+    const int *__restrict__ g_doff = a.dict_off;                   // where there is no masked analysis)
     const T *__restrict__ g_dval = (const T *)a.dict_val;
 
     HIPK_WSTAMP(0);
@@ -1084,7 +1178,10 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
         sbo[k] = 0;
         sv[k] = (T)0;
     }
-    auto uniform_tile = [&](int tl, int i, unsigned long long uc) {
+    auto uniform_tile = [&](int tl, int i, unsigned long long uc_in) {
+        // a MASKED tile: the rows have subsets of the pattern; the marker byte reads as padding below
+        const bool masked = (unsigned)(uc_in >> 56) == HIPK_SELL_MASKED;
+        const unsigned long long uc = masked ? (uc_in | 0xFF00000000000000ull) : uc_in;
         if (uc != cur) {
             cur = uc;
             kc = -1;
@@ -1119,14 +1216,17 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
         }
         if (mode & HIPK_SPMV_RESID) ob = *(const double2 *)((const char *)a.bsub + vo);
         if (mode & HIPK_SPMV_SCALE) od = *(const double2 *)((const char *)a.dscale + vo);
+        unsigned pm = 0xFFFFu;   // presence of the pattern's entries in rows 2l (low byte) and 2l + 1 (high byte)
+        if (masked) pm = *(const unsigned short *)(a.row_mask + r0);
         double2 s = {0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
             if (ck != HIPK_SELL_PAD) {
                 const double px = sv[k] * xv[k].x, py = sv[k] * xv[k].y;
-                s.x = s.x + px;
-                s.y = s.y + py;
+                const double sx = s.x + px, sy = s.y + py;
+                s.x = ((pm >> k) & 1u) ? sx : s.x;
+                s.y = ((pm >> (8 + k)) & 1u) ? sy : s.y;
             }
         }
         double2 out = s;

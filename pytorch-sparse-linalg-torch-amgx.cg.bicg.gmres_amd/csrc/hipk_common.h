@@ -114,6 +114,12 @@ struct hipk_csr_s {
     unsigned long long *tile_ucode;  // device, ntiles: code bytes shared by all 256 rows of a tile (0: rows differ);
     int n_uniform_tiles;             //   null unless enough tiles are uniform (constant-coefficient stencils)
     int uniform_units;               //   256-byte units of code planes the uniform tiles own (never read by the SpMV)
+    // round 3: tiles whose rows differ only by WHICH entries of one pattern they have (grid-line ends of a stencil): the
+    // two-rows-per-lane kernel takes them like uniform tiles, a per-row presence mask skipping the absent entries
+    unsigned long long *tile_wcode;  // device, ntiles: tile_ucode for uniform tiles; union pattern with byte 7 = HIPK_SELL_MASKED for
+                                     //   masked tiles; 0 otherwise (null: no such analysis)
+    unsigned char *row_mask;         // device, 256 * ntiles: bit k = entry k of the tile's pattern is present in this row
+    int n_masked_tiles, masked_units;
     int sell_w;             // uniform tile size in units of 256 B, or 0
     int64_t sell_bytes;     // bytes of all tiles
     int sell_loop;          // persistent sliced-ELL kernel: grid = sell_loop * 8 * n_cu workgroups (0: off)

@@ -61,6 +61,9 @@ struct hipk_spmv_args {
     int sell_w;           //   > 0: every tile has this size
     const void *sell_vals;  // offset-coded layout: value planes (same tile prefix as the code planes), else null
     const unsigned long long *tile_ucode;  // per tile: the 8 code bytes every row of the tile shares, 0 = rows differ
+    const unsigned long long *tile_wcode;  // two-rows-per-lane kernel: tile_ucode, or the union pattern of a MASKED tile (byte 7 =
+                                           //   HIPK_SELL_MASKED) whose rows have subsets of it (row_mask), or 0
+    const unsigned char *row_mask;         // per row of a masked tile: bit k = entry k of the pattern is present
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
     int group_tiles;        // hipk_spmv_sell_loop_kernel<.., CHUNKED = true>: > 0 = tiles per workgroup on a grid of groups (set by the
                             //   launcher), 0 = a workgroup per reduction chunk

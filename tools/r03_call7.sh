@@ -2,7 +2,7 @@
 # round 3, call 7: coded SpMV (two rows per lane) with the uniform tiles BEFORE the dictionary barrier (scalar dictionary loads)
 # against the committed kernel (library twin libhipk_head.so), same box, alternating; parity of the new one first
 set -o pipefail
-O=gpurun_out/r03c7
+O=gpurun_out/r03c12
 mkdir -p $O
 export TMPDIR=/tmp
 L=$PWD/pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd/pytorch_sparse_solver/_lib
