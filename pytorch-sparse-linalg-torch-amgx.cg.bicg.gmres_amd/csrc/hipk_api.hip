@@ -252,9 +252,11 @@ static hipError_t hipk_build_coded(hipk_csr_s *h, hipStream_t stream) {
                 if (e == hipSuccess)
                     e = hipMemcpyAsync(&h->uniform_units, ucount + 1, sizeof(int), hipMemcpyDeviceToHost, stream);
                 // masked tiles (hipk_tile_masked_kernel): pair codes in fp64 only (the two-rows-per-lane kernel's domain), code 254
-                // free for the marker; HIPK_SPMV_MASKED=0 skips the analysis
+                // free for the marker.  OPT-IN (HIPK_SPMV_MASKED=1): bit-identical, but measured SLOWER where it was meant to help
+                // (N = 4 M: 15.7-16.2 vs 14.6-14.9 us stand-alone, CG 17.6 vs 17.97 k it/s; N = 1.96 M: equal;
+                // profiles/r03_spmv_wide_stamps.md section 4)
                 const char *menv = getenv("HIPK_SPMV_MASKED");
-                if (e == hipSuccess && !OFFS_ONLY && sizeof(T) == 8 && nc <= 254 && !(menv && menv[0] == '0')) {
+                if (e == hipSuccess && !OFFS_ONLY && sizeof(T) == 8 && nc <= 254 && menv && menv[0] == '1') {
                     int *mcount = nullptr;
                     e = hipMalloc((void **)&h->tile_wcode, sizeof(unsigned long long) * (size_t)ntiles + 2 * sizeof(int));
                     if (e == hipSuccess) e = hipMalloc((void **)&h->row_mask, (size_t)ntiles * HIPK_TILE + 16);

@@ -279,7 +279,8 @@ def _spmv_ex_mode(hipk, h, mode, x, w, b):
 @pytest.mark.parametrize("offsets", [[-1, 0, 1], [-1500, -1, 0, 1], [-1500, -1, 0, 1, 1500], [-1500, -1, 1, 1500],
                                      [-9000, -1500, -1, 0, 1, 1500, 9000], [-9000, -1500, -2, -1, 0, 1, 1500, 9000]])
 @pytest.mark.parametrize("strided", ["0", "1"])
-def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeypatch):
+@pytest.mark.parametrize("masked", ["0", "1"])
+def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, masked, monkeypatch):
     """strided = 1: the kernel's grouped walk (one workgroup per 4 consecutive tiles on an ordinary grid, tile sums through
     hipk_tile_combine_kernel) -- what row blocks of few large chunks and systems of N > 16 M take -- forced here at a size the
     CPU oracle checks in seconds.
@@ -290,6 +291,9 @@ def test_uniform_tiles_two_rows_per_lane(hipk, oracle, offsets, strided, monkeyp
     residual form with both dots -- against the plain CSR kernels bit for bit, y against the oracle."""
     n = 2_200_077
     monkeypatch.setenv("HIPK_SPMV_SELL_STRIDED", strided)
+    # masked = 1 (opt-in, round 3): tiles whose rows have SUBSETS of one pattern (the band's first / last rows, a partial pattern)
+    # go through the two-rows-per-lane path as well, absent entries skipped by a per-row presence mask
+    monkeypatch.setenv("HIPK_SPMV_MASKED", masked)
     crow, col, val = banded(n, offsets, lambda r, k: 1.5 + 0.25 * k)
     h = make_handle(hipk, crow, col, val, n)
     g = torch.Generator(device=DEV).manual_seed(5)
