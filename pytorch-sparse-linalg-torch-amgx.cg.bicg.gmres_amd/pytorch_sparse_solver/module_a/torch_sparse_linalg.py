@@ -438,8 +438,37 @@ def _gmres_flat(P: _Flat, atol_eff, ptol, restart, maxiter, incremental: bool):
 
 
 # ------------------------------------------------------------------------- public wrappers
+def _flat_tree_operands(A, b, x0):
+    """A device MATRIX with PyTree right-hand sides (`b` a dict / tuple / list of device tensors -- or a tensor that is not
+    1-D): `_normalize_matvec` applies a matrix to the concatenation of the leaves (TSL:186-205), so the solve is the flat one.
+    Returns (b_flat, x0_flat, unravel) for the fast path, or None when the operands are not of that kind.  Same structure
+    errors as the generic path."""
+    if not (isinstance(A, torch.Tensor) and A.is_cuda and A.ndim == 2 and not torch.is_complex(A)):
+        return None
+    if isinstance(b, torch.Tensor) and b.ndim == 1:
+        return None
+    leaves = tree_leaves(b)
+    if not leaves or not all(isinstance(v, torch.Tensor) and v.device == A.device and not torch.is_complex(v) for v in leaves):
+        return None
+    if x0 is not None:
+        xl = tree_leaves(x0)
+        if len(xl) != len(leaves):
+            raise ValueError('x0 and b must have matching tree structure')
+        for bv, xv in zip(leaves, xl):
+            if not isinstance(xv, torch.Tensor) or xv.device != A.device or torch.is_complex(xv):
+                return None
+            if bv.shape != xv.shape:
+                raise ValueError(f'arrays in x0 and b must have matching shapes: {xv.shape} vs {bv.shape}')
+    bf, unravel = tree_ravel(b)
+    return bf, (None if x0 is None else tree_ravel(x0)[0]), unravel
+
+
 def _isolve(kind: str, A, b, x0, tol, atol, maxiter, M):
     """Shared CG/BiCGStab wrapper (`_isolve`, TSL:968-1016)."""
+    flat = _flat_tree_operands(A, b, x0)
+    if flat is not None and (M is None or M is _identity or _jacobi_of(M) is not None):
+        x, info = _isolve(kind, A, flat[0], flat[1], tol, atol, maxiter, M)     # the flat solve on the fast path
+        return flat[2](x), info
     if _fast_ok(A, b, x0, M):
         return _fast_solve(kind, A, b, x0, tol, atol, maxiter)
     if _jacobi_of(M) is not None and _fast_ok(A, b, x0, None):
@@ -600,6 +629,10 @@ def _gmres_impl(A, b, x0, tol, atol, restart, maxiter, M, solve_method):
     # the device-resident GMRES keeps at most 255 basis vectors (restart <= 31: H in the header block and the small-system
     # one-launch kernels; beyond: H in a workspace block, launch sequences); larger Krylov
     # spaces take the generic path (documented routing rule, not a fallback on failure; warned about once)
+    flat = _flat_tree_operands(A, b, x0)
+    if flat is not None and (M is None or M is _identity or _jacobi_of(M) is not None):
+        x, info = _gmres_impl(A, flat[0], flat[1], tol, atol, restart, maxiter, M, solve_method)
+        return flat[2](x), info
     _warn_restart_route(A, b, x0, restart)
     if _fast_ok(A, b, x0, M) and 1 <= restart <= _HIP_MAX_RESTART:
         return _fast_solve('gmres', A, b, x0, tol, atol, maxiter, restart=restart, solve_method=solve_method)
