@@ -660,10 +660,6 @@ int hipk_launch_spmv(const hipk_csr_s *h, const hipk_spmv_args &a_, hipStream_t 
         const bool sell = h->coded_layout >= 2;
         a.sell_vals = h->sell_vals;
         a.tile_ucode = h->tile_ucode;
-        {
-            static const int pf_env = getenv("HIPK_SPMV_SELL_PF") ? atoi(getenv("HIPK_SPMV_SELL_PF")) : 1;
-            a.sell_pair_prefetch = pf_env;
-        }
         a.tile_wcode = h->tile_wcode ? h->tile_wcode : h->tile_ucode;   // two-rows-per-lane kernel: uniform AND masked tiles
         a.row_mask = h->row_mask;
         if (sell) {

@@ -1178,10 +1178,9 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
         sbo[k] = 0;
         sv[k] = (T)0;
     }
-    // a uniform (or masked) tile in three steps, so that the grouped walk can keep TWO tiles' loads in flight per wavefront pair
-    auto ut_decode = [&](unsigned long long uc_in, bool &masked) -> unsigned long long {
+    auto uniform_tile = [&](int tl, int i, unsigned long long uc_in) {
         // a MASKED tile: the rows have subsets of the pattern; the marker byte reads as padding below
-        masked = (unsigned)(uc_in >> 56) == HIPK_SELL_MASKED;
+        const bool masked = (unsigned)(uc_in >> 56) == HIPK_SELL_MASKED;
         const unsigned long long uc = masked ? (uc_in | 0xFF00000000000000ull) : uc_in;
         if (uc != cur) {
             cur = uc;
@@ -1197,20 +1196,14 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
                                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
             }
         }
-        return uc;
-    };
-    auto ut_load = [&](int tl, unsigned long long uc, double2(&xv)[NE]) {
         const int r0 = tl * HIPK_TILE + wh * 128 + 2 * lane;
         const unsigned vo = (unsigned)r0 * (unsigned)sizeof(T);
+        double2 xv[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const unsigned ck = (unsigned)(uc >> (8 * k)) & 0xFFu;
             if (ck != HIPK_SELL_PAD) xv[k] = *(const double2 *)(xb + sbo[k] + vo);
         }
-    };
-    auto ut_finish = [&](int tl, int i, unsigned long long uc, bool masked, double2(&xv)[NE]) {
-        const int r0 = tl * HIPK_TILE + wh * 128 + 2 * lane;
-        const unsigned vo = (unsigned)r0 * (unsigned)sizeof(T);
         double2 ow = {0.0, 0.0}, ob = {0.0, 0.0}, od = {0.0, 0.0};
         if (mode & HIPK_SPMV_DOT_W) {
             if (w_is_x && kc >= 0) {
@@ -1264,13 +1257,6 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
             }
         }
     };
-    auto uniform_tile = [&](int tl, int i, unsigned long long uc_in) {
-        bool masked;
-        const unsigned long long uc = ut_decode(uc_in, masked);
-        double2 xv[NE];
-        ut_load(tl, uc, xv);
-        ut_finish(tl, i, uc, masked, xv);
-    };
 
     // ---- the tiles whose rows differ first, whole workgroup
     for (int i = 0; i < cnt; ++i) {
@@ -1279,27 +1265,7 @@ __global__ __launch_bounds__(HIPK_THREADS) HIPK_SGPR80 void hipk_spmv_sell_wide_
     }
     HIPK_WSTAMP(3);
     // ---- the uniform tiles of this wavefront pair's parity
-    bool paired = false;
-    if constexpr (WALK == 1) {
-        // grouped walk (systems whose vectors live in HBM, row blocks of a partition): the pair's two tiles of the group with BOTH
-        // tiles' loads in flight before the first product (round 3; same products, same sums).  Only when the two carry the same pattern
-        static_assert(HIPK_SELL_GROUP == 4, "a wavefront pair owns tiles wp and wp + 2 of its group");
-        const int i0 = wp, i1 = wp + 2;
-        if (a.sell_pair_prefetch && i1 < cnt) {
-            const unsigned long long u0 = tile_ucode_of(i0), u1 = tile_ucode_of(i1);
-            if (u0 != 0ull && u0 == u1) {
-                bool masked;
-                const unsigned long long uc = ut_decode(u0, masked);
-                double2 xa[NE], xc[NE];
-                ut_load(t_first + i0, uc, xa);
-                ut_load(t_first + i1, uc, xc);
-                ut_finish(t_first + i0, i0, uc, masked, xa);
-                ut_finish(t_first + i1, i1, uc, masked, xc);
-                paired = true;
-            }
-        }
-    }
-    for (int i = wp; i < cnt && !paired; i += 2) {
+    for (int i = wp; i < cnt; i += 2) {
         const unsigned long long uc = tile_ucode_of(i);
         if (uc == 0ull) continue;
         uniform_tile(t_first + i, i, uc);

@@ -67,7 +67,6 @@ struct hipk_spmv_args {
     const void *dscale;     // HIPK_SPMV_SCALE: row scaling vector
     int group_tiles;        // hipk_spmv_sell_loop_kernel<.., CHUNKED = true>: > 0 = tiles per workgroup on a grid of groups (set by the
                             //   launcher), 0 = a workgroup per reduction chunk
-    int sell_pair_prefetch; // two-rows-per-lane kernel, grouped walk: both tiles of a wavefront pair in flight (HIPK_SPMV_SELL_PF, launcher)
     int skip_combine;       // small systems: leave the fused dots as per-wavefront tile sums (hipk_csr_s::tile_part); the
                             //   consumer folds them itself (hipk_fold_tiles8) -- one launch less per SpMV
 };
