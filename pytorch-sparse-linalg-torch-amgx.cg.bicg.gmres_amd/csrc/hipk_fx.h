@@ -9,9 +9,9 @@
 //     rank, a partials array laid out exactly like the global chunk-partial array the kernels fold (rank s owns entries
 //     s * per ...), and -- kind 1 -- a halo array laid out exactly like the rank's ghost tail;
 //   * the CONSUMER kernel of the exchange (update / direction, FX kernels in hipk_cg.hip) starts with: workgroups 0 .. world-1
-//     PUBLISH -- workgroup q stores this rank's partials (written by the previous kernel on the stream) and the boundary
-//     entries of r that rank q's rows reference into q's mailbox with system-scope stores, fences, then stores the exchange's
-//     sequence number into its flag there.  Workgroup 0 is also the COLLECTOR: it polls the `world` flags of its own mailbox
+//     PUBLISH -- workgroup q (q != this rank) stores this rank's partials (written by the previous kernel on the stream) and the
+//     boundary entries of r that rank q's rows reference into q's mailbox with system-scope stores, fences, then stores the
+//     exchange's sequence number into its flag there (the rank's own partials stay where they are: the collector reads them in place).  Workgroup 0 is also the COLLECTOR: it polls the `world` flags of its own mailbox
 //     (one lane per source, bounded), folds the gathered partials -- the spec's fold, once -- and hands the SCALAR to the other
 //     workgroups through a word of ordinary device memory (agent-scope store + sequence flag); they poll that flag and read
 //     the scalar.  (First version: every workgroup polled the mailbox and folded from it -- 1954 workgroups x 31 KB of
@@ -80,7 +80,7 @@ __device__ __forceinline__ const double *hipk_fx_halo(const hipk_fx &fx) {
 // workgroups 0 .. world-1 (all their threads): publish to rank blockIdx.x.  Others: nothing.
 __device__ __forceinline__ void hipk_fx_publish(const hipk_fx &fx) {
     const int q = blockIdx.x;
-    if (q >= fx.world) return;
+    if (q >= fx.world || q == fx.rank) return;   // this rank's own partials never leave its memory: the collector reads them in place
     char *box = fx.peer[q];
     double *dp = (double *)(box + fx.off_parts) + ((size_t)(fx.kind * 2 + fx.ch) * fx.world + fx.rank) * fx.per;
     for (int i = threadIdx.x; i < fx.per; i += blockDim.x) hipk_fx_store(dp + i, fx.parts[i]);
@@ -102,7 +102,7 @@ __device__ __forceinline__ void hipk_fx_publish(const hipk_fx &fx) {
 __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double *sbuf, int *lds_ok) {
     if (threadIdx.x == 0) *lds_ok = 1;
     __syncthreads();
-    if ((int)threadIdx.x < fx.world) {
+    if ((int)threadIdx.x < fx.world && (int)threadIdx.x != fx.rank) {
         const unsigned long long *flag =
             (const unsigned long long *)(fx.peer[fx.rank] + fx.off_flags) + (size_t)(fx.kind * 2 + fx.ch) * fx.world + threadIdx.x;
         unsigned spins = 0;
@@ -116,8 +116,18 @@ __device__ __forceinline__ void hipk_fx_collect(const hipk_fx &fx, int g, double
         }
     }
     __syncthreads();
-    // the mailbox is fine-grained (uncached) memory: the loads below go to memory, after the polls above have returned
-    const double v = hipk_reduce_parts(hipk_fx_parts(fx), g, sbuf);   // the only reads of the mailbox's partials on this rank
+    // hipk_reduce_parts over the gathered array -- thread t adds partials t, t + 256, ... in ascending order, then the block tree --
+    // with this rank's own entries taken from where the previous kernel wrote them and the peers' from the mailbox (fine-grained
+    // memory: those loads go to memory, after the polls above have returned; the only reads of the mailbox's partials on this rank)
+    const double *mb = hipk_fx_parts(fx);
+    const int own0 = fx.rank * fx.per;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < HIPK_MAX_PARTS / HIPK_THREADS; ++k) {
+        const int i = (int)threadIdx.x + k * HIPK_THREADS;
+        if (i < g) acc = acc + ((i >= own0 && i < own0 + fx.per) ? fx.parts[i - own0] : mb[i]);
+    }
+    const double v = hipk_block_sum(acc, sbuf);
     if (threadIdx.x == 0) {
         __hip_atomic_store((unsigned long long *)&fx.loc_val[fx.kind * 2 + fx.ch], (unsigned long long)__double_as_longlong(v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
