@@ -194,6 +194,171 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     }
 }
 
+// ---- TWO launches per iteration for launch-bound mid-size systems (33 .. 256 reduction chunks: 65 k < n <= 524 k) ----------------
+// Above the one-launch kernels' size an iteration of three launches costs ~15 us whatever the three kernels move (a dependent
+// launch is ~4.5 us end to end on MI355X: hipk_tile_combine_kernel, one wavefront per chunk, averages 4.6 us in the profiles).
+// The direction step is folded into the SpMV: K1(k) folds <r,r> of iteration k-1 (every workgroup, the same bits), does the stop
+// test and the gamma bookkeeping, forms p_k = r + beta p_{k-1} ON THE FLY at the gathered columns (the owner's formula on the
+// owner's operands: the bits the direction kernel would have stored), writes its own rows of p_k into the OTHER p buffer and
+// Ap_k, and leaves the per-wavefront tile sums of <p_k, Ap_k>; K2(k) folds them, alpha, x += alpha p_k, r -= alpha Ap_k, <r,r>
+// partials.  Same operations, same order per element as the three-launch sequence: same bits
+// (tests/test_gpu_api.py::test_cg_two_launch_iteration_is_bit_identical).  General CSR tiles (the FAST form of hipk_spmv_kernel:
+// every tile fits the LDS product buffer, no long rows), also for matrices that have a coded form: at these sizes the matrix
+// comes from L2 / the Infinity Cache and the kernel is launch-bound either way.
+struct hipk_cg2_args {
+    const int *crow;
+    const int *col;
+    const void *val;
+    int64_t n;
+    int ch, g;
+    hipk_cg_scal *scal;
+    int64_t it, maxiter;
+    const double *part_rr;   // chunk partials of <r,r> (K2 of the iteration before; unused at it == 0)
+    const void *r;
+    const void *p_old;
+    void *p_new;
+    void *Ap;
+    double *tpart;           // per-wavefront tile sums of <p, Ap>, 4 per tile
+};
+
+template <typename T, int CAP>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg2_spmv_kernel(hipk_cg2_args a) {
+    constexpr int NI = CAP / HIPK_THREADS;
+    const int ntiles = (int)((a.n + HIPK_TILE - 1) / HIPK_TILE);
+    const int tile = hipk_xcd_tile(blockIdx.x, ntiles);
+    __shared__ __attribute__((aligned(16))) T prod[CAP];
+    __shared__ int crowL[HIPK_TILE + 1];
+    __shared__ double sbuf[HIPK_THREADS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int *__restrict__ crow = a.crow;
+    const int *__restrict__ col = a.col;
+    const T *__restrict__ val = (const T *)a.val;
+    const T *__restrict__ r = (const T *)a.r;
+    const T *__restrict__ po = (const T *)a.p_old;
+    hipk_cg_scal *scal = a.scal;
+    const int64_t it = a.it;
+    const int64_t r0 = (int64_t)(tile < 0 ? 0 : tile) * HIPK_TILE;
+    const int nr = tile < 0 ? 0 : (int)((a.n - r0 < HIPK_TILE) ? (a.n - r0) : HIPK_TILE);
+    int crow_t = 0, crow_e = 0;
+    T rrow = (T)0, prow = (T)0;
+    if (t < nr) {
+        crow_t = crow[r0 + t];
+        rrow = r[r0 + t];
+        prow = po[r0 + t];
+    }
+    if (t == 0 && nr > 0) crow_e = crow[r0 + nr];
+    if (it >= scal->stop_it) return;
+    // <r,r> of the iteration before -> gamma_it, beta, the stop test of THIS pass (TSL:841, 851-853); every workgroup the same bits
+    T beta = (T)0;
+    if (it > 0) {
+        const double gamma = hipk_reduce_parts(a.part_rr, a.g, sbuf);
+        const double gamma_prev = scal->gamma[(it - 1) & 1];
+        beta = (T)(gamma / gamma_prev);  // TSL:851
+        const bool done = (it >= a.maxiter || gamma <= scal->atol2);
+        if (blockIdx.x == 0 && t == 0) {
+            scal->gamma[it & 1] = gamma;  // TSL:853
+            if (done) scal->stop_it = it;
+            hipk_signal(scal->host_sig, done ? (HIPK_SIG_STOP | it) : it);
+        }
+        if (done) return;
+    }
+    if (tile < 0) return;
+    if (t < nr) crowL[t] = crow_t;
+    if (t == 0) crowL[nr] = crow_e;
+    __syncthreads();
+    const int j0 = crowL[0];
+    const int cnt = crowL[nr] - j0;
+    if (cnt > 0) {
+        const int jb = __builtin_amdgcn_readfirstlane(j0);
+        const int *__restrict__ colb = col + jb;
+        const T *__restrict__ valb = val + jb;
+        unsigned jj[NI];
+        int cc[NI];
+        T vv[NI], rv[NI], pv[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = t + i * HIPK_THREADS;
+            jj[i] = (unsigned)(j < cnt ? j : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cc[i] = colb[jj[i]];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vv[i] = valb[jj[i]];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            rv[i] = r[cc[i]];
+            pv[i] = po[cc[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const T m = beta * pv[i];
+            const T pj = rv[i] + m;  // TSL:852 at column cc[i]: the bits its owner stores
+            prod[t + i * HIPK_THREADS] = vv[i] * pj;
+        }
+    }
+    __syncthreads();
+    double d0 = 0.0;
+    if (t < nr) {
+        const int lo = crowL[t] - j0, len = crowL[t + 1] - j0 - lo;
+        T s = (T)0;
+        for (int j = 0; j < len; ++j) s = s + prod[lo + j];
+        const T m = beta * prow;
+        const T pn = rrow + m;  // TSL:852, own row
+        ((T *)a.p_new)[r0 + t] = pn;
+        ((T *)a.Ap)[r0 + t] = s;
+        d0 = (double)pn * (double)s;
+    }
+    d0 = hipk_wave_sum(d0);
+    if (lane == 0) a.tpart[(size_t)tile * 4 + wave] = d0;
+}
+
+// K2: <p,Ap> from the tile sums (the combine kernel's chunk fold, then the spec's fold of the chunk partials), alpha,
+// x += alpha p, r -= alpha Ap, partials of <r,r>.  grid = chunks (<= 256).
+template <typename T>
+__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg2_update_kernel(int64_t n, int ch, int g, const hipk_cg_scal *__restrict__ scal,
+                                                                      int64_t it, const double *__restrict__ tpart, int ntiles,
+                                                                      const T *__restrict__ Ap, const T *__restrict__ p,
+                                                                      T *__restrict__ r, T *__restrict__ x,
+                                                                      double *__restrict__ part_rr) {
+    const int c = blockIdx.x;
+    hipk_pre<T, 2, false> pre;
+    pre.issue(n, ch, c, {Ap, (const T *)r});
+    if (it >= scal->stop_it) return;
+    __shared__ double sbuf[HIPK_THREADS];
+    __shared__ double cp[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tpc = ch / HIPK_TILE;
+    for (int k = wave; k < g; k += HIPK_THREADS / 64) {
+        const int first = k * tpc;
+        const int cnt = (ntiles - first < tpc) ? ntiles - first : tpc;
+        const double rk = hipk_wave_fold(tpart + (size_t)first * 4, cnt, lane);
+        if (lane == 0) cp[k] = rk;
+    }
+    __syncthreads();
+    const double pAp = hipk_reduce_parts(cp, g, sbuf);
+    const double gamma = scal->gamma[it & 1];
+    const T alpha = (T)(gamma / pAp);  // TSL:846
+    double acc = 0.0;
+    pre.run([&](int64_t i, int nv, T(&v)[2][hipk_vec<T>::VEC]) {
+        constexpr int VEC = hipk_vec<T>::VEC;
+        T rv[VEC], xv[VEC], pv[VEC];
+        hipk_ld<T>(p, i, nv, pv);
+        hipk_ld<T>((const T *)x, i, nv, xv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T m0 = alpha * pv[k];
+            xv[k] = xv[k] + m0;  // TSL:847
+            const T m1 = alpha * v[0][k];
+            rv[k] = v[1][k] - m1;  // TSL:848
+            if (k < nv) acc = fma((double)rv[k], (double)rv[k], acc);  // TSL:850
+        }
+        hipk_st<T>(x, i, nv, xv);
+        hipk_st<T>(r, i, nv, rv);
+    });
+    acc = hipk_block_sum(acc, sbuf);
+    if (threadIdx.x == 0) part_rr[c] = acc;
+}
+
 // ---- row-partitioned CG with the exchanges folded into the kernels (hipk_fx.h; hipk_dist.hip drives them) -----------------
 // The update / direction kernels above with an exchange in front: workgroups 0 .. world-1 publish this rank's partials (and, in
 // the direction kernel, the boundary entries of r) into the peers' mailboxes, every workgroup waits for all sources and folds the
@@ -746,7 +911,9 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_sca
 extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
-    return 256 + hipk_scratch_bytes() + 3 * vec;
+    // r, p, Ap; mid-size systems (two launches per iteration) a second p: the direction step is formed while the old p is gathered
+    const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
+    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= 256) ? 1 : 0)) * vec;
 }
 
 template <typename T>
@@ -898,7 +1065,44 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             if (hs0.stop_it <= it || it >= maxiter) break;
         }
     }
-    for (; !lds_loop && it < maxiter; ++it) {
+    // launch-bound mid-size systems: TWO launches per iteration (hipk_cg2_spmv_kernel / hipk_cg2_update_kernel above)
+    constexpr int kCap2 = sizeof(T) == 8 ? 1280 : 2048;
+    const bool two_launch = !lds_loop && !small && gm.g > 32 && gm.g <= 256 && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+                            A->crow != nullptr && A->max_tile_nnz <= kCap2 && A->max_row_len <= HIPK_LONG_ROW && prm->profile == 0 &&
+                            it == 0 && !(getenv("HIPK_CG_TWO_LAUNCH") && getenv("HIPK_CG_TWO_LAUNCH")[0] == '0') &&
+                            hipk_cg_work_bytes(n, A->dtype) >= 256 + hipk_scratch_bytes() + 4 * vec;
+    if (two_launch) {
+        T *pbuf[2] = {p, (T *)((char *)Ap + vec)};   // p_0 = r_0 sits in pbuf[0] (start kernel); pass k reads pbuf[k & 1], writes the other
+        hipk_cg2_args ca;
+        ca.crow = A->crow;
+        ca.col = A->col;
+        ca.val = A->val;
+        ca.n = n;
+        ca.ch = gm.ch;
+        ca.g = gm.g;
+        ca.scal = scal;
+        ca.maxiter = maxiter;
+        ca.part_rr = part_b;
+        ca.r = r;
+        ca.Ap = Ap;
+        ca.tpart = A->tile_part;
+        const int grid1 = ((ntiles + 7) >> 3) << 3;
+        // pass `maxiter` is bookkeeping only (its K1 folds the last <r,r>, sets the stop word and gamma: TSL:841 "k >= maxiter")
+        for (; it <= maxiter; ++it) {
+            HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
+            if (stop <= it) break;
+            ca.it = it;
+            ca.p_old = pbuf[it & 1];
+            ca.p_new = pbuf[(it + 1) & 1];
+            hipk_cg2_spmv_kernel<T, kCap2><<<grid1, HIPK_THREADS, 0, stream>>>(ca);
+            if (it < maxiter)
+                hipk_cg2_update_kernel<T><<<gm.g, HIPK_THREADS, 0, stream>>>(n, gm.ch, gm.g, scal, it, A->tile_part, ntiles, Ap,
+                                                                            (const T *)pbuf[(it + 1) & 1], r, x, part_b);
+            if ((it & 63) == 63) HIPK_CHECK_HIP(hipGetLastError());
+        }
+        if (it > maxiter) it = maxiter;
+    }
+    for (; !lds_loop && !two_launch && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;
         {

@@ -798,3 +798,51 @@ def test_pytree_right_hand_sides_stay_on_the_hip_path(hipk):
         cg(A, tree(bf), x0={"u": x0f[:500].reshape(20, 25)})
     with pytest.raises(ValueError, match="matching shapes"):
         cg(A, tree(bf), x0={"u": x0f[:500].reshape(25, 20), "v": (x0f[500:900], [x0f[900:]])})
+
+
+@pytest.mark.gpu
+def test_cg_two_launch_iteration_is_bit_identical(hipk, oracle, monkeypatch):
+    """Launch-bound mid-size systems (33 .. 256 reduction chunks) run CG with TWO launches per iteration: the direction step is
+    formed on the fly inside the SpMV (hipk_cg2_spmv_kernel / hipk_cg2_update_kernel).  Same bits as the three-launch sequence --
+    x, iteration count, info, true and recurrence residuals -- for fp64 and fp32 storage, warm starts, maxiter cut-offs (even and
+    odd, 0 and 1), a stop at iteration 0; and, on one system, as the CPU oracle."""
+    from pytorch_sparse_solver.module_a import get_last_stats
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr, create_variable_diffusion_2d_csr
+    cases = [(create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-8)),                       # 44 chunks
+             (create_poisson_2d_csr(500, 500, device=DEV), dict(tol=1e-6)),                       # 123 chunks
+             (create_poisson_2d_csr(700, 724, device=DEV), dict(tol=1e-5)),                       # 248 chunks, ragged last chunk
+             (create_variable_diffusion_2d_csr(400, 300, device=DEV), dict(tol=1e-7)),            # values differ per entry
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=37)),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=38)),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=1)),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=0)),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=0.5))]                         # b = A x0 below: stops at iteration 0
+    for idx, (A, kw) in enumerate(cases):
+        for dt in (torch.float64, torch.float32):
+            Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
+            h = hipk.handle_for(Ad)
+            n = A.shape[0]
+            g = torch.Generator(device=DEV).manual_seed(idx)
+            b = torch.randn(n, dtype=dt, device=DEV, generator=g)
+            x0 = torch.randn(n, dtype=dt, device=DEV, generator=g) if idx % 2 else None
+            if idx == 8:
+                x0 = torch.randn(n, dtype=dt, device=DEV, generator=g)
+                b = hipk.spmv(h, x0)
+            out = []
+            for two in ("1", "0"):
+                monkeypatch.setenv("HIPK_CG_TWO_LAUNCH", two)
+                x = torch.zeros_like(b) if x0 is None else x0.clone()
+                st = hipk.solve("cg", h, b, x, atol=0.0, **{"maxiter": None, **kw})
+                out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs))
+            assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, dt, out[0][1:], out[1][1:])
+            if idx == 8:
+                assert out[0][1] == 0
+    monkeypatch.delenv("HIPK_CG_TWO_LAUNCH", raising=False)
+    A, kw = cases[0]
+    b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
+    x = torch.zeros_like(b)
+    st = hipk.solve("cg", hipk.handle_for(A), b, x, atol=0.0, maxiter=None, **kw)
+    Ac = A.cpu()
+    ref = oracle.cg(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
+                    np.ones(A.shape[0]), **kw)
+    assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)
