@@ -194,7 +194,7 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_direction_kernel(
     }
 }
 
-// ---- TWO launches per iteration for launch-bound mid-size systems (33 .. 256 reduction chunks: 65 k < n <= 524 k) ----------------
+// ---- TWO launches per iteration for launch-bound mid-size systems (33 .. 150 reduction chunks: 65 k < n <= 307 k) ----------------
 // Above the one-launch kernels' size an iteration of three launches costs ~15 us whatever the three kernels move (a dependent
 // launch is ~4.5 us end to end on MI355X: hipk_tile_combine_kernel, one wavefront per chunk, averages 4.6 us in the profiles).
 // The direction step is folded into the SpMV: K1(k) folds <r,r> of iteration k-1 (every workgroup, the same bits), does the stop
@@ -919,12 +919,17 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_final_kernel(hipk_cg_sca
 }
 
 
+// two launches per iteration (hipk_cg2_*): 33 .. 150 reduction chunks.  Same box, alternating, 5-point Poisson, us per iteration
+// two / three launches: n = 90 k 12.4 / 15.7-16.7, 160 k 14.0 / 16.7-17.5, 250 k 15.7 / 17.0-17.9, 360 k 18.5 / 18.7-18.8,
+// 518 k 21.2 / 20.2 (the general CSR tiles' 12 bytes per entry catch up with the saved launch): profiles/r03_cg_two_launch.txt
+static constexpr int kCg2MaxChunks = 150;
+
 extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
     // r, p, Ap; mid-size systems (two launches per iteration) a second p: the direction step is formed while the old p is gathered
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
-    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= 256) ? 1 : 0)) * vec;
+    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= kCg2MaxChunks) ? 1 : 0)) * vec;
 }
 
 template <typename T>
@@ -1078,7 +1083,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     }
     // launch-bound mid-size systems: TWO launches per iteration (hipk_cg2_spmv_kernel / hipk_cg2_update_kernel above)
     constexpr int kCap2 = sizeof(T) == 8 ? 1280 : 2048;
-    const bool two_launch = !lds_loop && !small && gm.g > 32 && gm.g <= 256 && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+    const bool two_launch = !lds_loop && !small && gm.g > 32 && gm.g <= kCg2MaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                             A->crow != nullptr && A->max_tile_nnz <= kCap2 && A->max_row_len <= HIPK_LONG_ROW && prm->profile == 0 &&
                             it == 0 && !(getenv("HIPK_CG_TWO_LAUNCH") && getenv("HIPK_CG_TWO_LAUNCH")[0] == '0') &&
                             hipk_cg_work_bytes(n, A->dtype) >= 256 + hipk_scratch_bytes() + 4 * vec;
