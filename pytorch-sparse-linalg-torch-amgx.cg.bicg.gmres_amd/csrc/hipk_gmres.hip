@@ -91,6 +91,7 @@ struct hipk_gm_scal {
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
 static constexpr int kGmSlots = 8;  // ww, qq, res, bb, xx, spare x3
+static constexpr int kGmSplitChunks = 512;   // normalise step as two launches from this many reduction chunks (see hipk_gm_hcol_kernel)
 
 template <int KC>
 struct hipk_gm_yN {
@@ -2293,7 +2294,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     // VERDICT r2), and 113 VGPRs (4 workgroups per CU) cost more than they did.  Kept for the counters, not taken.
     const bool md_wide = env_int("HIPK_GM_MD_WIDE", 0) != 0;
     // normalise step as hipk_gm_hcol_kernel + hipk_gm_scale_kernel (HIPK_GM_SPLIT_NORM=0: the one-kernel form)
-    const bool split_norm = !small && env_int("HIPK_GM_SPLIT_NORM", 1) != 0;
+    // from kGmSplitChunks reduction chunks up: below, a workgroup's fold of 2 g partials is cheap and the extra launch is not
+    const bool split_norm = !small && env_int("HIPK_GM_SPLIT_NORM", gm.g >= kGmSplitChunks ? 1 : 0) != 0;
     const int gm_nres = env_int("HIPK_GM_NRES", 5);  // basis columns read with the default cache policy (the rest: nt)
     // large systems: second-pass launches only at the steps where a second CGS pass is expected (step 0, then every step
     // that ever asked for one in this solve); a miss is caught on the device and the cycle re-enqueued from that step

@@ -13,7 +13,8 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 switch = sys.argv[2] if len(sys.argv) > 2 else "HIPK_GM_MD_WIDE"
 A = create_convdiff_2d_csr(nx, nx, device="cuda:0")
 b = torch.ones(nx * nx, dtype=torch.float64, device="cuda:0")
-for restart, cycles in ((30, 8), (50, 5), (100, 3)):
+shapes = ((30, 8), (50, 5), (100, 3)) if nx >= 2000 else ((30, 8),)
+for restart, cycles in shapes:
     for rep in range(2):
         for wide in ("1", "0"):
             os.environ[switch] = wide
