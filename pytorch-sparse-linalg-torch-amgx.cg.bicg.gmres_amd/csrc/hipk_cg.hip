@@ -47,6 +47,7 @@ struct hipk_cg_scal {
     hipk_lds_ctl ctl;  // hipk_cg_solve_lds_kernel (small systems: the whole loop in one launch)
 };
 static_assert(sizeof(hipk_cg_scal) <= 256, "the scalar block is 256 bytes");
+#include "hipk_cg_mid.h"   // one-launch loop for mid-size systems (uses hipk_lds_ctl)
 
 // gamma0 = <r0,r0>, bs = <b,b>, atol2; p = r0.
 template <typename T>
@@ -929,7 +930,8 @@ extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
     // r, p, Ap; mid-size systems (two launches per iteration) a second p: the direction step is formed while the old p is gathered
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
-    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= kCg2MaxChunks) ? 1 : 0)) * vec;
+    // (the one-launch mid-size loop, hipk_cg_mid.h, keeps r as 16-byte flagged words in Ap + that fourth vector)
+    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= kMidMaxChunks) ? 1 : 0)) * vec;
 }
 
 template <typename T>
@@ -1079,6 +1081,92 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             }
             it = hs0.ctl.it_done;
             if (hs0.stop_it <= it || it >= maxiter) break;
+        }
+    }
+    // launch-bound mid-size systems (33 .. 512 chunks, fp64, rows of <= 12 entries within a window around their chunk): the whole
+    // loop in one launch, one workgroup per chunk (hipk_cg_mid.h); HIPK_CG_MID=0 leaves them to the launch sequences below
+    static bool mid_failed = false;
+    bool mid_loop = false;
+    if constexpr (sizeof(T) == 8) {
+        mid_loop = !lds_loop && it == 0 && gm.g > 32 && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+                   A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
+                   !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0');
+        void (*mid_kern)(hipk_cg_mid_args) = A->max_row_len <= 5   ? hipk_cg_mid_kernel<5>
+                                             : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7>
+                                             : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9>
+                                                                   : hipk_cg_mid_kernel<12>;
+        int H = 0;
+        size_t lds = 0;
+        if (mid_loop) {
+            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
+                int *out = (int *)part_c, reach = 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+                int rgrid = (int)((n + 255) / 256);
+                if (rgrid > 2048) rgrid = 2048;
+                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                A->mid_reach1 = reach + 1;
+            }
+            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
+            lds = hipk_cg_mid_lds_bytes(H);
+            int occ = 0;
+            mid_loop = lds <= (size_t)160 * 1024 &&
+                       hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, HIPK_THREADS, lds) == hipSuccess &&
+                       (int64_t)occ * A->n_cu >= gm.g;
+            (void)hipGetLastError();
+        }
+        if (mid_loop) {
+            const size_t vec8 = hipk_align_up((size_t)n * sizeof(double), 256);
+            const char *e = getenv("HIPK_CG_LAUNCH_ITS");
+            hipk_cg_mid_args ca;
+            ca.n = n;
+            ca.g = gm.g;
+            ca.H = H;
+            ca.crow = A->crow;
+            ca.col = A->col;
+            ca.val = (const double *)A->val;
+            ca.x = (double *)x;
+            ca.r = (double *)r;
+            ca.p = (double *)p;
+            ca.r_ll = (unsigned long long *)Ap;      // Ap + the fourth vector: 2 x vec >= 16 n bytes
+            ca.pap_ll = (unsigned long long *)part_c;
+            ca.rr_ll = ca.pap_ll + 2 * kMidMaxChunks;
+            ca.ctl = &scal->ctl;
+            ca.gamma = scal->gamma;
+            ca.atol2 = &scal->atol2;
+            ca.stop_it = &scal->stop_it;
+            ca.maxiter = maxiter;
+            ca.max_its = e ? atoll(e) : 16384;
+            if (ca.max_its < 1) ca.max_its = 1;
+            const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+            int launch_no = 0;
+            hipk_cg_scal hs0;
+            for (;;) {
+                ca.it0 = it;
+                ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
+                mid_kern<<<gm.g, HIPK_THREADS, lds, stream>>>(ca);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                if (hs0.ctl.redo < 0) {
+                    if (hs0.ctl.redo == -3) {
+                        hipk_set_error("hipk_cg_solve: a resident workgroup of the one-launch loop stopped arriving");
+                        return HIPK_ERR_HIP;
+                    }
+                    if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;   // not co-resident; nothing was modified
+                    mid_loop = false;
+                    break;
+                }
+                it = hs0.ctl.it_done;
+                if (hs0.stop_it <= it || it >= maxiter) break;
+            }
+            lds_loop = mid_loop;   // finished here: none of the launch sequences below runs
         }
     }
     // launch-bound mid-size systems: TWO launches per iteration (hipk_cg2_spmv_kernel / hipk_cg2_update_kernel above)

@@ -100,6 +100,7 @@ struct hipk_csr_s {
     int n_huge;          //   row-per-wavefront pre-pass when the matrix as a whole is short-rowed
     int max_row_len;     // structure analysis at creation
     int max_tile_nnz;    //   (tile = 256 consecutive rows)
+    int mid_reach1;      // 1 + the largest distance of a column from its row's reduction chunk (0: not computed yet; hipk_cg_mid.h)
     // coded form (hipk_coded.h), present when the matrix has <= 256 distinct (col - row, value) pairs and short rows
     unsigned char *code;    // device, nnz (+32 bytes of padding), owned
     unsigned char *rowlen;  // device, n_rows, owned

@@ -91,7 +91,9 @@ struct hipk_gm_scal {
 static constexpr size_t kGmHeader = 32768;
 static_assert(sizeof(hipk_gm_scal) <= kGmHeader, "header too small");
 static constexpr int kGmSlots = 8;  // ww, qq, res, bb, xx, spare x3
-static constexpr int kGmSplitChunks = 512;   // normalise step as two launches from this many reduction chunks (see hipk_gm_hcol_kernel)
+static constexpr int kGmSplitChunks = 1536;  // normalise step as two launches from this many reduction chunks (see hipk_gm_hcol_kernel):
+                                             // GMRES(30) ms per cycle, split / one kernel: 44 chunks 1.34-1.36 / 1.31, 123: 1.56 / 1.51, 254: 1.83-1.86 / 1.80,
+                                             // 489: 2.41 / 2.38, 958: 3.74 / 3.68-3.70, 1954: 6.54-6.55 / 6.61 (profiles/r03_gmres_history.md)
 
 template <int KC>
 struct hipk_gm_yN {

@@ -846,3 +846,85 @@ def test_cg_two_launch_iteration_is_bit_identical(hipk, oracle, monkeypatch):
     ref = oracle.cg(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
                     np.ones(A.shape[0]), **kw)
     assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)
+
+
+def _scipy_to_csr_dev(M):
+    M = M.tocsr()
+    M.sort_indices()
+    return torch.sparse_csr_tensor(torch.from_numpy(M.indptr.astype(np.int64)), torch.from_numpy(M.indices.astype(np.int64)),
+                                   torch.from_numpy(M.data.astype(np.float64)), size=M.shape).to(DEV)
+
+
+@pytest.mark.gpu
+def test_cg_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
+    """Launch-bound mid-size fp64 systems (33 .. 512 reduction chunks, rows of <= 12 entries that stay within a window around their
+    chunk) run the WHOLE CG loop in one launch, one workgroup per chunk (csrc/hipk_cg_mid.h): x and r in registers, p as an LDS window
+    advanced on the consumer side, chunk partials and r exchanged as flagged words.  Same bits as the launch sequences
+    (HIPK_CG_MID=0) -- x, iteration count, info, true and recurrence residuals -- for 2-D and 3-D stencils, per-entry values, a banded
+    random SPD matrix with 9 .. 11 entries per row, ragged last chunks, one and two workgroups per CU, warm starts, maxiter cut-offs,
+    a stop at iteration 0, re-launches every 7 iterations, a launch whose workgroups report "not co-resident" (first and second);
+    and, on one system, as the CPU oracle."""
+    import scipy.sparse as sp
+    from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr, create_variable_diffusion_2d_csr
+
+    def poisson3d(m):
+        T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
+        I = sp.identity(m)
+        return _scipy_to_csr_dev(sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T))
+
+    def banded_spd(n, offs, seed):
+        rng = np.random.default_rng(seed)
+        M = sp.diags([rng.uniform(-1.0, -0.1, n - o) for o in offs], offs, shape=(n, n))
+        M = M + M.T
+        return _scipy_to_csr_dev(M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 0.5))
+
+    cases = [(create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {}),                       # 44 chunks
+             (create_poisson_2d_csr(500, 500, device=DEV), dict(tol=1e-6), {}),                       # 123 chunks
+             (create_poisson_2d_csr(550, 557, device=DEV), dict(tol=1e-5), {}),                       # ragged last chunk
+             (create_variable_diffusion_2d_csr(400, 300, device=DEV), dict(tol=1e-7), {}),            # values differ per entry
+             (create_poisson_2d_csr(720, 720, device=DEV), dict(tol=1e-5), {}),                       # 254 chunks: one workgroup on (almost) every CU
+             (create_poisson_2d_csr(1000, 1000, device=DEV), dict(tol=1e-4), {}),                     # 489 chunks: two per CU
+             (poisson3d(48), dict(tol=1e-8), {}),                                                     # 7 entries per row, reach 2304
+             (banded_spd(100003, (1, 2, 3, 700, 1500), 5), dict(tol=1e-10), {}),                      # 9 .. 11 entries per row
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=37), {}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=38), {}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=1), {}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=0), {}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=0.5), {}),                        # b = A x0 below: stops at iteration 0
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_CG_LAUNCH_ITS": "7"}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_TEST_LDS_NOT_RESIDENT": "1"}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_CG_LAUNCH_ITS": "7", "HIPK_TEST_LDS_NOT_RESIDENT": "2"})]
+    for idx, (A, kw, env) in enumerate(cases):
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        g = torch.Generator(device=DEV).manual_seed(idx)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        if idx == 12:
+            x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+            b = hipk.spmv(h, x0)
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_CG_MID", mid)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b) if x0 is None else x0.clone()
+            st = hipk.solve("cg", h, b, x, atol=0.0, **{"maxiter": None, **kw})
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs))
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, out[0][1:], out[1][1:])
+        if idx == 12:
+            assert out[0][1] == 0
+        if idx < 8:
+            assert out[0][1] > 20, (idx, out[0][1])
+    monkeypatch.delenv("HIPK_CG_MID", raising=False)
+    A, kw, _ = cases[0]
+    b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
+    x = torch.zeros_like(b)
+    st = hipk.solve("cg", hipk.handle_for(A), b, x, atol=0.0, maxiter=None, **kw)
+    Ac = A.cpu()
+    ref = oracle.cg(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
+                    np.ones(A.shape[0]), **kw)
+    assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """CG per iteration on launch-bound mid-size systems (5-point Poisson, 65 k < n <= 524 k and the sizes around): two launches per
-iteration (default, hipk_cg2_*) against three (HIPK_CG_TWO_LAUNCH=0), same process, alternating."""
+iteration (hipk_cg2_*) against three (HIPK_CG_TWO_LAUNCH=0) and against the one-launch loop (hipk_cg_mid.h, "mid"), same
+process, alternating."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd"))
@@ -13,8 +14,9 @@ for nx in (200, 300, 400, 500, 600, 720, 1000):
     h = _hipk.handle_for(A)
     b = torch.ones(nx * nx, dtype=torch.float64, device=dev)
     for rep in range(2):
-        for two in ("1", "0"):
-            os.environ["HIPK_CG_TWO_LAUNCH"] = two
+        for two in ("mid", "1", "0"):
+            os.environ["HIPK_CG_MID"] = "1" if two == "mid" else "0"
+            os.environ["HIPK_CG_TWO_LAUNCH"] = "1" if two == "mid" else two
             x = torch.zeros_like(b)
             _hipk.solve("cg", h, b, x, tol=1e-12, atol=0.0, maxiter=50)
             x.zero_()
@@ -24,4 +26,4 @@ for nx in (200, 300, 400, 500, 600, 720, 1000):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(json.dumps({"n": nx * nx, "chunks": -(-nx * nx // 2048), "two_launch": two, "iterations": st.iterations,
-                              "us_per_iteration": round(dt / st.iterations * 1e6, 2), "x_sum": float(x.sum())}), flush=True)
+                              "us_per_iteration": round(dt / st.iterations * 1e6, 2), "x_sha": __import__("hashlib").sha1(x.cpu().numpy().tobytes()).hexdigest()[:12]}), flush=True)
