@@ -1091,10 +1091,16 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         mid_loop = !lds_loop && it == 0 && gm.g > 32 && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0');
-        void (*mid_kern)(hipk_cg_mid_args) = A->max_row_len <= 5   ? hipk_cg_mid_kernel<5>
-                                             : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7>
-                                             : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9>
-                                                                   : hipk_cg_mid_kernel<12>;
+        // one workgroup of 1024 threads per CU up to n_cu chunks; beyond, two of 512 (then at most 7 entries per row in registers)
+        const bool wide = gm.g <= A->n_cu;
+        void (*mid_kern)(hipk_cg_mid_args) =
+            wide ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1024>
+                    : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1024>
+                    : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1024>
+                                          : hipk_cg_mid_kernel<12, 1024>)
+                 : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 512> : hipk_cg_mid_kernel<7, 512>);
+        const int mid_threads = wide ? 1024 : 512;
+        if (!wide && A->max_row_len > 7) mid_loop = false;
         int H = 0;
         size_t lds = 0;
         if (mid_loop) {
@@ -1114,7 +1120,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             int occ = 0;
             mid_loop = lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, HIPK_THREADS, lds) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, mid_threads, lds) == hipSuccess &&
                        (int64_t)occ * A->n_cu >= gm.g;
             (void)hipGetLastError();
         }
@@ -1150,7 +1156,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
-                mid_kern<<<gm.g, HIPK_THREADS, lds, stream>>>(ca);
+                mid_kern<<<gm.g, mid_threads, lds, stream>>>(ca);
                 HIPK_CHECK_HIP(hipGetLastError());
                 HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
                 HIPK_CHECK_HIP(hipStreamSynchronize(stream));
@@ -1870,3 +1876,13 @@ extern "C" int hipk_pcg_solve(hipk_csr_t A, const void *dinv, const void *b, voi
     return hipk_pcg_solve_t<float>(A, (const float *)dinv, (const float *)b, (float *)x, (char *)work, prm, st,
                                    (hipStream_t)stream);
 }
+
+#ifdef HIPK_GM_STAMPS
+// diagnostic twin only: per-workgroup phase time sums of the last hipk_cg_mid_kernel launch (hipk_cg_mid.h)
+extern "C" int hipk_debug_mid_stamps(unsigned long long *out, size_t count) {
+    const size_t have = sizeof(hipk_mid_stamps) / sizeof(unsigned long long);
+    HIPK_CHECK_HIP(hipDeviceSynchronize());
+    HIPK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk_mid_stamps), sizeof(unsigned long long) * (count < have ? count : have)));
+    return HIPK_OK;
+}
+#endif

@@ -26,16 +26,18 @@
 static constexpr int kMidMaxChunks = 512;     // two partials per thread in the fold
 static constexpr int kMidSpinBound = 1 << 18; // polls (~1 us each) before a workgroup gives up on a hand-off
 
+// One 16-byte store / load per flagged double: {lo, seq, hi, seq}.  Each 8-byte half validates itself, so a store or load torn
+// into its halves is harmless.  sc1 = the agent-scope policy the compiler gives relaxed atomics (write-through / L2-coherent read).
+typedef unsigned hipk_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void hipk_ll_put(unsigned long long *slot, double v, unsigned seq) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v), s = (unsigned long long)seq << 32;
-    __hip_atomic_store(slot, (b & 0xffffffffull) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 1, (b >> 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const hipk_v4u w = {(unsigned)__double2loint(v), seq, (unsigned)__double2hiint(v), seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(w) : "memory");
 }
 __device__ __forceinline__ bool hipk_ll_get(const unsigned long long *slot, unsigned seq, double &v) {
-    const unsigned long long w0 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
-    return (unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq;
+    hipk_v4u w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(slot) : "memory");
+    v = __hiloint2double((int)w.z, (int)w.x);
+    return w.y == seq && w.w == seq;
 }
 // poll one flagged word; false when the spin bound was hit
 __device__ __forceinline__ bool hipk_ll_wait(const unsigned long long *slot, unsigned seq, double &v) {
@@ -82,52 +84,78 @@ struct hipk_cg_mid_args {
     int64_t it0, maxiter, max_its;
     int test_not_resident;
 };
-static inline size_t hipk_cg_mid_lds_bytes(int H) { return (size_t)(2 * (HIPK_BASE_CHUNK + 2 * H) + 8 + HIPK_THREADS + 32 + 8) * sizeof(double); }
+static inline size_t hipk_cg_mid_lds_bytes(int H) { return (size_t)(2 * (HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 + 32 + 8) * sizeof(double); }
 
-// fold of the G flagged chunk partials in the spec's order (hipk_reduce_parts); *fail set when a partial never arrived
-__device__ __forceinline__ double hipk_mid_fold(const unsigned long long *ll, int g, unsigned seq, double *sbuf, int *fail) {
+// thread t's share of the G flagged chunk partials in the spec's order (hipk_reduce_parts: t, t + 256; the tree follows);
+// *fail set when a partial never arrived
+__device__ __forceinline__ double hipk_mid_poll(const unsigned long long *ll, int g, unsigned seq, int *fail) {
     const int t = threadIdx.x;
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < kMidMaxChunks / HIPK_THREADS; ++k) {
-        const int i = t + k * HIPK_THREADS;
+    for (int k = 0; k < kMidMaxChunks / 256; ++k) {
+        const int i = t + k * 256;
         if (i < g) {
             double v;
             if (!hipk_ll_wait(ll + 2 * i, seq, v)) *fail = 1;
             acc = acc + v;
         }
     }
-    return hipk_block_sum(acc, sbuf);
+    return acc;
 }
 
-template <int W>
-__global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
+// Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the iterations of a launch, the constant 100 MHz clock
+// between its phase boundaries; tools/cg_mid_stamps_probe.py prints where an iteration goes.
+#ifdef HIPK_GM_STAMPS
+#define HIPK_MID_NSTAMP 12
+__device__ unsigned long long hipk_mid_stamps[kMidMaxChunks * HIPK_MID_NSTAMP];
+#define HIPK_MSTAMP(k)                                                  \
+    do {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        st_acc[k] += t_ - st_prev;                                      \
+        st_prev = t_;                                                   \
+    } while (0)
+#else
+#define HIPK_MSTAMP(k)
+#endif
+
+// The spec's fold of 256 per-thread values (hipk_block_sum: v[t] += v[t+128], v[t] += v[t+64], wavefront tree), done by EVERY
+// wavefront for itself from the LDS copy sb[256]: no second barrier, no broadcast.  Same pairing, same bits.
+__device__ __forceinline__ double hipk_mid_tree(const double *sb, int lane) {
+    double a = (sb[lane] + sb[lane + 128]) + (sb[lane + 64] + sb[lane + 192]);
+    a = hipk_wave_sum(a);
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(a)), __builtin_amdgcn_readfirstlane(__double2loint(a)));
+}
+
+// W: matrix entries per row held in registers; NTHR: threads per workgroup (1024: one workgroup per CU, 512: two)
+template <int W, int NTHR>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
     constexpr int CH = HIPK_BASE_CHUNK, NT = CH / HIPK_TILE;   // 2048 rows = 8 tiles of 256
+    constexpr int R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;      // rows per thread; tiles one pass of the workgroup covers
     extern __shared__ double mid_lds[];
     const int c = blockIdx.x, g = a.g, H = a.H, WIN = CH + 2 * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
     double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + CH) is the own chunk
-    double *sbuf = rw + WIN;         // [256]
-    double *ts = sbuf + HIPK_THREADS;   // [32] wavefront sums of <p,Ap>, 4 per tile
+    double *sb = rw + WIN;           // 2 x [256]: fold buffers, used alternately (one barrier per fold)
+    double *ts = sb + 2 * 256;       // [32] wavefront sums of <p,Ap>, 4 per tile
     int *fail = (int *)(ts + 32);
     const int64_t n = a.n, base = (int64_t)c * CH, w0 = base - H;
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
 
-    // ---- the chunk's rows: x, r, matrix entries in registers; the p window in LDS
-    double xo[NT], ro[NT], vj[NT][W];
-    int cj[NT][W];
+    // ---- the chunk's rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + TSTEP k) + tl); the p window in LDS
+    double xo[R], ro[R], vj[R][W];
+    int cj[R][W];
     // short rows are padded with (value +0.0, column slot WIN holding +0.0): acc + (0.0 * 0.0) leaves every acc as it is (acc
     // starts at +0.0 and can never become -0.0), so the sum has the bits of the row's own entries added in CSR order -- and no
     // per-entry predicate has to be kept alive over the loop (as 64-bit lane masks they cost 2 W scalar registers per row)
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        const int64_t row = base + tt * HIPK_TILE + tid;
+    for (int k = 0; k < R; ++k) {
+        const int64_t row = base + (t0 + TSTEP * k) * HIPK_TILE + tl;
         const bool live = row < n;
-        xo[tt] = live ? a.x[row] : 0.0;
-        ro[tt] = live ? a.r[row] : 0.0;
+        xo[k] = live ? a.x[row] : 0.0;
+        ro[k] = live ? a.r[row] : 0.0;
         int lo = 0, len = 0;
         if (live) {
             lo = a.crow[row];
@@ -136,12 +164,12 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const bool has = j < len;
-            cj[tt][j] = has ? (int)(a.col[lo + j] - w0) : WIN;
-            vj[tt][j] = has ? a.val[lo + j] : 0.0;
+            cj[k][j] = has ? (int)(a.col[lo + j] - w0) : WIN;
+            vj[k][j] = has ? a.val[lo + j] : 0.0;
         }
     }
     if (tid < 8) pw[WIN + tid] = 0.0;
-    for (int idx = tid; idx < WIN; idx += HIPK_THREADS) {
+    for (int idx = tid; idx < WIN; idx += NTHR) {
         const int64_t gc = w0 + idx;
         pw[idx] = (gc >= 0 && gc < n) ? a.p[gc] : 0.0;
         rw[idx] = 0.0;
@@ -150,6 +178,8 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
     const double atol2 = *a.atol2;
     const int64_t stop0 = *a.stop_it;
     double rs_last = scal->rs_last;
+    // rows whose r another chunk's window holds: within H of either end of the chunk (H >= 1024: all)
+    const int pub_lo = H, pub_hi = CH - H;
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the solve to the launch sequences
     int epoch = 0;
@@ -158,36 +188,47 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
         return;
     }
     unsigned seq = 0;
+    int buf = 0;
     int64_t it = a.it0;
     bool done = stop0 <= it;
+#ifdef HIPK_GM_STAMPS
+    unsigned long long st_acc[HIPK_MID_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     while (!done) {
         ++seq;
         // ---- A p of the own rows (products rounded, added in CSR order), wavefront sums of p .* (A p)   (TSL:845-846)
-        double Ap[NT];
+        double Ap[R];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
+        for (int k = 0; k < R; ++k) {
+            const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                const double pr = vj[tt][j] * pw[cj[tt][j]];
+                const double pr = vj[k][j] * pw[cj[k][j]];
                 acc = acc + pr;
             }
-            const bool live = base + tt * HIPK_TILE + tid < n;
-            Ap[tt] = acc;   // rows beyond n: padding only, +0.0
-            double d0 = live ? pw[H + tt * HIPK_TILE + tid] * Ap[tt] : 0.0;
+            Ap[k] = acc;   // rows beyond n: padding only, +0.0
+            double d0 = (base + lrow < n) ? pw[H + lrow] * acc : 0.0;
             d0 = hipk_wave_sum(d0);
-            if (lane == 0) ts[tt * 4 + wave] = d0;
+            if (lane == 0) ts[(t0 + TSTEP * k) * 4 + tw] = d0;
         }
         __syncthreads();
-        if (tid == 0) {   // the chunk's partial of the tiled dot (hipk_tile_combine_kernel's fold)
-            double tp[NT];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-                tp[tt] = (c * NT + tt < ntiles) ? 0.0 + ((ts[tt * 4] + ts[tt * 4 + 1]) + (ts[tt * 4 + 2] + ts[tt * 4 + 3])) : 0.0;
-            const double part = 0.0 + (((tp[0] + tp[4]) + (tp[2] + tp[6])) + ((tp[1] + tp[5]) + (tp[3] + tp[7])));
-            hipk_ll_put(a.pap_ll + 2 * c, part, seq);
+        HIPK_MSTAMP(0);
+        if (tid < 64) {   // the chunk's partial of the tiled dot (hipk_tile_combine_kernel's fold): lanes 0..7 a tile each
+            double tp = 0.0;
+            if (lane < NT && c * NT + lane < ntiles) tp = 0.0 + ((ts[lane * 4] + ts[lane * 4 + 1]) + (ts[lane * 4 + 2] + ts[lane * 4 + 3]));
+            tp = tp + hipk_row_shl<4>(tp);   // (p0+p4) (p1+p5) (p2+p6) (p3+p7)
+            tp = tp + hipk_row_shl<2>(tp);   // (p0+p4)+(p2+p6)  (p1+p5)+(p3+p7)
+            tp = tp + hipk_row_shl<1>(tp);
+            if (lane == 0) hipk_ll_put(a.pap_ll + 2 * c, 0.0 + tp, seq);
         }
-        const double pAp = hipk_mid_fold(a.pap_ll, g, seq, sbuf, fail);
+        HIPK_MSTAMP(1);
+        if (tid < 256) sb[buf * 256 + tid] = hipk_mid_poll(a.pap_ll, g, seq, fail);
+        HIPK_MSTAMP(2);
+        __syncthreads();
+        const double pAp = hipk_mid_tree(sb + buf * 256, lane);
+        buf ^= 1;
+        HIPK_MSTAMP(3);
         if (*fail) {
             if (tid == 0) scal->redo = -3;
             return;
@@ -195,31 +236,39 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
         // ---- alpha, r, x; r to the neighbours; the chunk's partial of <r,r>   (TSL:846-850)
         const double alpha = gamma / pAp;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const int64_t row = base + tt * HIPK_TILE + tid;
-            const double m1 = alpha * Ap[tt];
-            ro[tt] = ro[tt] - m1;
-            const double m0 = alpha * pw[H + tt * HIPK_TILE + tid];
-            xo[tt] = xo[tt] + m0;
-            rw[H + tt * HIPK_TILE + tid] = ro[tt];
-            if (row < n) hipk_ll_put(a.r_ll + 2 * row, ro[tt], seq);
+        for (int k = 0; k < R; ++k) {
+            const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
+            const double m1 = alpha * Ap[k];
+            ro[k] = ro[k] - m1;
+            const double m0 = alpha * pw[H + lrow];
+            xo[k] = xo[k] + m0;
+            rw[H + lrow] = ro[k];
+            if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(a.r_ll + 2 * (base + lrow), ro[k], seq);
         }
         __syncthreads();
-        {
+        HIPK_MSTAMP(4);
+        if (tid < 256) {
             double acc = 0.0;   // virtual thread t of the chunk: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
 #pragma unroll
-            for (int j = 0; j < CH / (2 * HIPK_THREADS); ++j)
+            for (int j = 0; j < CH / 512; ++j)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int i = 2 * tid + 2 * HIPK_THREADS * j + k;
+                    const int i = 2 * tid + 512 * j + k;
                     const double v = rw[H + i];
                     if (base + i < n) acc = fma(v, v, acc);
                 }
-            acc = hipk_block_sum(acc, sbuf);
-            if (tid == 0) hipk_ll_put(a.rr_ll + 2 * c, acc, seq);
+            sb[buf * 256 + tid] = acc;
         }
-        // r at the window's halo columns (issued before the fold of <r,r>: the neighbours published r before their partial)
-        for (int idx = tid; idx < 2 * H; idx += HIPK_THREADS) {
+        HIPK_MSTAMP(5);
+        __syncthreads();
+        {
+            const double part = hipk_mid_tree(sb + buf * 256, lane);
+            buf ^= 1;
+            if (tid == 0) hipk_ll_put(a.rr_ll + 2 * c, part, seq);
+        }
+        HIPK_MSTAMP(6);
+        // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs)
+        for (int idx = tid; idx < 2 * H; idx += NTHR) {
             const int widx = idx < H ? idx : idx + CH;
             const int64_t gc = w0 + widx;
             if (gc >= 0 && gc < n) {
@@ -228,18 +277,25 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
                 rw[widx] = v;
             }
         }
-        const double rr = hipk_mid_fold(a.rr_ll, g, seq, sbuf, fail);
+        HIPK_MSTAMP(7);
+        if (tid < 256) sb[buf * 256 + tid] = hipk_mid_poll(a.rr_ll, g, seq, fail);
+        HIPK_MSTAMP(8);
+        __syncthreads();
+        const double rr = hipk_mid_tree(sb + buf * 256, lane);
+        buf ^= 1;
+        HIPK_MSTAMP(9);
         if (*fail) {
             if (tid == 0) scal->redo = -3;
             return;
         }
         // ---- beta, p over the whole window, stop test   (TSL:851-853, 841)
         const double beta = rr / gamma;
-        for (int idx = tid; idx < WIN; idx += HIPK_THREADS) {
+        for (int idx = tid; idx < WIN; idx += NTHR) {
             const double m = beta * pw[idx];
             pw[idx] = rw[idx] + m;
         }
         __syncthreads();
+        HIPK_MSTAMP(10);
         gamma = rr;
         rs_last = rr;
         ++it;
@@ -247,14 +303,18 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_cg_mid_kernel(hipk_cg_mid_a
         if (it - a.it0 >= a.max_its) break;
     }
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        const int64_t row = base + tt * HIPK_TILE + tid;
-        if (row < n) {
-            a.x[row] = xo[tt];
-            a.r[row] = ro[tt];
-            a.p[row] = pw[H + tt * HIPK_TILE + tid];
+    for (int k = 0; k < R; ++k) {
+        const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
+        if (base + lrow < n) {
+            a.x[base + lrow] = xo[k];
+            a.r[base + lrow] = ro[k];
+            a.p[base + lrow] = pw[H + lrow];
         }
     }
+#ifdef HIPK_GM_STAMPS
+    if (tid == 0)
+        for (int k = 0; k < HIPK_MID_NSTAMP; ++k) hipk_mid_stamps[c * HIPK_MID_NSTAMP + k] = st_acc[k];
+#endif
     if (c == 0 && tid == 0) {
         a.gamma[it & 1] = gamma;
         scal->rs_last = rs_last;
