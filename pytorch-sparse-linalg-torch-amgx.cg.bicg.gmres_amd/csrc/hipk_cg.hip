@@ -1091,16 +1091,16 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
         mid_loop = !lds_loop && it == 0 && gm.g > 32 && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0');
-        // one workgroup of 1024 threads per CU up to n_cu chunks; beyond, two of 512 (then at most 7 entries per row in registers)
-        const bool wide = gm.g <= A->n_cu;
+        // one workgroup of 1024 threads per CU; a chunk each up to n_cu chunks, two each beyond
+        const int nch = gm.g <= A->n_cu ? 1 : 2;
         void (*mid_kern)(hipk_cg_mid_args) =
-            wide ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1024>
-                    : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1024>
-                    : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1024>
-                                          : hipk_cg_mid_kernel<12, 1024>)
-                 : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 512> : hipk_cg_mid_kernel<7, 512>);
-        const int mid_threads = wide ? 1024 : 512;
-        if (!wide && A->max_row_len > 7) mid_loop = false;
+            nch == 1 ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1>
+                        : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1>
+                        : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1>
+                                              : hipk_cg_mid_kernel<12, 1>)
+                     : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 2> : hipk_cg_mid_kernel<7, 2>);
+        const int mid_threads = 1024, mid_grid = (gm.g + nch - 1) / nch;
+        if (nch == 2 && A->max_row_len > 7) mid_loop = false;   // four rows per thread: at most 7 entries each in registers
         int H = 0;
         size_t lds = 0;
         if (mid_loop) {
@@ -1116,12 +1116,12 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                 A->mid_reach1 = reach + 1;
             }
             H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_cg_mid_lds_bytes(H);
+            lds = hipk_cg_mid_lds_bytes(H, nch);
             int occ = 0;
             mid_loop = lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, mid_threads, lds) == hipSuccess &&
-                       (int64_t)occ * A->n_cu >= gm.g;
+                       (int64_t)occ * A->n_cu >= mid_grid;
             (void)hipGetLastError();
         }
         if (mid_loop) {
@@ -1156,7 +1156,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
-                mid_kern<<<gm.g, mid_threads, lds, stream>>>(ca);
+                mid_kern<<<mid_grid, mid_threads, lds, stream>>>(ca);
                 HIPK_CHECK_HIP(hipGetLastError());
                 HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
                 HIPK_CHECK_HIP(hipStreamSynchronize(stream));

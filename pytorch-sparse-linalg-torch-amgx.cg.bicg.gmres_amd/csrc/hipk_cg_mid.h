@@ -84,7 +84,10 @@ struct hipk_cg_mid_args {
     int64_t it0, maxiter, max_its;
     int test_not_resident;
 };
-static inline size_t hipk_cg_mid_lds_bytes(int H) { return (size_t)(2 * (HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 + 32 + 8) * sizeof(double); }
+// LDS of a workgroup that owns `nch` chunks with reach H: p window + 8 zero slots | r window | 2 fold buffers | tile sums | flag
+static inline size_t hipk_cg_mid_lds_bytes(int H, int nch) {
+    return (size_t)(2 * (nch * HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 * nch + 32 * nch + 8) * sizeof(double);
+}
 
 // thread t's share of the G flagged chunk partials in the spec's order (hipk_reduce_parts: t, t + 256; the tree follows);
 // *fail set when a partial never arrived
@@ -126,25 +129,36 @@ __device__ __forceinline__ double hipk_mid_tree(const double *sb, int lane) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(a)), __builtin_amdgcn_readfirstlane(__double2loint(a)));
 }
 
-// W: matrix entries per row held in registers; NTHR: threads per workgroup (1024: one workgroup per CU, 512: two)
-template <int W, int NTHR>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
-    constexpr int CH = HIPK_BASE_CHUNK, NT = CH / HIPK_TILE;   // 2048 rows = 8 tiles of 256
-    constexpr int R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;      // rows per thread; tiles one pass of the workgroup covers
+// two wavefront sums of the tiled dot at once: lanes 0..31 take a[l] + a[l+32], lanes 32..63 b[l] + b[l+32] (one
+// v_permlane32_swap per dword exchanges a's upper with b's lower half), then the strides 16 .. 1 run in both halves together.
+// Sum of a in lane 0, of b in lane 32; the pairing -- and the bits -- of hipk_wave_sum on each.
+__device__ __forceinline__ double hipk_wave_sum_pair(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    const double x = __hiloint2double(hi[0], lo[0]), y = __hiloint2double(hi[1], lo[1]);
+    return hipk_half_sum(x + y);
+}
+
+// W: matrix entries per row held in registers; NCH: reduction chunks per workgroup (1: up to n_cu chunks; 2: beyond -- half the
+// rows then sit inside a workgroup's own window and are not published).  1024 threads, 2 NCH rows each, one workgroup per CU.
+template <int W, int NCH>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
+    constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, NT = CH / HIPK_TILE;   // a chunk: 2048 rows = 8 tiles of 256
+    constexpr int OWN = NCH * CH, R = OWN / NTHR, TSTEP = NTHR / HIPK_TILE;  // rows per thread; tiles one pass of the workgroup covers
     extern __shared__ double mid_lds[];
-    const int c = blockIdx.x, g = a.g, H = a.H, WIN = CH + 2 * H;
+    const int wg = blockIdx.x, g = a.g, H = a.H, WIN = OWN + 2 * H;
     const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
-    double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + CH) is the own chunk
-    double *sb = rw + WIN;           // 2 x [256]: fold buffers, used alternately (one barrier per fold)
-    double *ts = sb + 2 * 256;       // [32] wavefront sums of <p,Ap>, 4 per tile
-    int *fail = (int *)(ts + 32);
-    const int64_t n = a.n, base = (int64_t)c * CH, w0 = base - H;
+    double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows
+    double *sb = rw + WIN;           // 2 x [256 NCH]: fold buffers, used alternately (one barrier per fold)
+    double *ts = sb + 2 * 256 * NCH; // [32 NCH] wavefront sums of <p,Ap>, 4 per tile
+    int *fail = (int *)(ts + 32 * NCH);
+    const int64_t n = a.n, base = (int64_t)wg * OWN, w0 = base - H;
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
 
-    // ---- the chunk's rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + TSTEP k) + tl); the p window in LDS
+    // ---- the own rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); the p window in LDS
     double xo[R], ro[R], vj[R][W];
     int cj[R][W];
     // short rows are padded with (value +0.0, column slot WIN holding +0.0): acc + (0.0 * 0.0) leaves every acc as it is (acc
@@ -178,12 +192,12 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const double atol2 = *a.atol2;
     const int64_t stop0 = *a.stop_it;
     double rs_last = scal->rs_last;
-    // rows whose r another chunk's window holds: within H of either end of the chunk (H >= 1024: all)
-    const int pub_lo = H, pub_hi = CH - H;
+    // rows whose r another workgroup's window holds: within H of either end of the own rows
+    const int pub_lo = H, pub_hi = OWN - H;
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the solve to the launch sequences
     int epoch = 0;
-    if (!hipk_gbar(&scal->bar, g, epoch, fail) || a.test_not_resident) {
+    if (!hipk_gbar(&scal->bar, (int)gridDim.x, epoch, fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
     }
@@ -199,46 +213,53 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // ---- A p of the own rows (products rounded, added in CSR order), wavefront sums of p .* (A p)   (TSL:845-846)
         double Ap[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-            double acc = 0.0;
+        for (int k = 0; k < R; k += 2) {
+            double d[2];
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const double pr = vj[k][j] * pw[cj[k][j]];
-                acc = acc + pr;
+            for (int h = 0; h < 2; ++h) {
+                const int lrow = (t0 + TSTEP * (k + h)) * HIPK_TILE + tl;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const double pr = vj[k + h][j] * pw[cj[k + h][j]];
+                    acc = acc + pr;
+                }
+                Ap[k + h] = acc;   // rows beyond n: padding only, +0.0
+                if (R > 2) rw[H + lrow] = acc;   // four rows per thread: A p waits in the (idle) own slot of the r window
+                d[h] = (base + lrow < n) ? pw[H + lrow] * acc : 0.0;
             }
-            Ap[k] = acc;   // rows beyond n: padding only, +0.0
-            double d0 = (base + lrow < n) ? pw[H + lrow] * acc : 0.0;
-            d0 = hipk_wave_sum(d0);
-            if (lane == 0) ts[(t0 + TSTEP * k) * 4 + tw] = d0;
+            const double s2 = hipk_wave_sum_pair(d[0], d[1]);
+            if ((lane & 31) == 0) ts[(t0 + TSTEP * (k + (lane >> 5))) * 4 + tw] = s2;
         }
         __syncthreads();
         HIPK_MSTAMP(0);
-        if (tid < 64) {   // the chunk's partial of the tiled dot (hipk_tile_combine_kernel's fold): lanes 0..7 a tile each
+        if (tid < 64) {   // the chunks' partials of the tiled dot (hipk_tile_combine_kernel's fold): lanes 8 q .. 8 q + 7 a tile each
+            const int q = lane >> 3;
             double tp = 0.0;
-            if (lane < NT && c * NT + lane < ntiles) tp = 0.0 + ((ts[lane * 4] + ts[lane * 4 + 1]) + (ts[lane * 4 + 2] + ts[lane * 4 + 3]));
+            if (lane < NT * NCH && (wg * NCH) * NT + lane < ntiles) tp = 0.0 + ((ts[lane * 4] + ts[lane * 4 + 1]) + (ts[lane * 4 + 2] + ts[lane * 4 + 3]));
             tp = tp + hipk_row_shl<4>(tp);   // (p0+p4) (p1+p5) (p2+p6) (p3+p7)
             tp = tp + hipk_row_shl<2>(tp);   // (p0+p4)+(p2+p6)  (p1+p5)+(p3+p7)
             tp = tp + hipk_row_shl<1>(tp);
-            if (lane == 0) hipk_ll_put(a.pap_ll + 2 * c, 0.0 + tp, seq);
+            if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(a.pap_ll + 2 * (wg * NCH + q), 0.0 + tp, seq);
         }
         HIPK_MSTAMP(1);
-        if (tid < 256) sb[buf * 256 + tid] = hipk_mid_poll(a.pap_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(a.pap_ll, g, seq, fail);
         HIPK_MSTAMP(2);
         __syncthreads();
-        const double pAp = hipk_mid_tree(sb + buf * 256, lane);
+        const double pAp = hipk_mid_tree(sb + buf * 256 * NCH, lane);
         buf ^= 1;
         HIPK_MSTAMP(3);
         if (*fail) {
             if (tid == 0) scal->redo = -3;
             return;
         }
-        // ---- alpha, r, x; r to the neighbours; the chunk's partial of <r,r>   (TSL:846-850)
+        // ---- alpha, r, x; r to the neighbours; the chunks' partials of <r,r>   (TSL:846-850)
         const double alpha = gamma / pAp;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-            const double m1 = alpha * Ap[k];
+            const double Ap_k = (R > 2) ? rw[H + lrow] : Ap[k];
+            const double m1 = alpha * Ap_k;
             ro[k] = ro[k] - m1;
             const double m0 = alpha * pw[H + lrow];
             xo[k] = xo[k] + m0;
@@ -247,29 +268,31 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         __syncthreads();
         HIPK_MSTAMP(4);
-        if (tid < 256) {
-            double acc = 0.0;   // virtual thread t of the chunk: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
+        if (tid < 256 * NCH) {
+            const int q = tid >> 8, t = tid & 255;
+            double acc = 0.0;   // virtual thread t of chunk q: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
 #pragma unroll
             for (int j = 0; j < CH / 512; ++j)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int i = 2 * tid + 512 * j + k;
+                    const int i = q * CH + 2 * t + 512 * j + k;
                     const double v = rw[H + i];
                     if (base + i < n) acc = fma(v, v, acc);
                 }
-            sb[buf * 256 + tid] = acc;
+            sb[buf * 256 * NCH + tid] = acc;
         }
         HIPK_MSTAMP(5);
         __syncthreads();
-        {
-            const double part = hipk_mid_tree(sb + buf * 256, lane);
-            buf ^= 1;
-            if (tid == 0) hipk_ll_put(a.rr_ll + 2 * c, part, seq);
+        if (tid < 64 * NCH) {   // wavefront q folds chunk q's 256 chains and publishes the partial
+            const int q = tid >> 6;
+            const double part = hipk_mid_tree(sb + buf * 256 * NCH + q * 256, lane);
+            if (lane == 0 && wg * NCH + q < g) hipk_ll_put(a.rr_ll + 2 * (wg * NCH + q), part, seq);
         }
+        buf ^= 1;
         HIPK_MSTAMP(6);
         // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs)
         for (int idx = tid; idx < 2 * H; idx += NTHR) {
-            const int widx = idx < H ? idx : idx + CH;
+            const int widx = idx < H ? idx : idx + OWN;
             const int64_t gc = w0 + widx;
             if (gc >= 0 && gc < n) {
                 double v;
@@ -278,10 +301,10 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
         }
         HIPK_MSTAMP(7);
-        if (tid < 256) sb[buf * 256 + tid] = hipk_mid_poll(a.rr_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(a.rr_ll, g, seq, fail);
         HIPK_MSTAMP(8);
         __syncthreads();
-        const double rr = hipk_mid_tree(sb + buf * 256, lane);
+        const double rr = hipk_mid_tree(sb + buf * 256 * NCH, lane);
         buf ^= 1;
         HIPK_MSTAMP(9);
         if (*fail) {
@@ -313,9 +336,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 #ifdef HIPK_GM_STAMPS
     if (tid == 0)
-        for (int k = 0; k < HIPK_MID_NSTAMP; ++k) hipk_mid_stamps[c * HIPK_MID_NSTAMP + k] = st_acc[k];
+        for (int k = 0; k < HIPK_MID_NSTAMP; ++k) hipk_mid_stamps[wg * HIPK_MID_NSTAMP + k] = st_acc[k];
 #endif
-    if (c == 0 && tid == 0) {
+    if (wg == 0 && tid == 0) {
         a.gamma[it & 1] = gamma;
         scal->rs_last = rs_last;
         scal->it_done = it;
