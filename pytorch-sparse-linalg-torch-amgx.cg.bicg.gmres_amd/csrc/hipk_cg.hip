@@ -931,7 +931,7 @@ extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     // r, p, Ap; mid-size systems (two launches per iteration) a second p: the direction step is formed while the old p is gathered
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     // (the one-launch mid-size loop, hipk_cg_mid.h, keeps r as 16-byte flagged words in Ap + that fourth vector)
-    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > 32 && gm.g <= kMidMaxChunks) ? 1 : 0)) * vec;
+    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > kMidMinChunks && gm.g <= kMidMaxChunks) ? 1 : 0)) * vec;
 }
 
 template <typename T>
@@ -1012,6 +1012,99 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     if (const char *e = getenv("HIPK_CG_FLAT_DIRECTION")) flat_dir = e[0] == '1';
 
     int64_t it = 0, stop = INT64_MAX;
+    // launch-bound systems of 9 .. 512 chunks (fp64, rows of <= 12 entries within a window around their chunk): the whole loop in
+    // one launch, one workgroup per chunk or pair of chunks (hipk_cg_mid.h); HIPK_CG_MID=0 leaves them to the paths below.
+    // (At 9 .. 32 chunks it replaces the eight-workgroups-per-chunk kernel below: 5.0 against 10.7 us per iteration at n = 40 000.)
+    static bool mid_failed = false;
+    bool mid_loop = false;
+    if constexpr (sizeof(T) == 8) {
+        mid_loop = it == 0 && gm.g > kMidMinChunks && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+                   A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
+                   !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0') && !getenv("HIPK_CG_NO_LDS_LOOP") && !getenv("HIPK_CG_NO_SMALL");
+        // one workgroup of 1024 threads per CU; a chunk each up to n_cu chunks, two each beyond
+        const int nch = gm.g <= A->n_cu ? 1 : 2;
+        void (*mid_kern)(hipk_cg_mid_args) =
+            nch == 1 ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1>
+                        : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1>
+                        : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1>
+                                              : hipk_cg_mid_kernel<12, 1>)
+                     : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 2> : hipk_cg_mid_kernel<7, 2>);
+        const int mid_threads = 1024, mid_grid = (gm.g + nch - 1) / nch;
+        if (nch == 2 && A->max_row_len > 7) mid_loop = false;   // four rows per thread: at most 7 entries each in registers
+        int H = 0;
+        size_t lds = 0;
+        if (mid_loop) {
+            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
+                int *out = (int *)part_c, reach = 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+                int rgrid = (int)((n + 255) / 256);
+                if (rgrid > 2048) rgrid = 2048;
+                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                A->mid_reach1 = reach + 1;
+            }
+            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
+            lds = hipk_cg_mid_lds_bytes(H, nch);
+            int occ = 0;
+            mid_loop = lds <= (size_t)160 * 1024 &&
+                       hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, mid_threads, lds) == hipSuccess &&
+                       (int64_t)occ * A->n_cu >= mid_grid;
+            (void)hipGetLastError();
+        }
+        if (mid_loop) {
+            const size_t vec8 = hipk_align_up((size_t)n * sizeof(double), 256);
+            const char *e = getenv("HIPK_CG_LAUNCH_ITS");
+            hipk_cg_mid_args ca;
+            ca.n = n;
+            ca.g = gm.g;
+            ca.H = H;
+            ca.crow = A->crow;
+            ca.col = A->col;
+            ca.val = (const double *)A->val;
+            ca.x = (double *)x;
+            ca.r = (double *)r;
+            ca.p = (double *)p;
+            ca.r_ll = (unsigned long long *)Ap;      // Ap + the fourth vector: 2 x vec >= 16 n bytes
+            ca.pap_ll = (unsigned long long *)part_c;
+            ca.rr_ll = ca.pap_ll + 2 * kMidMaxChunks;
+            ca.ctl = &scal->ctl;
+            ca.gamma = scal->gamma;
+            ca.atol2 = &scal->atol2;
+            ca.stop_it = &scal->stop_it;
+            ca.maxiter = maxiter;
+            ca.xcd_aware = !(getenv("HIPK_CG_MID_XCD") && getenv("HIPK_CG_MID_XCD")[0] == '0');
+            ca.max_its = e ? atoll(e) : 16384;
+            if (ca.max_its < 1) ca.max_its = 1;
+            const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+            int launch_no = 0;
+            hipk_cg_scal hs0;
+            for (;;) {
+                ca.it0 = it;
+                ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
+                mid_kern<<<hipk_xcd_grid(mid_grid), mid_threads, lds, stream>>>(ca);   // hipk_xcd_chunk: padded to a multiple of 8
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                if (hs0.ctl.redo < 0) {
+                    if (hs0.ctl.redo == -3) {
+                        hipk_set_error("hipk_cg_solve: a resident workgroup of the one-launch loop stopped arriving");
+                        return HIPK_ERR_HIP;
+                    }
+                    if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;   // not co-resident; nothing was modified
+                    mid_loop = false;
+                    break;
+                }
+                it = hs0.ctl.it_done;
+                if (hs0.stop_it <= it || it >= maxiter) break;
+            }
+        }
+    }
     // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel), bounded iterations per launch
     static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
     // up to 64 workgroups (8 chunks) on ONE XCD, up to 512 (64 chunks, n <= 131072) spread over the chip, two per compute unit
@@ -1020,7 +1113,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     // 18.3 vs 18.3 at 64: the agent-scope hand-offs grow with the workgroup count -- taken up to 32 chunks, n <= 65536)
     bool lds_loop = gm.g <= 32 && !getenv("HIPK_CG_NO_SMALL") && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs &&
                     prm->profile == 0 && maxiter > 0 && kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) &&
-                    !lds_loop_failed && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
+                    !lds_loop_failed && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD")) && !mid_loop;
     if (lds_loop) {
         bool local = !lds_spread && !getenv("HIPK_CG_LOOP_AGENT");
         const char *e = getenv("HIPK_CG_LAUNCH_ITS");
@@ -1083,98 +1176,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             if (hs0.stop_it <= it || it >= maxiter) break;
         }
     }
-    // launch-bound mid-size systems (33 .. 512 chunks, fp64, rows of <= 12 entries within a window around their chunk): the whole
-    // loop in one launch, one workgroup per chunk (hipk_cg_mid.h); HIPK_CG_MID=0 leaves them to the launch sequences below
-    static bool mid_failed = false;
-    bool mid_loop = false;
-    if constexpr (sizeof(T) == 8) {
-        mid_loop = !lds_loop && it == 0 && gm.g > 32 && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
-                   A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
-                   !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0');
-        // one workgroup of 1024 threads per CU; a chunk each up to n_cu chunks, two each beyond
-        const int nch = gm.g <= A->n_cu ? 1 : 2;
-        void (*mid_kern)(hipk_cg_mid_args) =
-            nch == 1 ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1>
-                        : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1>
-                        : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1>
-                                              : hipk_cg_mid_kernel<12, 1>)
-                     : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 2> : hipk_cg_mid_kernel<7, 2>);
-        const int mid_threads = 1024, mid_grid = (gm.g + nch - 1) / nch;
-        if (nch == 2 && A->max_row_len > 7) mid_loop = false;   // four rows per thread: at most 7 entries each in registers
-        int H = 0;
-        size_t lds = 0;
-        if (mid_loop) {
-            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
-                int *out = (int *)part_c, reach = 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
-                int rgrid = (int)((n + 255) / 256);
-                if (rgrid > 2048) rgrid = 2048;
-                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                A->mid_reach1 = reach + 1;
-            }
-            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_cg_mid_lds_bytes(H, nch);
-            int occ = 0;
-            mid_loop = lds <= (size_t)160 * 1024 &&
-                       hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, mid_threads, lds) == hipSuccess &&
-                       (int64_t)occ * A->n_cu >= mid_grid;
-            (void)hipGetLastError();
-        }
-        if (mid_loop) {
-            const size_t vec8 = hipk_align_up((size_t)n * sizeof(double), 256);
-            const char *e = getenv("HIPK_CG_LAUNCH_ITS");
-            hipk_cg_mid_args ca;
-            ca.n = n;
-            ca.g = gm.g;
-            ca.H = H;
-            ca.crow = A->crow;
-            ca.col = A->col;
-            ca.val = (const double *)A->val;
-            ca.x = (double *)x;
-            ca.r = (double *)r;
-            ca.p = (double *)p;
-            ca.r_ll = (unsigned long long *)Ap;      // Ap + the fourth vector: 2 x vec >= 16 n bytes
-            ca.pap_ll = (unsigned long long *)part_c;
-            ca.rr_ll = ca.pap_ll + 2 * kMidMaxChunks;
-            ca.ctl = &scal->ctl;
-            ca.gamma = scal->gamma;
-            ca.atol2 = &scal->atol2;
-            ca.stop_it = &scal->stop_it;
-            ca.maxiter = maxiter;
-            ca.max_its = e ? atoll(e) : 16384;
-            if (ca.max_its < 1) ca.max_its = 1;
-            const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
-            int launch_no = 0;
-            hipk_cg_scal hs0;
-            for (;;) {
-                ca.it0 = it;
-                ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
-                HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
-                mid_kern<<<mid_grid, mid_threads, lds, stream>>>(ca);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                if (hs0.ctl.redo < 0) {
-                    if (hs0.ctl.redo == -3) {
-                        hipk_set_error("hipk_cg_solve: a resident workgroup of the one-launch loop stopped arriving");
-                        return HIPK_ERR_HIP;
-                    }
-                    if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;   // not co-resident; nothing was modified
-                    mid_loop = false;
-                    break;
-                }
-                it = hs0.ctl.it_done;
-                if (hs0.stop_it <= it || it >= maxiter) break;
-            }
-            lds_loop = mid_loop;   // finished here: none of the launch sequences below runs
-        }
-    }
+    if (mid_loop) lds_loop = true;   // finished in the one-launch loop: none of the launch sequences below runs
     // launch-bound mid-size systems: TWO launches per iteration (hipk_cg2_spmv_kernel / hipk_cg2_update_kernel above)
     constexpr int kCap2 = sizeof(T) == 8 ? 1280 : 2048;
     const bool two_launch = !lds_loop && !small && gm.g > 32 && gm.g <= kCg2MaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&

@@ -23,29 +23,35 @@
 #define HIPK_CG_MID_H
 #include "hipk_handoff.h"
 
+static constexpr int kMidMinChunks = 8;       // up to 8 chunks the one-XCD kernel (hipk_cg_solve_lds_kernel, LOCAL) is faster
 static constexpr int kMidMaxChunks = 512;     // two partials per thread in the fold
 static constexpr int kMidSpinBound = 1 << 18; // polls (~1 us each) before a workgroup gives up on a hand-off
 
 // One 16-byte store / load per flagged double: {lo, seq, hi, seq}.  Each 8-byte half validates itself, so a store or load torn
-// into its halves is harmless.  sc1 = the agent-scope policy the compiler gives relaxed atomics (write-through / L2-coherent read).
+// into its halves is harmless.  Raw buffer accesses with the sc1 policy (aux bit 4) -- what the compiler gives relaxed agent-scope
+// atomics: write-through stores, loads served at the device's coherence point -- so that they stay compiler-tracked: several polls
+// of a thread are in flight together and a load can be issued long before its value is examined (the halo of r, below).
 typedef unsigned hipk_v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void hipk_ll_put(unsigned long long *slot, double v, unsigned seq) {
+typedef __amdgpu_buffer_rsrc_t hipk_ll_rsrc;
+__device__ __forceinline__ hipk_ll_rsrc hipk_ll_make(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ void hipk_ll_put(hipk_ll_rsrc rs, unsigned slot, double v, unsigned seq) {
     const hipk_v4u w = {(unsigned)__double2loint(v), seq, (unsigned)__double2hiint(v), seq};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(w) : "memory");
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, slot * 16u, 0, 16);
 }
-__device__ __forceinline__ bool hipk_ll_get(const unsigned long long *slot, unsigned seq, double &v) {
-    hipk_v4u w;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(slot) : "memory");
-    v = __hiloint2double((int)w.z, (int)w.x);
-    return w.y == seq && w.w == seq;
-}
-// poll one flagged word; false when the spin bound was hit
-__device__ __forceinline__ bool hipk_ll_wait(const unsigned long long *slot, unsigned seq, double &v) {
+__device__ __forceinline__ hipk_v4u hipk_ll_load(hipk_ll_rsrc rs, unsigned slot) { return __builtin_amdgcn_raw_buffer_load_b128(rs, slot * 16u, 0, 16); }
+__device__ __forceinline__ bool hipk_ll_ok(const hipk_v4u w, unsigned seq) { return w.y == seq && w.w == seq; }
+__device__ __forceinline__ double hipk_ll_val(const hipk_v4u w) { return __hiloint2double((int)w.z, (int)w.x); }
+// poll one flagged word, starting from an earlier load's result; false when the spin bound was hit
+__device__ __forceinline__ bool hipk_ll_wait(hipk_ll_rsrc rs, unsigned slot, unsigned seq, hipk_v4u w, double &v) {
     unsigned spins = 0;
-    while (!hipk_ll_get(slot, seq, v)) {
+    while (!hipk_ll_ok(w, seq)) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (unsigned)kMidSpinBound) return false;
+        w = hipk_ll_load(rs, slot);
     }
+    v = hipk_ll_val(w);
     return true;
 }
 
@@ -83,6 +89,7 @@ struct hipk_cg_mid_args {
     int64_t *stop_it;
     int64_t it0, maxiter, max_its;
     int test_not_resident;
+    int xcd_aware;                // 0 (HIPK_CG_MID_XCD=0, A/B measurements): workgroup b takes row range b
 };
 // LDS of a workgroup that owns `nch` chunks with reach H: p window + 8 zero slots | r window | 2 fold buffers | tile sums | flag
 static inline size_t hipk_cg_mid_lds_bytes(int H, int nch) {
@@ -91,18 +98,20 @@ static inline size_t hipk_cg_mid_lds_bytes(int H, int nch) {
 
 // thread t's share of the G flagged chunk partials in the spec's order (hipk_reduce_parts: t, t + 256; the tree follows);
 // *fail set when a partial never arrived
-__device__ __forceinline__ double hipk_mid_poll(const unsigned long long *ll, int g, unsigned seq, int *fail) {
+__device__ __forceinline__ double hipk_mid_poll(hipk_ll_rsrc rs, int g, unsigned seq, int *fail) {
     const int t = threadIdx.x;
+    hipk_v4u w[kMidMaxChunks / 256];
+#pragma unroll
+    for (int k = 0; k < kMidMaxChunks / 256; ++k)
+        if (t + k * 256 < g) w[k] = hipk_ll_load(rs, t + k * 256);
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < kMidMaxChunks / 256; ++k) {
-        const int i = t + k * 256;
-        if (i < g) {
-            double v;
-            if (!hipk_ll_wait(ll + 2 * i, seq, v)) *fail = 1;
+    for (int k = 0; k < kMidMaxChunks / 256; ++k)
+        if (t + k * 256 < g) {
+            double v = 0.0;
+            if (!hipk_ll_wait(rs, t + k * 256, seq, w[k], v)) *fail = 1;
             acc = acc + v;
         }
-    }
     return acc;
 }
 
@@ -146,7 +155,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, NT = CH / HIPK_TILE;   // a chunk: 2048 rows = 8 tiles of 256
     constexpr int OWN = NCH * CH, R = OWN / NTHR, TSTEP = NTHR / HIPK_TILE;  // rows per thread; tiles one pass of the workgroup covers
     extern __shared__ double mid_lds[];
-    const int wg = blockIdx.x, g = a.g, H = a.H, WIN = OWN + 2 * H;
+    // XCD-aware placement (blocks b and b + 8 share an XCD): XCD k takes the k-th contiguous eighth of the workgroups' row
+    // ranges, so that a window's neighbours mostly sit behind the same L2 -- their write-through r then HITS there (a 0.1 us
+    // poll instead of a 0.5 us trip through the fabric).  Speed only; the grid is padded to a multiple of 8, idle blocks leave.
+    const int g = a.g, H = a.H, WIN = OWN + 2 * H, nwg = (g + NCH - 1) / NCH;
+    const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, nwg) : ((int)blockIdx.x < nwg ? (int)blockIdx.x : -1);
+    if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
     double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows
@@ -157,6 +171,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
+    const hipk_ll_rsrc r_ll = hipk_ll_make(a.r_ll, (size_t)n * 16), pap_ll = hipk_ll_make(a.pap_ll, (size_t)g * 16),
+                       rr_ll = hipk_ll_make(a.rr_ll, (size_t)g * 16);
 
     // ---- the own rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); the p window in LDS
     double xo[R], ro[R], vj[R][W];
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the solve to the launch sequences
     int epoch = 0;
-    if (!hipk_gbar(&scal->bar, (int)gridDim.x, epoch, fail) || a.test_not_resident) {
+    if (!hipk_gbar(&scal->bar, nwg, epoch, fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
     }
@@ -240,10 +256,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             tp = tp + hipk_row_shl<4>(tp);   // (p0+p4) (p1+p5) (p2+p6) (p3+p7)
             tp = tp + hipk_row_shl<2>(tp);   // (p0+p4)+(p2+p6)  (p1+p5)+(p3+p7)
             tp = tp + hipk_row_shl<1>(tp);
-            if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(a.pap_ll + 2 * (wg * NCH + q), 0.0 + tp, seq);
+            if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(pap_ll, wg * NCH + q, 0.0 + tp, seq);
         }
         HIPK_MSTAMP(1);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(a.pap_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(pap_ll, g, seq, fail);
         HIPK_MSTAMP(2);
         __syncthreads();
         const double pAp = hipk_mid_tree(sb + buf * 256 * NCH, lane);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const double m0 = alpha * pw[H + lrow];
             xo[k] = xo[k] + m0;
             rw[H + lrow] = ro[k];
-            if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(a.r_ll + 2 * (base + lrow), ro[k], seq);
+            if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(r_ll, (unsigned)(base + lrow), ro[k], seq);
         }
         __syncthreads();
         HIPK_MSTAMP(4);
@@ -286,22 +302,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (tid < 64 * NCH) {   // wavefront q folds chunk q's 256 chains and publishes the partial
             const int q = tid >> 6;
             const double part = hipk_mid_tree(sb + buf * 256 * NCH + q * 256, lane);
-            if (lane == 0 && wg * NCH + q < g) hipk_ll_put(a.rr_ll + 2 * (wg * NCH + q), part, seq);
+            if (lane == 0 && wg * NCH + q < g) hipk_ll_put(rr_ll, wg * NCH + q, part, seq);
         }
         buf ^= 1;
         HIPK_MSTAMP(6);
-        // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs)
+        // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs).
+        // (Issuing these loads earlier and examining them after the fold measured slower: a poll is a 0.5 us trip, the early
+        // ones mostly came back empty and the partials' polls queued behind them -- 7.1 vs 5.8 us per iteration at n = 250 k.)
         for (int idx = tid; idx < 2 * H; idx += NTHR) {
             const int widx = idx < H ? idx : idx + OWN;
             const int64_t gc = w0 + widx;
             if (gc >= 0 && gc < n) {
-                double v;
-                if (!hipk_ll_wait(a.r_ll + 2 * gc, seq, v)) *fail = 1;
+                double v = 0.0;
+                if (!hipk_ll_wait(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
                 rw[widx] = v;
             }
         }
         HIPK_MSTAMP(7);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(a.rr_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(rr_ll, g, seq, fail);
         HIPK_MSTAMP(8);
         __syncthreads();
         const double rr = hipk_mid_tree(sb + buf * 256 * NCH, lane);

@@ -560,8 +560,11 @@ def test_cg_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
             # more than 8 chunks: up to 512 workgroups spread over the chip (agent-scope hand-offs, one lane per chunk in the folds)
             create_poisson_2d_csr(181, 181, device=dev), create_poisson_2d_csr(300, 200, device=dev),
             create_poisson_2d_csr(256, 256, device=dev), create_variable_diffusion_2d_csr(129, 128, device=dev)]
-    variants = ({}, {"HIPK_CG_NO_LDS_LOOP": "1"}, {"HIPK_CG_LAUNCH_ITS": "7"}, {"HIPK_CG_LOOP_AGENT": "1", "HIPK_CG_LAUNCH_ITS": "50"})
-    keys = ("HIPK_CG_NO_LDS_LOOP", "HIPK_CG_LAUNCH_ITS", "HIPK_CG_LOOP_AGENT")
+    # (fp64 systems of 9 .. 32 chunks take the one-workgroup-per-chunk loop of hipk_cg_mid.h by default; HIPK_CG_MID=0 keeps this
+    # kernel on them)
+    variants = ({}, {"HIPK_CG_NO_LDS_LOOP": "1"}, {"HIPK_CG_LAUNCH_ITS": "7"}, {"HIPK_CG_LOOP_AGENT": "1", "HIPK_CG_LAUNCH_ITS": "50"},
+                {"HIPK_CG_MID": "0"}, {"HIPK_CG_MID": "0", "HIPK_CG_LAUNCH_ITS": "7"})
+    keys = ("HIPK_CG_NO_LDS_LOOP", "HIPK_CG_LAUNCH_ITS", "HIPK_CG_LOOP_AGENT", "HIPK_CG_MID")
     for mi, A in enumerate(mats):
         n = A.shape[0]
         for dt in (torch.float64, torch.float32):

@@ -14,9 +14,10 @@ for nx in (200, 300, 400, 500, 600, 720, 1000):
     h = _hipk.handle_for(A)
     b = torch.ones(nx * nx, dtype=torch.float64, device=dev)
     for rep in range(2):
-        for two in ("mid", "1", "0"):
-            os.environ["HIPK_CG_MID"] = "1" if two == "mid" else "0"
-            os.environ["HIPK_CG_TWO_LAUNCH"] = "1" if two == "mid" else two
+        for two in ("mid", "mid-noxcd", "1", "0"):
+            os.environ["HIPK_CG_MID"] = "1" if two.startswith("mid") else "0"
+            os.environ["HIPK_CG_MID_XCD"] = "0" if two == "mid-noxcd" else "1"
+            os.environ["HIPK_CG_TWO_LAUNCH"] = "1" if two.startswith("mid") else two
             x = torch.zeros_like(b)
             _hipk.solve("cg", h, b, x, tol=1e-12, atol=0.0, maxiter=50)
             x.zero_()
