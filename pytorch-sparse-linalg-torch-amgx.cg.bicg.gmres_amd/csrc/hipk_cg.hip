@@ -931,7 +931,8 @@ extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     // r, p, Ap; mid-size systems (two launches per iteration) a second p: the direction step is formed while the old p is gathered
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     // (the one-launch mid-size loop, hipk_cg_mid.h, keeps r as 16-byte flagged words in Ap + that fourth vector)
-    return 256 + hipk_scratch_bytes() + (size_t)(3 + ((gm.g > kMidMinChunks && gm.g <= kMidMaxChunks) ? 1 : 0)) * vec;
+    const bool mid = gm.g > kMidMinChunks && gm.g <= kMidMaxChunks;   // + the chunk-partial slots of that loop, a line each
+    return 256 + hipk_scratch_bytes() + (size_t)(3 + (mid ? 1 : 0)) * vec + (mid ? kMidSlotBytes : 0);
 }
 
 template <typename T>
@@ -1068,8 +1069,13 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             ca.r = (double *)r;
             ca.p = (double *)p;
             ca.r_ll = (unsigned long long *)Ap;      // Ap + the fourth vector: 2 x vec >= 16 n bytes
-            ca.pap_ll = (unsigned long long *)part_c;
-            ca.rr_ll = ca.pap_ll + 2 * kMidMaxChunks;
+            ca.pap_ll = (unsigned long long *)((char *)Ap + 2 * vec8);   // behind the four vectors (hipk_cg_work_bytes)
+            ca.rr_ll = ca.pap_ll + kMidSlotBytes / 16;
+            // a 256-byte line per chunk partial: every workgroup polls every slot, and packed slots are ONE memory channel's
+            // hot spot (same box, us per iteration, 256 B / 16 B per slot: 5.1 / 5.8 at 79 chunks, 5.4 / 6.6 at 123, 6.8 / 8.2 at
+            // 254; 64 B from 257 chunks: 9.65 / 9.95 at 489; 16 B up to 32 chunks: 5.05 / 5.3 at 20) -- HIPK_CG_MID_STRIDE forces
+            ca.slot_stride = getenv("HIPK_CG_MID_STRIDE") ? atoi(getenv("HIPK_CG_MID_STRIDE")) : gm.g <= 32 ? 1 : gm.g <= 256 ? 16 : 4;
+            if (ca.slot_stride < 1 || ca.slot_stride > 16) ca.slot_stride = 16;
             ca.ctl = &scal->ctl;
             ca.gamma = scal->gamma;
             ca.atol2 = &scal->atol2;
@@ -1085,7 +1091,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                 ca.it0 = it;
                 ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec8, stream));
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, 4 * kMidMaxChunks * sizeof(unsigned long long), stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, kMidSlotBytes, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
                 mid_kern<<<hipk_xcd_grid(mid_grid), mid_threads, lds, stream>>>(ca);   // hipk_xcd_chunk: padded to a multiple of 8
                 HIPK_CHECK_HIP(hipGetLastError());

@@ -25,6 +25,7 @@
 
 static constexpr int kMidMinChunks = 8;       // up to 8 chunks the one-XCD kernel (hipk_cg_solve_lds_kernel, LOCAL) is faster
 static constexpr int kMidMaxChunks = 512;     // two partials per thread in the fold
+static constexpr size_t kMidSlotBytes = 2 * (size_t)kMidMaxChunks * 256;   // both partial arrays at the widest slot stride
 static constexpr int kMidSpinBound = 1 << 18; // polls (~1 us each) before a workgroup gives up on a hand-off
 
 // One 16-byte store / load per flagged double: {lo, seq, hi, seq}.  Each 8-byte half validates itself, so a store or load torn
@@ -89,6 +90,7 @@ struct hipk_cg_mid_args {
     int64_t *stop_it;
     int64_t it0, maxiter, max_its;
     int test_not_resident;
+    int slot_stride;              // distance of consecutive chunk-partial slots in 16-byte words (16: a 256-byte line each)
     int xcd_aware;                // 0 (HIPK_CG_MID_XCD=0, A/B measurements): workgroup b takes row range b
 };
 // LDS of a workgroup that owns `nch` chunks with reach H: p window + 8 zero slots | r window | 2 fold buffers | tile sums | flag
@@ -98,18 +100,18 @@ static inline size_t hipk_cg_mid_lds_bytes(int H, int nch) {
 
 // thread t's share of the G flagged chunk partials in the spec's order (hipk_reduce_parts: t, t + 256; the tree follows);
 // *fail set when a partial never arrived
-__device__ __forceinline__ double hipk_mid_poll(hipk_ll_rsrc rs, int g, unsigned seq, int *fail) {
+__device__ __forceinline__ double hipk_mid_poll(hipk_ll_rsrc rs, int g, unsigned seq, int *fail, int ss) {
     const int t = threadIdx.x;
     hipk_v4u w[kMidMaxChunks / 256];
 #pragma unroll
     for (int k = 0; k < kMidMaxChunks / 256; ++k)
-        if (t + k * 256 < g) w[k] = hipk_ll_load(rs, t + k * 256);
+        if (t + k * 256 < g) w[k] = hipk_ll_load(rs, (t + k * 256) * ss);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < kMidMaxChunks / 256; ++k)
         if (t + k * 256 < g) {
             double v = 0.0;
-            if (!hipk_ll_wait(rs, t + k * 256, seq, w[k], v)) *fail = 1;
+            if (!hipk_ll_wait(rs, (t + k * 256) * ss, seq, w[k], v)) *fail = 1;
             acc = acc + v;
         }
     return acc;
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
-    const hipk_ll_rsrc r_ll = hipk_ll_make(a.r_ll, (size_t)n * 16), pap_ll = hipk_ll_make(a.pap_ll, (size_t)g * 16),
-                       rr_ll = hipk_ll_make(a.rr_ll, (size_t)g * 16);
+    const hipk_ll_rsrc r_ll = hipk_ll_make(a.r_ll, (size_t)n * 16), pap_ll = hipk_ll_make(a.pap_ll, (size_t)g * a.slot_stride * 16),
+                       rr_ll = hipk_ll_make(a.rr_ll, (size_t)g * a.slot_stride * 16);
+    const int ss = a.slot_stride;
 
     // ---- the own rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); the p window in LDS
     double xo[R], ro[R], vj[R][W];
@@ -256,10 +259,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             tp = tp + hipk_row_shl<4>(tp);   // (p0+p4) (p1+p5) (p2+p6) (p3+p7)
             tp = tp + hipk_row_shl<2>(tp);   // (p0+p4)+(p2+p6)  (p1+p5)+(p3+p7)
             tp = tp + hipk_row_shl<1>(tp);
-            if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(pap_ll, wg * NCH + q, 0.0 + tp, seq);
+            if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(pap_ll, (wg * NCH + q) * ss, 0.0 + tp, seq);
         }
         HIPK_MSTAMP(1);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(pap_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(pap_ll, g, seq, fail, ss);
         HIPK_MSTAMP(2);
         __syncthreads();
         const double pAp = hipk_mid_tree(sb + buf * 256 * NCH, lane);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (tid < 64 * NCH) {   // wavefront q folds chunk q's 256 chains and publishes the partial
             const int q = tid >> 6;
             const double part = hipk_mid_tree(sb + buf * 256 * NCH + q * 256, lane);
-            if (lane == 0 && wg * NCH + q < g) hipk_ll_put(rr_ll, wg * NCH + q, part, seq);
+            if (lane == 0 && wg * NCH + q < g) hipk_ll_put(rr_ll, (wg * NCH + q) * ss, part, seq);
         }
         buf ^= 1;
         HIPK_MSTAMP(6);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
         }
         HIPK_MSTAMP(7);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(rr_ll, g, seq, fail);
+        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(rr_ll, g, seq, fail, ss);
         HIPK_MSTAMP(8);
         __syncthreads();
         const double rr = hipk_mid_tree(sb + buf * 256 * NCH, lane);

@@ -9,14 +9,16 @@ import torch
 from pytorch_sparse_solver import _hipk
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dev = torch.device("cuda", 0)
+VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ("mid", "mid-noxcd", "1", "0")
 for nx in (200, 300, 400, 500, 600, 720, 1000):
     A = create_poisson_2d_csr(nx, nx, device=dev)
     h = _hipk.handle_for(A)
     b = torch.ones(nx * nx, dtype=torch.float64, device=dev)
     for rep in range(2):
-        for two in ("mid", "mid-noxcd", "1", "0"):
+        for two in VARIANTS:
             os.environ["HIPK_CG_MID"] = "1" if two.startswith("mid") else "0"
             os.environ["HIPK_CG_MID_XCD"] = "0" if two == "mid-noxcd" else "1"
+            os.environ["HIPK_CG_MID_STRIDE"] = two[5:] if two.startswith("mid-s") else "16"
             os.environ["HIPK_CG_TWO_LAUNCH"] = "1" if two.startswith("mid") else two
             x = torch.zeros_like(b)
             _hipk.solve("cg", h, b, x, tol=1e-12, atol=0.0, maxiter=50)
