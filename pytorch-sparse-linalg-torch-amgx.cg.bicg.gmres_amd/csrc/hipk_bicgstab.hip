@@ -55,6 +55,8 @@ struct hipk_eps<float> {
     static constexpr double v = HIPK_EPS32;
 };
 
+#include "hipk_bi_mid.h"   // one-launch loop for mid-size systems (uses hipk_bi_scal, HIPK_EPS64)
+
 template <typename T>
 __global__ __launch_bounds__(HIPK_THREADS) void hipk_bi_start_kernel(
     int64_t n, int ch, int g, hipk_bi_scal *__restrict__ scal, const double *__restrict__ part_rr,
@@ -668,7 +670,10 @@ static constexpr int kBiSlots = 8;
 extern "C" size_t hipk_bicgstab_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
-    return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec;
+    // mid-size systems (hipk_bi_mid.h): q and r travel as 16-byte flagged words (q in s + t, r in two more vectors) + the partial slots
+    const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
+    const bool mid = gm.g > kMidMinChunks && gm.g <= kBiMidMaxChunks;
+    return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec + (mid ? 4 * vec + kBiMidSlotBytes : 0);
 }
 extern "C" size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
@@ -756,6 +761,94 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     sq.skip_combine = stt.skip_combine = small ? 1 : 0;
 
     int64_t it = 0, stop = INT64_MAX;
+    // launch-bound systems of 9 .. 256 chunks (fp64, M = identity, rows of <= 12 entries within a window around their chunk): the
+    // whole loop in one launch, one workgroup per chunk (hipk_bi_mid.h); HIPK_BICGSTAB_MID=0 leaves them to the paths below
+    static bool mid_failed = false;
+    bool mid_loop = false;
+    if constexpr (sizeof(T) == 8 && !PRE) {
+        mid_loop = !ext && gm.g > kMidMinChunks && gm.g <= kBiMidMaxChunks && gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+                   A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
+                   !(getenv("HIPK_BICGSTAB_MID") && getenv("HIPK_BICGSTAB_MID")[0] == '0') && !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") &&
+                   !getenv("HIPK_BICGSTAB_NO_SMALL");
+        void (*mid_kern)(hipk_bi_mid_args) = A->max_row_len <= 5   ? hipk_bi_mid_kernel<5>
+                                             : A->max_row_len <= 7 ? hipk_bi_mid_kernel<7>
+                                             : A->max_row_len <= 9 ? hipk_bi_mid_kernel<9>
+                                                                   : hipk_bi_mid_kernel<12>;
+        int H = 0;
+        size_t lds = 0;
+        if (mid_loop) {
+            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
+                int *out = (int *)part_spare, reach = 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+                int rgrid = (int)((n + 255) / 256);
+                if (rgrid > 2048) rgrid = 2048;
+                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                A->mid_reach1 = reach + 1;
+            }
+            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
+            lds = hipk_bi_mid_lds_bytes(H);
+            int occ = 0;
+            mid_loop = lds <= (size_t)160 * 1024 &&
+                       hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
+            (void)hipGetLastError();
+        }
+        if (mid_loop) {
+            const char *e = getenv("HIPK_BICGSTAB_LAUNCH_ITS");
+            hipk_bi_mid_args ca;
+            ca.n = n;
+            ca.g = gm.g;
+            ca.H = H;
+            ca.crow = A->crow;
+            ca.col = A->col;
+            ca.val = (const double *)A->val;
+            ca.x = (double *)x;
+            ca.r = (double *)r;
+            ca.p = (double *)p;
+            ca.q = (double *)q;
+            ca.rhat = (const double *)rhat;
+            ca.q_ll = (unsigned long long *)s;                      // s + t: 2 x vec >= 16 n bytes (both are scratch of the launch sequence)
+            ca.r_ll = (unsigned long long *)(vbase + 8 * vec);      // behind the eight vectors (hipk_bicgstab_work_bytes)
+            ca.slots = (unsigned long long *)(vbase + 10 * vec);
+            ca.part_rr = part_rr;
+            ca.part_rhr = part_rhr;
+            ca.scal = scal;
+            ca.maxiter = maxiter;
+            ca.max_its = e ? atoll(e) : 8192;
+            if (ca.max_its < 1) ca.max_its = 1;
+            ca.slot_stride = gm.g <= 32 ? 1 : 16;
+            ca.xcd_aware = 1;
+            const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+            int launch_no = 0;
+            hipk_bi_scal hs0;
+            for (;;) {
+                ca.it0 = it;
+                ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.q_ll, 0, 2 * vec, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.slots, 0, kBiMidSlotBytes, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
+                mid_kern<<<hipk_xcd_grid(gm.g), 1024, lds, stream>>>(ca);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                if (hs0.redo < 0) {
+                    if (hs0.redo == -3) {
+                        hipk_set_error("hipk_bicgstab_solve: a resident workgroup of the one-launch loop stopped arriving");
+                        return HIPK_ERR_HIP;
+                    }
+                    if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;   // not co-resident; this launch modified nothing
+                    mid_loop = false;
+                    break;
+                }
+                it = hs0.it_done;
+                if (hs0.stop_it <= it || it >= maxiter) break;
+            }
+        }
+    }
     // launch-bound systems with short rows, M = identity: the whole loop in one launch (hipk_bi_solve_lds_kernel)
     static bool lds_loop_failed = false;   // its workgroups once failed to meet (a shared device): do not wait for that verdict again
     // up to 64 workgroups (8 chunks) on ONE XCD; up to 32 chunks (n <= 65536) spread over the chip, two workgroups per compute unit
@@ -763,7 +856,8 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     bool lds_loop = gm.g <= 32 && !getenv("HIPK_BICGSTAB_NO_SMALL") && !ext && gm.ch == HIPK_BASE_CHUNK &&
                     A->max_row_len <= kBiRowRegs && prm->profile == 0 && maxiter > 0 &&
                     kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_loop_failed &&
-                    !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
+                    !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD")) && !mid_loop &&
+                    it == 0;   // (after a one-launch loop above gave up mid-solve, part_rr / part_rhr hold CHUNK partials: launch sequence)
     if (lds_loop) {
         bool local = !lds_spread && !getenv("HIPK_BICGSTAB_LOOP_AGENT");
         const char *e = getenv("HIPK_BICGSTAB_LAUNCH_ITS");
@@ -835,6 +929,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             if (hs0.stop_it <= it || it >= maxiter) break;
         }
     }
+    if (mid_loop) lds_loop = true;   // finished in the one-launch loop
     for (; !lds_loop && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;

@@ -610,9 +610,12 @@ def test_bicgstab_whole_loop_in_one_launch_is_bit_identical(monkeypatch):
             # more than 8 chunks: workgroups spread over the chip (agent-scope hand-offs, one lane per chunk in the folds)
             create_convdiff_2d_csr(181, 181, device=dev), create_convdiff_2d_csr(300, 200, device=dev),
             create_convdiff_2d_csr(256, 256, device=dev)]
+    # (fp64 systems of 9 .. 32 chunks with M = identity take the one-workgroup-per-chunk loop of hipk_bi_mid.h by default;
+    # HIPK_BICGSTAB_MID=0 keeps this kernel on them)
     variants = ({}, {"HIPK_BICGSTAB_NO_LDS_LOOP": "1"}, {"HIPK_BICGSTAB_LAUNCH_ITS": "5"},
-                {"HIPK_BICGSTAB_LOOP_AGENT": "1", "HIPK_BICGSTAB_LAUNCH_ITS": "40"})
-    keys = ("HIPK_BICGSTAB_NO_LDS_LOOP", "HIPK_BICGSTAB_LAUNCH_ITS", "HIPK_BICGSTAB_LOOP_AGENT")
+                {"HIPK_BICGSTAB_LOOP_AGENT": "1", "HIPK_BICGSTAB_LAUNCH_ITS": "40"}, {"HIPK_BICGSTAB_MID": "0"},
+                {"HIPK_BICGSTAB_MID": "0", "HIPK_BICGSTAB_LAUNCH_ITS": "5"})
+    keys = ("HIPK_BICGSTAB_NO_LDS_LOOP", "HIPK_BICGSTAB_LAUNCH_ITS", "HIPK_BICGSTAB_LOOP_AGENT", "HIPK_BICGSTAB_MID")
     for mi, A in enumerate(mats):
         n = A.shape[0]
         for dt in (torch.float64, torch.float32):
@@ -931,3 +934,86 @@ def test_cg_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
     ref = oracle.cg(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
                     np.ones(A.shape[0]), **kw)
     assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)
+
+
+@pytest.mark.gpu
+def test_bicgstab_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
+    """Launch-bound mid-size fp64 systems (9 .. 256 reduction chunks, M = identity, rows of <= 12 entries within a window around
+    their chunk) run the WHOLE BiCGStab loop in one launch, one workgroup per chunk (csrc/hipk_bi_mid.h): three hand-offs per
+    iteration instead of five launches, p and s advanced over an LDS window on the consumer side.  Same bits as the launch
+    sequence (HIPK_BICGSTAB_MID=0 + HIPK_BICGSTAB_NO_LDS_LOOP=1) -- x, iteration count, matvecs, info, residuals, breakdown codes --
+    for nonsymmetric and symmetric stencils, per-entry values, a 3-D stencil, a banded random matrix with 9 .. 11 entries per row,
+    ragged last chunks, warm starts, maxiter cut-offs, the early exit, re-launches every 5 iterations, not-co-resident launches
+    (first and second), a breakdown; and, on one system, as the CPU oracle."""
+    import scipy.sparse as sp
+    from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_poisson_2d_csr,
+                                                          create_variable_diffusion_2d_csr)
+
+    def convdiff3d(m):
+        T = sp.diags([-1.3, 2.0, -0.7], [-1, 0, 1], shape=(m, m))
+        I = sp.identity(m)
+        return _scipy_to_csr_dev(sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T))
+
+    def banded(n, offs, seed):
+        rng = np.random.default_rng(seed)
+        M = sp.diags([rng.uniform(-1.0, -0.1, n - abs(o)) for o in offs], offs, shape=(n, n))
+        return _scipy_to_csr_dev(M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 0.5))
+
+    cases = [(create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {}),                      # 44 chunks
+             (create_convdiff_2d_csr(500, 500, device=DEV), dict(tol=1e-6), {}),                      # 123 chunks
+             (create_convdiff_2d_csr(550, 557, device=DEV), dict(tol=1e-5), {}),                      # ragged last chunk
+             (create_variable_diffusion_2d_csr(400, 300, device=DEV), dict(tol=1e-7), {}),
+             (create_poisson_2d_csr(720, 720, device=DEV), dict(tol=1e-5), {}),                       # 254 chunks
+             (create_convdiff_2d_csr(150, 150, device=DEV), dict(tol=1e-9), {}),                      # 11 chunks
+             (convdiff3d(44), dict(tol=1e-8), {}),                                                    # 7 entries per row, reach 1936
+             (banded(100003, (-1400, -700, -3, -2, -1, 1, 2, 3, 650, 1500), 5), dict(tol=1e-10), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=15), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=1), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-12, maxiter=0), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=0.5), {}),                       # b = A x0 below: stops at iteration 0
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_BICGSTAB_LAUNCH_ITS": "5"}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_TEST_LDS_NOT_RESIDENT": "1"}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_BICGSTAB_LAUNCH_ITS": "5", "HIPK_TEST_LDS_NOT_RESIDENT": "2"}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-30, maxiter=400), {})]       # runs into the iteration bound (or a breakdown)
+    for idx, (A, kw, env) in enumerate(cases):
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        g = torch.Generator(device=DEV).manual_seed(idx)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        if idx == 11:
+            x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+            b = hipk.spmv(h, x0)
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_BICGSTAB_MID", mid)
+            if mid == "0":
+                monkeypatch.setenv("HIPK_BICGSTAB_NO_LDS_LOOP", "1")
+            else:
+                monkeypatch.delenv("HIPK_BICGSTAB_NO_LDS_LOOP", raising=False)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b) if x0 is None else x0.clone()
+            print("bicgstab mid case", idx, "mid" if mid == "1" else "launch sequence", flush=True)   # (-s: which case a hang is in)
+            st = hipk.solve("bicgstab", h, b, x, atol=0.0, **{"maxiter": None, **kw})
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
+        assert torch.equal(torch.nan_to_num(out[0][0], nan=0.5), torch.nan_to_num(out[1][0], nan=0.5)), (idx, out[0][1:], out[1][1:])
+        assert all(a == b_ or (a != a and b_ != b_) for a, b_ in zip(out[0][1:], out[1][1:])), (idx, out[0][1:], out[1][1:])
+        if idx == 11:
+            assert out[0][1] == 0
+        if idx < 8:
+            assert out[0][1] > 10, (idx, out[0][1])
+    monkeypatch.delenv("HIPK_BICGSTAB_MID", raising=False)
+    monkeypatch.delenv("HIPK_BICGSTAB_NO_LDS_LOOP", raising=False)
+    A, kw, _ = cases[3]   # (the convection-diffusion systems above diverge for b = ones: a bounded run on a diffusion system)
+    b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
+    x = torch.zeros_like(b)
+    st = hipk.solve("bicgstab", hipk.handle_for(A), b, x, atol=0.0, maxiter=1500, **kw)
+    Ac = A.cpu()
+    ref = oracle.bicgstab(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
+                          np.ones(A.shape[0]), maxiter=1500, **kw)
+    assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)
+    assert st.iterations > 20
