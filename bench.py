@@ -477,6 +477,33 @@ def main():
             _hipk.clear_cache()
             torch.cuda.empty_cache()
 
+    # ---- launch-bound sizes: per-iteration time of whole cg / bicgstab solves through the C entry points on
+    # systems the one-launch loops take (csrc/hipk_cg_mid.h, hipk_bi_mid.h); fixed iteration counts, b = ones, wall clock around
+    # the call with the device drained on both sides.  Reported beside the headline, never part of `value`.
+    launch_bound = None
+    if not use_dist and nx == NX and not strong and not args.no_n64m:
+        launch_bound = []
+        from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
+        for solver, mk, side, its in (("cg", create_poisson_2d_csr, 500, 1000), ("cg", create_poisson_2d_csr, 1000, 1000),
+                                      ("bicgstab", create_convdiff_2d_csr, 500, 60)):
+            Am = mk(side, side, device=dev)
+            hm = _hipk.handle_for(Am)
+            bm = torch.ones(side * side, dtype=torch.float64, device=dev)
+            best = None
+            for rep in range(3):
+                xm = torch.zeros_like(bm)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                stm = _hipk.solve(solver, hm, bm, xm, tol=1e-12, atol=0.0, maxiter=its)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / max(stm.iterations, 1) * 1e6
+                best = us if best is None or us < best else best
+            launch_bound.append({"solver": solver, "rows": side * side, "reduction_chunks": -(-side * side // 2048),
+                                 "iterations": stm.iterations, "us_per_iteration": round(best, 2)})
+            del Am, hm, bm, xm
+        _hipk.clear_cache()
+        torch.cuda.empty_cache()
+
     if use_dist:
         # roofline leg at N > 1: this rank's local SpMV (no communication), HIP events on the launch stream,
         # on the bytes the selected path streams
@@ -532,6 +559,8 @@ def main():
             "kernels": kernels,
             "roofline": roof,
         }
+        if launch_bound is not None:
+            out["launch_bound_sizes"] = launch_bound
         if not args.no_cpu_baseline and not use_dist and nx == NX:
             out["cpu_baseline"] = cpu_baseline(nx, args.cpu_iters)
         line = json.dumps(out)

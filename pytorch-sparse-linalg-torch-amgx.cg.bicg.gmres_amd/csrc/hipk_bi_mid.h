@@ -122,8 +122,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     int code = 0, extra_mv = 0;
     double part_rr_own = 0.0, part_rhr_own = 0.0;   // this chunk's partials of the last completed iteration
     bool have_parts = false;
+    const int H_ = H, WIN_ = WIN;
     while (it < stop_it && it - a.it0 < a.max_its) {
         ++seq;
+        // the window geometry is made opaque once per iteration: otherwise every LDS address of the loop (three windows x gathered
+        // columns, own rows, passes) is formed ahead of it and kept in a register -- 25 VGPRs spilled at W = 5 with that
+        int H = H_, WIN = WIN_;
+        asm volatile("" : "+s"(H), "+s"(WIN));
+        double *qw = pw + WIN + 8, *rw = qw + WIN, *hw = rw + WIN + 8;
         double *sbb = sb + buf * 3 * 256;
         // ---- K1: rs = <r,r>, rho' = <rhat,r> -> tests; beta; p = r + beta (p - omega q) over the window   (TSL:893-907)
         if (tid < 256) {

@@ -138,8 +138,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #ifdef HIPK_GM_STAMPS
     unsigned long long st_acc[HIPK_MID_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memrealtime();
 #endif
+    const int H_ = H, WIN_ = WIN;
     while (!done) {
         ++seq;
+        // the window geometry is made opaque once per iteration: otherwise every LDS address of the loop is formed ahead of it and
+        // kept in a register (hipk_bi_mid.h: 25 spilled VGPRs became 1)
+        int H = H_, WIN = WIN_;
+        asm volatile("" : "+s"(H), "+s"(WIN));
+        double *rw = pw + WIN + 8;
         // ---- A p of the own rows (products rounded, added in CSR order), wavefront sums of p .* (A p)   (TSL:845-846)
         double Ap[R];
 #pragma unroll

@@ -23,7 +23,7 @@ def _vgprs(src):
                "-Rpass-analysis=kernel-resource-usage"]
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    usage, sgprs, name = {}, {}, None
+    usage, sgprs, scratch, name = {}, {}, {}, None
     for line in p.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
@@ -34,10 +34,14 @@ def _vgprs(src):
         m = re.search(r"\bVGPRs: (\d+)", line)
         if m and name:
             usage[name] = int(m.group(1))
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            scratch[name] = int(m.group(1))
     filt = shutil.which("c++filt")
     names = subprocess.run([filt], input="\n".join(usage), capture_output=True, text=True).stdout.splitlines()
     out = {d.split("(")[0]: v for d, v in zip(names, usage.values())}
     _vgprs.sgprs = {d.split("(")[0]: sgprs.get(k, 0) for d, k in zip(names, usage)}
+    _vgprs.scratch = {d.split("(")[0]: scratch.get(k, 0) for d, k in zip(names, usage)}
     return out
 
 
@@ -68,3 +72,23 @@ def test_bandwidth_bound_kernels_keep_eight_workgroups_per_cu(src):
         # MI355X admits only SEVEN 256-thread workgroups per CU at 82-96 scalar registers although the occupancy API says 8
         # (MI355X_MICROARCH.md "Residency"; round 3 found the GMRES multi-dot at 96 and the fused-exchange CG kernels at 83-84)
         assert _vgprs.sgprs[k] <= 80, f"{k}: {_vgprs.sgprs[k]} SGPRs (> 80: the hardware admits fewer than 8 workgroups per CU)"
+
+
+# The one-launch loops of mid-size systems (hipk_cg_mid.h, hipk_bi_mid.h) run 1024 threads per workgroup, one workgroup per CU:
+# four wavefronts per SIMD = 128 VGPRs.  The instantiations the stencil matrices take must fit them without (or nearly without)
+# scratch: their phases are VALU-issue bound, every spilled register is a memory round trip per iteration.
+MID = {
+    "hipk_cg.hip": {"void hipk_cg_mid_kernel<5, 1>": 0, "void hipk_cg_mid_kernel<7, 1>": 0, "void hipk_cg_mid_kernel<9, 1>": 0,
+                    "void hipk_cg_mid_kernel<5, 2>": 48},
+    "hipk_bicgstab.hip": {"void hipk_bi_mid_kernel<5>": 8, "void hipk_bi_mid_kernel<7>": 40},
+}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="hipcc / c++filt not installed")
+@pytest.mark.parametrize("src", sorted(MID))
+def test_one_launch_loops_fit_four_wavefronts_per_simd(src):
+    got = _vgprs(src)
+    for k, max_scratch in MID[src].items():
+        assert k in got, (k, sorted(got)[:60])
+        assert got[k] <= 128, f"{k}: {got[k]} VGPRs (> 128: a 1024-thread workgroup no longer fits a CU)"
+        assert _vgprs.scratch[k] <= max_scratch, f"{k}: {_vgprs.scratch[k]} bytes of scratch per lane (budget {max_scratch})"
