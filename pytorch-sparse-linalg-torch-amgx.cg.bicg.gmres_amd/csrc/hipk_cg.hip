@@ -1059,6 +1059,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             const size_t vec8 = hipk_align_up((size_t)n * sizeof(double), 256);
             const char *e = getenv("HIPK_CG_LAUNCH_ITS");
             hipk_cg_mid_args ca;
+            memset(&ca, 0, sizeof(ca));
             ca.n = n;
             ca.g = gm.g;
             ca.H = H;
@@ -1519,6 +1520,8 @@ extern "C" int hipk_cgm_direction(int64_t n_local, int chunk_rows, int g_red, vo
 // (16 n more than plain CG: dinv is read by both vector kernels).  Mirrored by orc_pcg_jacobi.
 //   partial slots: a <p,Ap> | b <r,r> | c spare dot of the SpMV | z0, z1 <r,z> ping-pong (read by all workgroups
 //   of the update kernel while the early ones already write the next one) | d <b,b> / <x,x>
+static constexpr int kPcgMidMaxChunks = 256;                                 // one chunk per workgroup, one workgroup per CU
+static constexpr size_t kPcgMidSlotBytes = 3 * (size_t)kMidMaxChunks * 256;   // <p,Ap>, <r,r>, <r,z> slot arrays
 struct hipk_pcg_scal {
     double atol2, bs, res2, xx, rs_last;
     int64_t stop_it;
@@ -1682,7 +1685,10 @@ __global__ __launch_bounds__(HIPK_THREADS) void hipk_pcg_final_kernel(hipk_pcg_s
 extern "C" size_t hipk_pcg_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
-    return 256 + 6 * HIPK_MAX_PARTS * sizeof(double) + 3 * vec;  // scalars | six partial slots | r, p, Ap
+    // mid-size systems (the one-launch loop, hipk_cg_mid.h<.., PRE>): r as 16-byte flagged words in Ap + a fourth vector, three slot arrays
+    const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
+    const bool mid = gm.g > kMidMinChunks && gm.g <= kPcgMidMaxChunks;
+    return 256 + 6 * HIPK_MAX_PARTS * sizeof(double) + (size_t)(3 + (mid ? 1 : 0)) * vec + (mid ? kPcgMidSlotBytes : 0);  // scalars | six partial slots | r, p, Ap
 }
 
 template <typename T>
@@ -1746,12 +1752,105 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     sa.stop_it = &scal->stop_it;
 
     int64_t it = 0, stop = INT64_MAX;
+    // launch-bound systems of 9 .. 256 chunks (fp64, rows of <= 12 entries within a window around their chunk): the whole loop in one
+    // launch, one workgroup per chunk (hipk_cg_mid_kernel<W, 1, PRE = true>); HIPK_CG_MID=0 leaves them to the paths below
+    static bool mid_failed = false;
+    bool mid_loop = false;
+    if constexpr (sizeof(T) == 8) {
+        mid_loop = gm.g > kMidMinChunks && gm.g <= kPcgMidMaxChunks && gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
+                   A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
+                   !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0') && !getenv("HIPK_CG_NO_LDS_LOOP") && !getenv("HIPK_CG_NO_SMALL");
+        void (*mid_kern)(hipk_cg_mid_args) = A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1, true>
+                                             : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1, true>
+                                             : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1, true>
+                                                                   : hipk_cg_mid_kernel<12, 1, true>;
+        int H = 0;
+        size_t lds = 0;
+        if (mid_loop) {
+            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
+                int *out = (int *)part_c, reach = 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+                int rgrid = (int)((n + 255) / 256);
+                if (rgrid > 2048) rgrid = 2048;
+                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                A->mid_reach1 = reach + 1;
+            }
+            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
+            lds = hipk_cg_mid_lds_bytes(H, 1, true);
+            int occ = 0;
+            mid_loop = lds <= (size_t)160 * 1024 &&
+                       hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
+            (void)hipGetLastError();
+        }
+        if (mid_loop) {
+            const char *e = getenv("HIPK_CG_LAUNCH_ITS");
+            hipk_cg_mid_args ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.n = n;
+            ca.g = gm.g;
+            ca.H = H;
+            ca.crow = A->crow;
+            ca.col = A->col;
+            ca.val = (const double *)A->val;
+            ca.x = (double *)x;
+            ca.r = (double *)r;
+            ca.p = (double *)p;
+            ca.r_ll = (unsigned long long *)Ap;                          // Ap + the fourth vector: 2 x vec >= 16 n bytes
+            ca.pap_ll = (unsigned long long *)((char *)Ap + 2 * vec);    // behind the four vectors (hipk_pcg_work_bytes)
+            ca.rr_ll = ca.pap_ll + (size_t)kMidMaxChunks * 256 / 8;
+            ca.rz_ll = ca.rr_ll + (size_t)kMidMaxChunks * 256 / 8;
+            ca.dinv = (const double *)dinv;
+            ca.rz0_parts = part_z[0];
+            ca.slot_stride = gm.g <= 32 ? 1 : 16;
+            ca.xcd_aware = 1;
+            ca.ctl = &scal->ctl;
+            ca.gamma = scal->gamma;
+            ca.atol2 = &scal->atol2;
+            ca.stop_it = &scal->stop_it;
+            ca.maxiter = maxiter;
+            ca.max_its = e ? atoll(e) : 16384;
+            if (ca.max_its < 1) ca.max_its = 1;
+            const int fail_launch = getenv("HIPK_TEST_LDS_NOT_RESIDENT") ? (atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) > 1 ? atoi(getenv("HIPK_TEST_LDS_NOT_RESIDENT")) : 1) : 0;
+            int launch_no = 0;
+            hipk_pcg_scal hs0;
+            for (;;) {
+                ca.it0 = it;
+                ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, kPcgMidSlotBytes, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
+                mid_kern<<<hipk_xcd_grid(gm.g), 1024, lds, stream>>>(ca);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&hs0, scal, sizeof(hs0), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                if (hs0.ctl.redo < 0) {
+                    if (hs0.ctl.redo == -3) {
+                        hipk_set_error("hipk_pcg_solve: a resident workgroup of the one-launch loop stopped arriving");
+                        return HIPK_ERR_HIP;
+                    }
+                    if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;   // this launch modified nothing
+                    if (it > 0) {   // as below: <r,z> lives in scal->gamma[it & 1]; the launch sequence folds it from part_z[it & 1]
+                        HIPK_CHECK_HIP(hipMemsetAsync(part_z[it & 1], 0, (size_t)gm.g * sizeof(double), stream));
+                        HIPK_CHECK_HIP(hipMemcpyAsync(part_z[it & 1], &scal->gamma[it & 1], sizeof(double), hipMemcpyDeviceToDevice, stream));
+                    }
+                    mid_loop = false;
+                    break;
+                }
+                it = hs0.ctl.it_done;
+                if (hs0.stop_it <= it || it >= maxiter) break;
+            }
+        }
+    }
     // launch-bound systems with short rows: the whole loop in one launch (hipk_cg_solve_lds_kernel<.., PRE = true>)
     static bool lds_loop_failed = false;
     const bool lds_spread = kGmSub * gm.g > 64;
     bool lds_loop = gm.g <= 32 && gm.ch == HIPK_BASE_CHUNK && A->max_row_len <= kCgRowRegs && prm->profile == 0 && maxiter > 0 &&
                     kGmSub * gm.g <= (lds_spread ? 2 * A->n_cu : 2 * (A->n_cu / 8)) && !lds_loop_failed &&
-                    !getenv("HIPK_CG_NO_SMALL") && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD"));
+                    !getenv("HIPK_CG_NO_SMALL") && !getenv("HIPK_CG_NO_LDS_LOOP") && !(lds_spread && getenv("HIPK_NO_LDS_SPREAD")) && !mid_loop;
     if (lds_loop) {
         bool local = !lds_spread && !getenv("HIPK_CG_LOOP_AGENT");
         const char *e = getenv("HIPK_CG_LAUNCH_ITS");
@@ -1821,6 +1920,7 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
             if (hs0.stop_it <= it || it >= maxiter) break;
         }
     }
+    if (mid_loop) lds_loop = true;   // finished in the one-launch loop
     for (; !lds_loop && it < maxiter; ++it) {
         HIPK_CHECK_HIP(pace.gate(it, stream, &stop));
         if (stop <= it) break;

@@ -32,6 +32,9 @@ struct hipk_cg_mid_args {
     unsigned long long *r_ll;     // [2 n] flagged words of r
     unsigned long long *pap_ll;   // [2 g] chunk partials of <p,Ap>
     unsigned long long *rr_ll;    // [2 g] chunk partials of <r,r>
+    unsigned long long *rz_ll;    // PRE: chunk partials of <r, M r>
+    const double *dinv;           // PRE: the Jacobi preconditioner's diagonal, M = diag(dinv) (TSL:849)
+    const double *rz0_parts;      // PRE, it0 = 0: chunk partials of gamma0 = <r0, M r0> (hipk_pcg_start_kernel)
     hipk_lds_ctl *ctl;
     double *gamma;
     const double *atol2;
@@ -42,8 +45,8 @@ struct hipk_cg_mid_args {
     int xcd_aware;                // 0 (HIPK_CG_MID_XCD=0, A/B measurements): workgroup b takes row range b
 };
 // LDS of a workgroup that owns `nch` chunks with reach H: p window + 8 zero slots | r window | 2 fold buffers | tile sums | flag
-static inline size_t hipk_cg_mid_lds_bytes(int H, int nch) {
-    return (size_t)(2 * (nch * HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 * nch + 32 * nch + 8) * sizeof(double);
+static inline size_t hipk_cg_mid_lds_bytes(int H, int nch, bool pre = false) {   // pre: + the window of dinv, two sums per fold
+    return (size_t)((pre ? 3 : 2) * (nch * HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 * nch * (pre ? 2 : 1) + 32 * nch + 8) * sizeof(double);
 }
 
 // Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the iterations of a launch, the constant 100 MHz clock
@@ -63,8 +66,12 @@ __device__ unsigned long long hipk_mid_stamps[kMidMaxChunks * HIPK_MID_NSTAMP];
 
 // W: matrix entries per row held in registers; NCH: reduction chunks per workgroup (1: up to n_cu chunks; 2: beyond -- half the
 // rows then sit inside a workgroup's own window and are not published).  1024 threads, 2 NCH rows each, one workgroup per CU.
-template <int W, int NCH>
+// PRE (NCH = 1 only): Jacobi-preconditioned CG -- z = dinv .* r is formed where it is used (never stored), gamma = <r,z> steers
+// alpha and beta, <r,r> the stop test (TSL:835-841, 849-852; hipk_pcg_update_kernel / hipk_pcg_direction_kernel bit for bit).
+template <int W, int NCH, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
+    static_assert(!PRE || NCH == 1, "the preconditioned form owns one chunk per workgroup");
+    constexpr int NSB = 256 * NCH * (PRE ? 2 : 1);   // doubles of one fold buffer
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, NT = CH / HIPK_TILE;   // a chunk: 2048 rows = 8 tiles of 256
     constexpr int OWN = NCH * CH, R = OWN / NTHR, TSTEP = NTHR / HIPK_TILE;  // rows per thread; tiles one pass of the workgroup covers
     extern __shared__ double mid_lds[];
@@ -77,15 +84,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
     double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows
-    double *sb = rw + WIN;           // 2 x [256 NCH]: fold buffers, used alternately (one barrier per fold)
-    double *ts = sb + 2 * 256 * NCH; // [32 NCH] wavefront sums of <p,Ap>, 4 per tile
+    double *sb = rw + WIN;           // 2 x [NSB]: fold buffers, used alternately (one barrier per fold)
+    double *ts = sb + 2 * NSB;       // [32 NCH] wavefront sums of <p,Ap>, 4 per tile
     int *fail = (int *)(ts + 32 * NCH);
+    double *dw = (double *)(fail + 2);   // PRE: dinv at the window's columns
     const int64_t n = a.n, base = (int64_t)wg * OWN, w0 = base - H;
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
     const hipk_ll_rsrc r_ll = hipk_ll_make(a.r_ll, (size_t)n * 16), pap_ll = hipk_ll_make(a.pap_ll, (size_t)g * a.slot_stride * 16),
-                       rr_ll = hipk_ll_make(a.rr_ll, (size_t)g * a.slot_stride * 16);
+                       rr_ll = hipk_ll_make(a.rr_ll, (size_t)g * a.slot_stride * 16),
+                       rz_ll = hipk_ll_make(PRE ? a.rz_ll : a.rr_ll, (size_t)g * a.slot_stride * 16);
     const int ss = a.slot_stride;
 
     // ---- the own rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); the p window in LDS
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const int64_t gc = w0 + idx;
         pw[idx] = (gc >= 0 && gc < n) ? a.p[gc] : 0.0;
         rw[idx] = 0.0;
+        if (PRE) dw[idx] = (gc >= 0 && gc < n) ? a.dinv[gc] : 0.0;
     }
     double gamma = a.gamma[a.it0 & 1];
     const double atol2 = *a.atol2;
@@ -130,6 +140,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (!hipk_gbar(&scal->bar, nwg, epoch, fail) || a.test_not_resident) {
         if (tid == 0) scal->redo = -1;
         return;
+    }
+    if (PRE && a.it0 == 0) {   // gamma0 = <r0, M r0>: chunk partials of the launch before this one (hipk_reduce_parts)
+        if (tid < 256) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < kMidMaxChunks / 256; ++k)
+                if (tid + k * 256 < g) acc = acc + a.rz0_parts[tid + k * 256];
+            sb[tid] = acc;
+        }
+        __syncthreads();
+        gamma = hipk_mid_tree(sb, lane);
+        __syncthreads();
     }
     unsigned seq = 0;
     int buf = 0;
@@ -146,6 +168,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         int H = H_, WIN = WIN_;
         asm volatile("" : "+s"(H), "+s"(WIN));
         double *rw = pw + WIN + 8;
+        double *dw = (double *)((int *)(rw + WIN + 2 * NSB + 32 * NCH) + 2);
         // ---- A p of the own rows (products rounded, added in CSR order), wavefront sums of p .* (A p)   (TSL:845-846)
         double Ap[R];
 #pragma unroll
@@ -179,10 +202,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(pap_ll, (wg * NCH + q) * ss, 0.0 + tp, seq);
         }
         HIPK_MSTAMP(1);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(pap_ll, g, seq, fail, ss);
+        if (tid < 256) sb[buf * NSB + tid] = hipk_mid_poll(pap_ll, g, seq, fail, ss);
         HIPK_MSTAMP(2);
         __syncthreads();
-        const double pAp = hipk_mid_tree(sb + buf * 256 * NCH, lane);
+        const double pAp = hipk_mid_tree(sb + buf * NSB, lane);
         buf ^= 1;
         HIPK_MSTAMP(3);
         if (*fail) {
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         HIPK_MSTAMP(4);
         if (tid < 256 * NCH) {
             const int q = tid >> 8, t = tid & 255;
-            double acc = 0.0;   // virtual thread t of chunk q: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
+            double acc = 0.0, acc1 = 0.0;   // virtual thread t of chunk q: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
 #pragma unroll
             for (int j = 0; j < CH / 512; ++j)
 #pragma unroll
@@ -214,15 +237,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     const int i = q * CH + 2 * t + 512 * j + k;
                     const double v = rw[H + i];
                     if (base + i < n) acc = fma(v, v, acc);
+                    if (PRE) {
+                        const double z = dw[H + i] * v;   // TSL:849
+                        if (base + i < n) acc1 = fma(v, z, acc1);   // TSL:850
+                    }
                 }
-            sb[buf * 256 * NCH + tid] = acc;
+            sb[buf * NSB + tid] = acc;
+            if (PRE) sb[buf * NSB + 256 + tid] = acc1;
         }
         HIPK_MSTAMP(5);
         __syncthreads();
         if (tid < 64 * NCH) {   // wavefront q folds chunk q's 256 chains and publishes the partial
             const int q = tid >> 6;
-            const double part = hipk_mid_tree(sb + buf * 256 * NCH + q * 256, lane);
+            const double part = hipk_mid_tree(sb + buf * NSB + q * 256, lane);
             if (lane == 0 && wg * NCH + q < g) hipk_ll_put(rr_ll, (wg * NCH + q) * ss, part, seq);
+        } else if (PRE && tid < 128) {
+            const double part = hipk_mid_tree(sb + buf * NSB + 256, lane);
+            if (lane == 0) hipk_ll_put(rz_ll, wg * ss, part, seq);
         }
         buf ^= 1;
         HIPK_MSTAMP(6);
@@ -239,10 +270,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
         }
         HIPK_MSTAMP(7);
-        if (tid < 256) sb[buf * 256 * NCH + tid] = hipk_mid_poll(rr_ll, g, seq, fail, ss);
+        if (tid < 256) {
+            sb[buf * NSB + tid] = hipk_mid_poll(rr_ll, g, seq, fail, ss);
+            if (PRE) sb[buf * NSB + 256 + tid] = hipk_mid_poll(rz_ll, g, seq, fail, ss);
+        }
         HIPK_MSTAMP(8);
         __syncthreads();
-        const double rr = hipk_mid_tree(sb + buf * 256 * NCH, lane);
+        const double rr = hipk_mid_tree(sb + buf * NSB, lane);
+        const double gamma_new = PRE ? hipk_mid_tree(sb + buf * NSB + 256, lane) : rr;   // <r,z> steers alpha and beta, <r,r> the stop test
         buf ^= 1;
         HIPK_MSTAMP(9);
         if (*fail) {
@@ -250,14 +285,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             return;
         }
         // ---- beta, p over the whole window, stop test   (TSL:851-853, 841)
-        const double beta = rr / gamma;
+        const double beta = gamma_new / gamma;
         for (int idx = tid; idx < WIN; idx += NTHR) {
+            const double zj = PRE ? dw[idx] * rw[idx] : rw[idx];   // z = M r (TSL:849), formed again: same operands, same bits
             const double m = beta * pw[idx];
-            pw[idx] = rw[idx] + m;
+            pw[idx] = zj + m;
         }
         __syncthreads();
         HIPK_MSTAMP(10);
-        gamma = rr;
+        gamma = gamma_new;
         rs_last = rr;
         ++it;
         done = (it >= a.maxiter || rr <= atol2);

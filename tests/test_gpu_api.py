@@ -925,6 +925,38 @@ def test_cg_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
             assert out[0][1] == 0
         if idx < 8:
             assert out[0][1] > 20, (idx, out[0][1])
+    # the same loop with M = diag(A)^-1 (hipk_cg_mid_kernel<W, 1, PRE = true>, up to 256 chunks): z = dinv .* r formed where it is
+    # used, <r,z> beside <r,r>; against hipk_pcg_solve's launch sequence
+    for idx, (A, kw, env) in enumerate(cases):
+        if idx in (5, 6):
+            continue   # 489 chunks / a window beyond the LDS: not taken by the preconditioned loop either way
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        Ac = A.cpu()
+        dinv = (1.0 / torch.from_numpy(sp.csr_matrix((Ac.values().numpy(), Ac.col_indices().numpy(), Ac.crow_indices().numpy()),
+                                                     shape=A.shape).diagonal())).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(100 + idx)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        if idx == 12:
+            x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+            b = hipk.spmv(h, x0)
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_CG_MID", mid)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b) if x0 is None else x0.clone()
+            st = hipk.solve_pcg(h, dinv, b, x, atol=0.0, **{"maxiter": None, **kw})
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs))
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], ("jacobi", idx, out[0][1:], out[1][1:])
+        if idx == 12:
+            assert out[0][1] == 0
+        if idx < 8:
+            assert out[0][1] > 15, ("jacobi", idx, out[0][1])
     monkeypatch.delenv("HIPK_CG_MID", raising=False)
     A, kw, _ = cases[0]
     b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
