@@ -1915,6 +1915,8 @@ __global__ void hipk_gm_resume_kernel(hipk_gm_scal *__restrict__ scal) {
     scal->pass2 = 0;
 }
 
+#include "hipk_gm_mid.h"   // the Arnoldi steps of a cycle in one launch, mid-size systems (uses hipk_gm_scal, hipk_gm_want_pass2, hipk_givens)
+
 // big: the workspace block of a solve with restart m > 31 (hipk_gm_big_doubles(m) doubles), else null: the struct's own arrays
 __global__ void hipk_gm_cycle_init_kernel(hipk_gm_scal *__restrict__ scal, int incremental, double ptol, double *big = nullptr,
                                           int m = HIPK_GM_MAXM) {
@@ -2126,8 +2128,11 @@ extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
     const size_t vec = hipk_align_up((size_t)(n > 0 ? n : 1) * sv, 256);
     const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM_BIG ? HIPK_GM_MAXM_BIG : restart);
+    // mid-size systems (hipk_gm_mid.h): v_{k+1} as 16-byte flagged words (two more vectors) + the partial slots
+    const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
+    const bool mid = gm.g > kGmMidMinChunks && gm.g <= kGmMidMaxChunks && m <= HIPK_GM_MAXM;
     return kGmHeader + hipk_gm_big_doubles(m) * sizeof(double) + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) +
-           (size_t)(m + 2) * vec;
+           (size_t)(m + 2) * vec + (mid ? 2 * vec + kGmMidSlotBytes : 0);
 }
 
 // partials of || d .* v ||^2 (||M b|| of the preconditioned solver, TSL:750)
@@ -2290,6 +2295,41 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     bool cyc_local = !lds_spread && !getenv("HIPK_GM_CYCLE_AGENT");
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     const bool stream_k = !small && (m > HIPK_GM_MAXM || !getenv("HIPK_GMRES_NO_STREAM"));  // large systems: hipk_gm_*_stream_kernel
+    // 33 .. 256 chunks (fp64, no preconditioner, restart <= 31, rows of <= 12 entries within a window around their chunk): the
+    // Arnoldi steps of a cycle in ONE launch, one workgroup per chunk (hipk_gm_mid.h); HIPK_GMRES_MID=0 keeps the launches
+    static bool mid_failed = false;
+    bool mid_cycle = false;
+    int mid_H = 0;
+    size_t mid_lds = 0;
+    void (*mid_kern)(hipk_gm_mid_args) = nullptr;
+    if constexpr (sizeof(T) == 8) {
+        mid_cycle = !small && !cyc && !ext && dinv == nullptr && m <= HIPK_GM_MAXM && gm.g > kGmMidMinChunks && gm.g <= kGmMidMaxChunks &&
+                    gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr && A->crow != nullptr && A->max_row_len <= 12 &&
+                    prm->profile == 0 && !mid_failed && !(getenv("HIPK_GMRES_MID") && getenv("HIPK_GMRES_MID")[0] == '0') &&
+                    !getenv("HIPK_GMRES_NO_CYCLE");
+        mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7>
+                   : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9> : hipk_gm_mid_kernel<12>;
+        if (mid_cycle) {
+            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
+                int *out = (int *)part_spare, reach = 0;
+                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+                int rgrid = (int)((n + 255) / 256);
+                if (rgrid > 2048) rgrid = 2048;
+                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
+                HIPK_CHECK_HIP(hipGetLastError());
+                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
+                A->mid_reach1 = reach + 1;
+            }
+            mid_H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
+            mid_lds = hipk_gm_mid_lds_bytes(mid_H);
+            int occ = 0;
+            mid_cycle = mid_lds <= (size_t)160 * 1024 &&
+                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) == hipSuccess &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, mid_lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
+            (void)hipGetLastError();
+        }
+    }
     // multi-dot with up to 32 columns per workgroup (w read ONCE per step; 0, the default: groups of 8, w re-read per group).  Same
     // box, alternating, N = 4 M (profiles/r03_gmres_history.md): GMRES(30) 6.67-6.70 vs 6.64-6.66 ms per cycle, GMRES(50) 16.50 vs
     // 16.38, GMRES(100) 60.1-60.2 vs 59.5-59.8 -- the re-reads of w are Infinity-Cache hits (FETCH_SIZE counts them: the 1.15 x of
@@ -2358,7 +2398,36 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             else
                 hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
-        for (int k = cyc ? m : k_start; k < m; ++k) {
+        if constexpr (sizeof(T) == 8) {
+            if (mid_cycle) {
+                hipk_gm_mid_args ca;
+                memset(&ca, 0, sizeof(ca));
+                ca.n = n;
+                ca.g = gm.g;
+                ca.H = mid_H;
+                ca.m = m;
+                ca.crow = A->crow;
+                ca.col = A->col;
+                ca.val = (const double *)A->val;
+                ca.V = (double *)V;
+                ca.ldv = ldv;
+                ca.v_ll = (unsigned long long *)(vbase + (size_t)(m + 2) * vec);      // behind the basis and tmp (hipk_gmres_work_bytes)
+                ca.slots = (unsigned long long *)(vbase + (size_t)(m + 4) * vec);
+                ca.scal = scal;
+                ca.eps = eps_t;
+                ca.slot_stride = 16;
+                ca.xcd_aware = 1;
+                {
+                    const char *fe = getenv("HIPK_TEST_LDS_NOT_RESIDENT");
+                    const int fail_launch = fe ? (atoi(fe) > 1 ? atoi(fe) : 1) : 0;
+                    ca.test_not_resident = (++lds_launch_no == fail_launch) ? 1 : 0;
+                }
+                (void)hipMemsetAsync(ca.v_ll, 0, 2 * vec, stream);
+                (void)hipMemsetAsync(ca.slots, 0, (size_t)kGmMidKinds * gm.g * ca.slot_stride * 16, stream);
+                mid_kern<<<hipk_xcd_grid(gm.g), 1024, mid_lds, stream>>>(ca);
+            }
+        }
+        for (int k = (cyc || mid_cycle) ? m : k_start; k < m; ++k) {
             T *w = V + (int64_t)(k + 1) * ldv;
             hipk_spmv_args sw = sa;
             sw.x = V + (int64_t)k * ldv;
@@ -2432,6 +2501,18 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             hipk_set_error("hipk_gmres_solve: HIP failure inside a restart cycle");
             rc = HIPK_ERR_HIP;
             break;
+        }
+        if (hs->redo < 0 && mid_cycle) {
+            // the workgroups of the one-launch step loop did not all arrive (nothing of the cycle is kept) or one of its hand-offs
+            // never completed
+            if (hs->redo == -3) {
+                hipk_set_error("hipk_gmres_solve: a resident workgroup of the one-launch cycle stopped arriving");
+                rc = HIPK_ERR_HIP;
+                break;
+            }
+            if (!getenv("HIPK_TEST_LDS_NOT_RESIDENT")) mid_failed = true;
+            mid_cycle = false;
+            continue;
         }
         if (hs->redo < 0) {
             // the resident workgroups of a one-launch cycle did not all arrive (the device is shared and they were not

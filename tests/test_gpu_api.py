@@ -724,6 +724,7 @@ def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypa
     from pytorch_sparse_solver.module_a import get_last_stats, gmres
     from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr, create_poisson_2d_csr
     dev = "cuda:0"
+    monkeypatch.setenv("HIPK_GMRES_MID", "0")   # (these sizes take the one-launch step loop of hipk_gm_mid.h by default: its own test below)
     for A, kw in ((create_convdiff_2d_csr(300, 300, device=dev), dict(tol=1e-8, restart=30, maxiter=5)),
                   (create_poisson_2d_csr(200, 170, device=dev), dict(tol=1e-8, restart=12, maxiter=7, solve_method="incremental"))):
         n = A.shape[0]
@@ -740,7 +741,7 @@ def test_gmres_large_system_streaming_and_speculation_are_bit_identical(monkeypa
             out.append((x.clone(), info, st.iterations, st.matvecs, st.residual_norm))
         for o in out[1:]:
             assert torch.equal(o[0], out[0][0]) and o[1:] == out[0][1:]
-    for k in ("HIPK_GMRES_NO_STREAM", "HIPK_GM_SPEC", "HIPK_GM_NRES"):
+    for k in ("HIPK_GMRES_NO_STREAM", "HIPK_GM_SPEC", "HIPK_GM_NRES", "HIPK_GMRES_MID"):
         monkeypatch.delenv(k, raising=False)
 
 
@@ -1049,3 +1050,57 @@ def test_bicgstab_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
                           np.ones(A.shape[0]), maxiter=1500, **kw)
     assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)
     assert st.iterations > 20
+
+
+@pytest.mark.gpu
+def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
+    """Launch-bound mid-size fp64 systems (33 .. 256 reduction chunks, restart <= 31, no preconditioner, rows of <= 12 entries within
+    a window around their chunk) run the Arnoldi steps of a restart cycle in ONE launch, one workgroup per chunk
+    (csrc/hipk_gm_mid.h): three hand-offs per step (five with a second CGS pass) instead of five to nine launches, the basis in
+    memory, v_k as an LDS window.  Same bits as the launch sequence (HIPK_GMRES_MID=0) -- x, cycles, matvecs, info, residuals,
+    breakdown flag -- for both solve methods, restarts 1 .. 31, nonsymmetric and symmetric stencils, per-entry values, ragged last
+    chunks, warm starts, cycle cut-offs, an early exit inside a cycle, a launch whose workgroups report "not co-resident" (first
+    and second cycle); and, on one system, as the CPU oracle."""
+    from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_poisson_2d_csr,
+                                                          create_variable_diffusion_2d_csr)
+    cases = [(create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=4), {}),          # 44 chunks
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=4, solve_method="incremental"), {}),
+             (create_poisson_2d_csr(500, 500, device=DEV), dict(tol=1e-6, restart=20, maxiter=3), {}),            # 123 chunks
+             (create_poisson_2d_csr(550, 557, device=DEV), dict(tol=1e-5, restart=31, maxiter=2, solve_method="incremental"), {}),
+             (create_variable_diffusion_2d_csr(400, 300, device=DEV), dict(tol=1e-7, restart=12, maxiter=6), {}),
+             (create_poisson_2d_csr(720, 720, device=DEV), dict(tol=1e-5, restart=10, maxiter=3), {}),            # 254 chunks
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=1, maxiter=5), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=2, maxiter=5, solve_method="incremental"), {}),
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-3, restart=30, maxiter=50, solve_method="incremental"), {}),   # converges inside a cycle
+             (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-3, restart=30, maxiter=50), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=0), {}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=15, maxiter=4), {"HIPK_TEST_LDS_NOT_RESIDENT": "1"}),
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=15, maxiter=4), {"HIPK_TEST_LDS_NOT_RESIDENT": "2"})]
+    for idx, (A, kw, env) in enumerate(cases):
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        g = torch.Generator(device=DEV).manual_seed(idx)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_GMRES_MID", mid)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b) if x0 is None else x0.clone()
+            print("gmres mid case", idx, "mid" if mid == "1" else "launch sequence", flush=True)
+            st = hipk.solve("gmres", h, b, x, atol=0.0, **kw)
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, out[0][1:], out[1][1:])
+    monkeypatch.delenv("HIPK_GMRES_MID", raising=False)
+    A, kw, _ = cases[2]
+    b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
+    x = torch.zeros_like(b)
+    st = hipk.solve("gmres", hipk.handle_for(A), b, x, atol=0.0, **kw)
+    Ac = A.cpu()
+    ref = oracle.gmres(Ac.crow_indices().numpy().astype(np.int32), Ac.col_indices().numpy().astype(np.int32), Ac.values().numpy(),
+                       np.ones(A.shape[0]), **kw)
+    assert (st.iterations, st.info) == (ref.iterations, ref.info) and np.array_equal(x.cpu().numpy(), ref.x)

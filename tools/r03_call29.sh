@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03c29
+timeout -k 10 600 python -m pytest tests/test_gpu_api.py -x -q -s -m gpu -k "gmres_mid" > gpurun_out/r03c29/pytest.log 2>&1
+rc=$?
+echo "pytest rc=$rc"; grep -v "Warning\|warn\|return torch\|^$\|Docs" gpurun_out/r03c29/pytest.log | tail -25 | cut -c1-600
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 300 python tools/gmres_mid_probe.py > gpurun_out/r03c29/gm_mid.jsonl 2> gpurun_out/r03c29/gm_mid.err
+echo "probe rc=$?"; cat gpurun_out/r03c29/gm_mid.jsonl
