@@ -42,6 +42,23 @@ static inline size_t hipk_gm_mid_lds_bytes(int H) {
     return (size_t)((HIPK_BASE_CHUNK + 2 * H) + 8 + HIPK_BASE_CHUNK + kGmMidCols * 256 + 6 * 40 + 32 + 8) * sizeof(double);
 }
 
+// Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the steps of a launch, the constant 100 MHz clock between
+// its phase boundaries; tools/gmres_mid_stamps_probe.py prints where a cycle goes.
+#ifdef HIPK_GM_STAMPS
+#define HIPK_GMM_NSTAMP 14
+__device__ unsigned long long hipk_gm_mid_stamps[kGmMidMaxChunks * HIPK_GMM_NSTAMP];
+#undef HIPK_MSTAMP
+#define HIPK_MSTAMP(k)                                                  \
+    do {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        st_acc[k] += t_ - st_prev;                                      \
+        st_prev = t_;                                                   \
+    } while (0)
+#else
+#undef HIPK_MSTAMP
+#define HIPK_MSTAMP(k)
+#endif
+
 template <int W>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_gm_mid_kernel(hipk_gm_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
@@ -119,6 +136,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (tid == 0) scal->redo = -3;   \
         return;                          \
     }
+#ifdef HIPK_GM_STAMPS
+    unsigned long long st_acc[HIPK_GMM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int k = 0; k < m; ++k) {
         // the window geometry is made opaque once per step (hipk_bi_mid.h: LDS addresses formed ahead of the loop cost registers)
         int H = H_, WIN = WIN_;
@@ -146,15 +166,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((lane & 31) == 0) ts[(t0 + TSTEP * (lane >> 5)) * 4 + tw] = s2;
         }
         __syncthreads();
+        HIPK_MSTAMP(0);
         if (tid < 64) {
             const double part = hipk_mid_tiles_fold(ts, lane, wg * (CH / HIPK_TILE), ntiles);
             if (lane == 0) hipk_ll_put(ll, wg * ss, part, seq_k, ww_o);
         }
         double qq = 0.0, ww = 0.0;
         for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) {   // second CGS pass iff ||r|| < ||q|| / sqrt(2)  (hipk_gm_decide_kernel)
-                double qnorm;
-                if (!hipk_gm_want_pass2(scal, k, qq, eps, &qnorm, rvec)) break;
+            if (pass == 1) {   // second CGS pass iff ||r|| < ||q|| / sqrt(2)  (hipk_gm_decide_kernel, hipk_gm_want_pass2): every
+                               // wavefront for itself -- lane j holds rvec[j], the chain of the spec takes them by v_readlane (as a loop
+                               // of dependent LDS reads it cost 1 us per step)
+                const double rl = (lane <= k) ? rvec[lane] : 0.0;
+                double rr = 0.0;
+                for (int j = 0; j <= k; ++j) {
+                    const double rj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rl), j), __builtin_amdgcn_readlane(__double2loint(rl), j));
+                    rr = fma(rj, rj, rr);
+                }
+                double qnorm = sqrt(qq < 0.0 ? 0.0 : qq);
+                if (!(qnorm > eps)) qnorm = 0.0;
+                double rnorm = sqrt(rr < 0.0 ? 0.0 : rr);
+                if (!(rnorm > eps)) rnorm = 0.0;
+                if (!(rnorm < qnorm * HIPK_INV_SQRT2)) break;
             }
             const unsigned seq_p = 2u * (unsigned)k + (unsigned)pass + 1u;
             // ---- h_j = <V_j, w>, j <= k: chains of the own chunk (column group q4 takes j = q4, q4 + 4, ...; virtual thread t
@@ -186,14 +218,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 }
             }
             __syncthreads();
+        HIPK_MSTAMP(1);
             for (int j = wave; j <= k; j += NTHR / 64) {
                 const double part = hipk_mid_tree(sbm + j * 256, lane);
                 if (lane == 0) hipk_ll_put(ll, wg * ss, part, seq_p, s_off + (unsigned)j * col_bytes);
             }
             __syncthreads();
+        HIPK_MSTAMP(2);
             // hand-off: every workgroup folds the g partials of every column in the spec's order   (hipk_gm_hreduce_kernel)
             {
-                constexpr int NB = 4;   // columns of a thread in flight
+                constexpr int NB = 4;   // columns of a thread in flight (8 spill registers)
                 for (int j0 = q4; j0 <= k; j0 += 4 * NB) {
                     hipk_v4u pw_[NB];
 #pragma unroll
@@ -213,12 +247,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 }
             }
             __syncthreads();
+        HIPK_MSTAMP(3);
             HIPK_GMM_FAIL()
             for (int j = wave; j <= k; j += NTHR / 64) {
                 const double h = hipk_mid_tree(sbm + j * 256, lane);
                 if (lane == 0) hs[j] = h;
             }
             __syncthreads();
+        HIPK_MSTAMP(4);
             // ---- q = w - V h (element i = 2t + 512 q4 + e of the own chunk), rvec += h   (hipk_gm_update_stream_kernel)
             {
                 const int i = 2 * t + 512 * q4;
@@ -237,6 +273,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 if (tid <= k) rvec[tid] = ((pass == 0) ? 0.0 : rvec[tid]) + hs[tid];
             }
             __syncthreads();
+        HIPK_MSTAMP(5);
             if (tid < 256) {
                 double acc = 0.0;
 #pragma unroll
@@ -250,6 +287,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 sbm[tid] = acc;
             }
             __syncthreads();
+        HIPK_MSTAMP(6);
             if (tid < 64) {
                 const double part = hipk_mid_tree(sbm, lane);
                 if (lane == 0) hipk_ll_put(ll, wg * ss, part, seq_p, qq_o);
@@ -272,12 +310,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
             __syncthreads();
             HIPK_GMM_FAIL()
+        HIPK_MSTAMP(7);
             qq = hipk_mid_tree(sbm + 256, lane);
             if (pass == 0) ww = hipk_mid_tree(sbm + 512, lane);
             __syncthreads();
+        HIPK_MSTAMP(8);
         }
         // ---- v_{k+1} = q / ||q|| (zero when ||q|| <= eps ||A v_k||), column k of H, breakdown, Givens + early exit
         // (hipk_gm_normalize_kernel)
+        HIPK_MSTAMP(11);   // (the second-pass decision of a step that needs none)
         double norm1 = sqrt(qq < 0.0 ? 0.0 : qq);
         double norm0 = sqrt(ww < 0.0 ? 0.0 : ww);
         if (!(norm0 > eps)) norm0 = 0.0;
@@ -298,9 +339,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 }
             }
         }
+        HIPK_MSTAMP(12);   // (scaling, stores)
+        if (wg == 0 && tid <= k) gv_.H[tid * ldh + k] = rvec[tid];   // column k of H, the header block's copy
+        if (incremental) {   // column k of H for the rotations: one element per thread (as one thread's loop of dependent LDS
+                             // round trips the copy cost ~1 us per step)
+            if (tid <= k) hc[tid] = rvec[tid];
+            __syncthreads();
+        }
         if (tid == 0) {
             if (!use) norm1 = 0.0;
-            for (int j = 0; j <= k; ++j) hc[j] = rvec[j];
             hc[k + 1] = norm1;
             bool stop = false;
             int breakdown = 0;
@@ -308,10 +355,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 breakdown = 1;
                 stop = true;
             }
-            if (wg == 0) {
-                for (int j = 0; j <= k; ++j) gv_.H[j * ldh + k] = rvec[j];
-                gv_.H[(k + 1) * ldh + k] = norm1;
-            }
+            if (wg == 0) gv_.H[(k + 1) * ldh + k] = norm1;
             double err = 0.0;
             if (incremental) {
                 for (int i = 0; i < k; ++i) {
@@ -355,6 +399,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             flags[1] = stop ? 1 : 0;
         }
         __syncthreads();
+        HIPK_MSTAMP(9);
         if (flags[1] || k + 1 >= m) break;
         // hand-off: v_{k+1} at the window's halo columns
         for (int idx = tid; idx < 2 * H; idx += NTHR) {
@@ -368,7 +413,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         __syncthreads();
         HIPK_GMM_FAIL()
+        HIPK_MSTAMP(10);
     }
 #undef HIPK_GMM_FAIL
+#ifdef HIPK_GM_STAMPS
+    if (tid == 0)
+        for (int j = 0; j < HIPK_GMM_NSTAMP; ++j) hipk_gm_mid_stamps[wg * HIPK_GMM_NSTAMP + j] = st_acc[j];
+#endif
 }
 #endif  // HIPK_GM_MID_H

@@ -2933,3 +2933,13 @@ extern "C" int hipk_dist_gmres_solve(hipk_csr_t A, const hipk_dist_plan *pl, con
 #undef HIPK_DGM_TRY
     return HIPK_OK;
 }
+
+#ifdef HIPK_GM_STAMPS
+// diagnostic twin only: per-workgroup phase time sums of the last hipk_gm_mid_kernel launch (hipk_gm_mid.h)
+extern "C" int hipk_debug_gm_mid_stamps(unsigned long long *out, size_t count) {
+    const size_t have = sizeof(hipk_gm_mid_stamps) / sizeof(unsigned long long);
+    HIPK_CHECK_HIP(hipDeviceSynchronize());
+    HIPK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk_gm_mid_stamps), sizeof(unsigned long long) * (count < have ? count : have)));
+    return HIPK_OK;
+}
+#endif

@@ -10,6 +10,8 @@ static constexpr int kMidMaxChunks = 512;     // two partials per thread in the 
 static constexpr size_t kMidSlotBytes = 2 * (size_t)kMidMaxChunks * 256;   // both partial arrays at the widest slot stride
 static constexpr int kMidSpinBound = 1 << 18; // polls (~1 us each) before a workgroup gives up on a hand-off
 
+// (A barrier that orders LDS traffic only -- s_waitcnt lgkmcnt(0); s_barrier instead of __syncthreads(), which also waits for the
+// wavefront's write-through stores -- was measured after every publish of the three loops: no change; not kept.)
 // One 16-byte store / load per flagged double: {lo, seq, hi, seq}.  Each 8-byte half validates itself, so a store or load torn
 // into its halves is harmless.  Raw buffer accesses with the sc1 policy (aux bit 4) -- what the compiler gives relaxed agent-scope
 // atomics: write-through stores, loads served at the device's coherence point -- so that they stay compiler-tracked: several polls

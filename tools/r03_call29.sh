@@ -6,3 +6,5 @@ echo "pytest rc=$rc"; grep -v "Warning\|warn\|return torch\|^$\|Docs" gpurun_out
 [ $rc -eq 0 ] || exit 1
 timeout -k 10 300 python tools/gmres_mid_probe.py > gpurun_out/r03c29/gm_mid.jsonl 2> gpurun_out/r03c29/gm_mid.err
 echo "probe rc=$?"; cat gpurun_out/r03c29/gm_mid.jsonl
+HIPK_LIB_PATH=$PWD/pytorch-sparse-linalg-torch-amgx.cg.bicg.gmres_amd/pytorch_sparse_solver/_lib/libhipk_stamps.so timeout -k 10 300 python tools/gmres_mid_stamps_probe.py 500 > gpurun_out/r03c29/stamps.jsonl 2> gpurun_out/r03c29/stamps.err
+echo "stamps rc=$?"; cat gpurun_out/r03c29/stamps.jsonl
