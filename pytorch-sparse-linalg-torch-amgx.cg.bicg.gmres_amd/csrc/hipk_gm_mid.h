@@ -18,7 +18,9 @@
 #define HIPK_GM_MID_H
 #include "hipk_mid.h"
 
-static constexpr int kGmMidMinChunks = 32;    // up to 32 chunks the whole-solve kernel (hipk_gm_solve_lds_kernel, spread) is taken
+static constexpr int kGmMidMinChunks = 32;    // up to 32 chunks the whole-solve kernel (hipk_gm_solve_lds_kernel, spread) is faster: GMRES(30) ms per
+                                              // cycle, that kernel / this one: 0.49 / 0.61 at 11 chunks, 0.53 / 0.59 at 20, 0.59 / 0.60 at 31
+                                              // (HIPK_GMRES_MID_MIN=8 forces this one; profiles/r03_gmres_mid_vs_whole_solve_9_32_chunks.jsonl)
 static constexpr int kGmMidMaxChunks = 256;   // one chunk per workgroup, one workgroup per CU
 static constexpr int kGmMidCols = 32;         // restart <= 31: columns 0 .. 31 of the basis
 // slot arrays: <V_j, w> [32][g] | <q,q> [g] | <w,w> [2][g], each slot up to 256 bytes

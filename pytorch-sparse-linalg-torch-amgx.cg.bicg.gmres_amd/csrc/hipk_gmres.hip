@@ -2130,7 +2130,7 @@ extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
     const int m = restart < 1 ? 1 : (restart > HIPK_GM_MAXM_BIG ? HIPK_GM_MAXM_BIG : restart);
     // mid-size systems (hipk_gm_mid.h): v_{k+1} as 16-byte flagged words (two more vectors) + the partial slots
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
-    const bool mid = gm.g > kGmMidMinChunks && gm.g <= kGmMidMaxChunks && m <= HIPK_GM_MAXM;
+    const bool mid = gm.g > 8 && gm.g <= kGmMidMaxChunks && m <= HIPK_GM_MAXM;
     return kGmHeader + hipk_gm_big_doubles(m) * sizeof(double) + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) +
            (size_t)(m + 2) * vec + (mid ? 2 * vec + kGmMidSlotBytes : 0);
 }
@@ -2303,7 +2303,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     size_t mid_lds = 0;
     void (*mid_kern)(hipk_gm_mid_args) = nullptr;
     if constexpr (sizeof(T) == 8) {
-        mid_cycle = !small && !cyc && !ext && dinv == nullptr && m <= HIPK_GM_MAXM && gm.g > kGmMidMinChunks && gm.g <= kGmMidMaxChunks &&
+        const int mid_min = env_int("HIPK_GMRES_MID_MIN", kGmMidMinChunks);   // (A/B against the whole-solve kernel of 9 .. 32 chunks)
+        mid_cycle = !small && !ext && dinv == nullptr && m <= HIPK_GM_MAXM && gm.g > (mid_min < 8 ? 8 : mid_min) && gm.g <= kGmMidMaxChunks &&
                     gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr && A->crow != nullptr && A->max_row_len <= 12 &&
                     prm->profile == 0 && !mid_failed && !(getenv("HIPK_GMRES_MID") && getenv("HIPK_GMRES_MID")[0] == '0') &&
                     !getenv("HIPK_GMRES_NO_CYCLE");
@@ -2329,6 +2330,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, mid_lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
             (void)hipGetLastError();
         }
+        if (mid_cycle) cyc = cyc_lds = false;   // (9 .. 32 chunks: instead of the whole-solve kernel)
     }
     // multi-dot with up to 32 columns per workgroup (w read ONCE per step; 0, the default: groups of 8, w re-read per group).  Same
     // box, alternating, N = 4 M (profiles/r03_gmres_history.md): GMRES(30) 6.67-6.70 vs 6.64-6.66 ms per cycle, GMRES(50) 16.50 vs

@@ -8,7 +8,7 @@ import torch
 from pytorch_sparse_solver import _hipk
 from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
 dev = torch.device("cuda", 0)
-for nx in (300, 400, 500, 600, 720):
+for nx in [int(a) for a in sys.argv[1:]] or (300, 400, 500, 600, 720):
     A = create_convdiff_2d_csr(nx, nx, device=dev)
     h = _hipk.handle_for(A)
     b = torch.ones(nx * nx, dtype=torch.float64, device=dev)
