@@ -539,6 +539,7 @@ extern "C" int hipk_csr_destroy(hipk_csr_t h) {
     if (h->col) (void)hipFree(h->col);
     if (h->tile_part) (void)hipFree(h->tile_part);
     if (h->huge_rows) (void)hipFree(h->huge_rows);
+    if (h->mid_plan_mem) (void)hipFree(h->mid_plan_mem);
     hipk_drop_coded(h);
     if (h->host_poll) (void)hipHostFree(h->host_poll);
     delete h;

@@ -1032,24 +1032,16 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
                      : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 2> : hipk_cg_mid_kernel<7, 2>);
         const int mid_threads = 1024, mid_grid = (gm.g + nch - 1) / nch;
         if (nch == 2 && A->max_row_len > 7) mid_loop = false;   // four rows per thread: at most 7 entries each in registers
-        int H = 0;
         size_t lds = 0;
+        hipk_mid_plan plan;
+        memset(&plan, 0, sizeof(plan));
         if (mid_loop) {
-            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
-                int *out = (int *)part_c, reach = 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
-                int rgrid = (int)((n + 255) / 256);
-                if (rgrid > 2048) rgrid = 2048;
-                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                A->mid_reach1 = reach + 1;
-            }
-            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_cg_mid_lds_bytes(H, nch);
+            // once per handle: the 256-column tiles each workgroup's window holds (hipk_mid.h); not for matrices whose rows reach
+            // further than the plan's range, or whose windows do not fit the LDS
+            mid_loop = hipk_mid_plan_get(A, nch, stream, &plan);
+            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, nch) : 0;
             int occ = 0;
-            mid_loop = lds <= (size_t)160 * 1024 &&
+            mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, mid_threads, lds) == hipSuccess &&
                        (int64_t)occ * A->n_cu >= mid_grid;
@@ -1062,7 +1054,8 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             memset(&ca, 0, sizeof(ca));
             ca.n = n;
             ca.g = gm.g;
-            ca.H = H;
+            ca.win = plan.max_slots * HIPK_TILE;
+            ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
             ca.val = (const double *)A->val;
@@ -1764,24 +1757,14 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
                                              : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1, true>
                                              : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1, true>
                                                                    : hipk_cg_mid_kernel<12, 1, true>;
-        int H = 0;
         size_t lds = 0;
+        hipk_mid_plan plan;
+        memset(&plan, 0, sizeof(plan));
         if (mid_loop) {
-            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
-                int *out = (int *)part_c, reach = 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
-                int rgrid = (int)((n + 255) / 256);
-                if (rgrid > 2048) rgrid = 2048;
-                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                A->mid_reach1 = reach + 1;
-            }
-            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_cg_mid_lds_bytes(H, 1, true);
+            mid_loop = hipk_mid_plan_get(A, 1, stream, &plan);   // the tiles each workgroup's window holds (hipk_mid.h)
+            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, 1, true) : 0;
             int occ = 0;
-            mid_loop = lds <= (size_t)160 * 1024 &&
+            mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
             (void)hipGetLastError();
@@ -1792,7 +1775,8 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
             memset(&ca, 0, sizeof(ca));
             ca.n = n;
             ca.g = gm.g;
-            ca.H = H;
+            ca.win = plan.max_slots * HIPK_TILE;
+            ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
             ca.val = (const double *)A->val;

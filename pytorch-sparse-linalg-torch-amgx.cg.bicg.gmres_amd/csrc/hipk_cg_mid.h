@@ -25,7 +25,8 @@
 
 struct hipk_cg_mid_args {
     int64_t n;
-    int g, H;                     // chunks; window reach (a multiple of 128)
+    int g, win;                   // chunks; doubles of a window in LDS = 256 x the most tiles any workgroup's window holds
+    hipk_mid_plan plan;           // which tiles (hipk_mid.h)
     const int *crow, *col;
     const double *val;
     double *x, *r, *p;
@@ -44,9 +45,10 @@ struct hipk_cg_mid_args {
     int slot_stride;              // distance of consecutive chunk-partial slots in 16-byte words (16: a 256-byte line each)
     int xcd_aware;                // 0 (HIPK_CG_MID_XCD=0, A/B measurements): workgroup b takes row range b
 };
-// LDS of a workgroup that owns `nch` chunks with reach H: p window + 8 zero slots | r window | 2 fold buffers | tile sums | flag
-static inline size_t hipk_cg_mid_lds_bytes(int H, int nch, bool pre = false) {   // pre: + the window of dinv, two sums per fold
-    return (size_t)((pre ? 3 : 2) * (nch * HIPK_BASE_CHUNK + 2 * H) + 8 + 2 * 256 * nch * (pre ? 2 : 1) + 32 * nch + 8) * sizeof(double);
+// LDS of a workgroup that owns `nch` chunks, windows of `win` doubles: p window + 8 zero slots | r window | 2 fold buffers | tile sums |
+// flag | (pre: the window of dinv; two sums per fold) | the window's tile list
+static inline size_t hipk_cg_mid_lds_bytes(int win, int nch, bool pre = false) {
+    return (size_t)((pre ? 3 : 2) * win + 8 + 2 * 256 * nch * (pre ? 2 : 1) + 32 * nch + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the iterations of a launch, the constant 100 MHz clock
@@ -78,17 +80,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // XCD-aware placement (blocks b and b + 8 share an XCD): XCD k takes the k-th contiguous eighth of the workgroups' row
     // ranges, so that a window's neighbours mostly sit behind the same L2 -- their write-through r then HITS there (a 0.1 us
     // poll instead of a 0.5 us trip through the fabric).  Speed only; the grid is padded to a multiple of 8, idle blocks leave.
-    const int g = a.g, H = a.H, WIN = OWN + 2 * H, nwg = (g + NCH - 1) / NCH;
+    const int g = a.g, WIN = a.win, nwg = (g + NCH - 1) / NCH;
     const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, nwg) : ((int)blockIdx.x < nwg ? (int)blockIdx.x : -1);
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
-    double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows
+    double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows (H: where the own tiles sit in the window)
     double *sb = rw + WIN;           // 2 x [NSB]: fold buffers, used alternately (one barrier per fold)
     double *ts = sb + 2 * NSB;       // [32 NCH] wavefront sums of <p,Ap>, 4 per tile
     int *fail = (int *)(ts + 32 * NCH);
     double *dw = (double *)(fail + 2);   // PRE: dinv at the window's columns
-    const int64_t n = a.n, base = (int64_t)wg * OWN, w0 = base - H;
+    int *stile = (int *)(dw + (PRE ? WIN : 0));   // the window's tiles: slot s holds columns 256 stile[s] .. + 255
+    const int64_t n = a.n, base = (int64_t)wg * OWN;
+    const int tlo = a.plan.tlo[wg], WINc = a.plan.nslot[wg] * HIPK_TILE;   // this workgroup's window
+    const short *tmap = a.plan.map + (size_t)wg * kMidPlanRange;
+    const int H = __builtin_amdgcn_readfirstlane((int)tmap[(int)(base >> 8) - tlo] * HIPK_TILE);   // (uniform: a 16-bit load lands in a VGPR)
+    if (tid < kMidPlanSlots) stile[tid] = (tid * HIPK_TILE < WINc) ? a.plan.tiles[wg * kMidPlanSlots + tid] : 0;
+    __syncthreads();
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_lds_ctl *scal = a.ctl;
     if (tid == 0) *fail = 0;
@@ -117,23 +125,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const bool has = j < len;
-            cj[k][j] = has ? (int)(a.col[lo + j] - w0) : WIN;
+            const int cc = has ? a.col[lo + j] : 0;
+            cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN;
             vj[k][j] = has ? a.val[lo + j] : 0.0;
         }
     }
     if (tid < 8) pw[WIN + tid] = 0.0;
-    for (int idx = tid; idx < WIN; idx += NTHR) {
-        const int64_t gc = w0 + idx;
-        pw[idx] = (gc >= 0 && gc < n) ? a.p[gc] : 0.0;
+    for (int idx = tid; idx < WINc; idx += NTHR) {
+        const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
+        pw[idx] = gc < n ? a.p[gc] : 0.0;
         rw[idx] = 0.0;
-        if (PRE) dw[idx] = (gc >= 0 && gc < n) ? a.dinv[gc] : 0.0;
+        if (PRE) dw[idx] = gc < n ? a.dinv[gc] : 0.0;
     }
     double gamma = a.gamma[a.it0 & 1];
     const double atol2 = *a.atol2;
     const int64_t stop0 = *a.stop_it;
     double rs_last = scal->rs_last;
-    // rows whose r another workgroup's window holds: within H of either end of the own rows
-    const int pub_lo = H, pub_hi = OWN - H;
+    // rows whose r another workgroup's window holds (their tile is in that window's list)
+    bool pub[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) pub[k] = a.plan.needed[(int)(base >> 8) + t0 + TSTEP * k] != 0;
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the solve to the launch sequences
     int epoch = 0;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const double m0 = alpha * pw[H + lrow];
             xo[k] = xo[k] + m0;
             rw[H + lrow] = ro[k];
-            if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(r_ll, (unsigned)(base + lrow), ro[k], seq);
+            if (base + lrow < n && pub[k]) hipk_ll_put(r_ll, (unsigned)(base + lrow), ro[k], seq);
         }
         __syncthreads();
         HIPK_MSTAMP(4);
@@ -260,10 +271,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs).
         // (Issuing these loads earlier and examining them after the fold measured slower: a poll is a 0.5 us trip, the early
         // ones mostly came back empty and the partials' polls queued behind them -- 7.1 vs 5.8 us per iteration at n = 250 k.)
-        for (int idx = tid; idx < 2 * H; idx += NTHR) {
-            const int widx = idx < H ? idx : idx + OWN;
-            const int64_t gc = w0 + widx;
-            if (gc >= 0 && gc < n) {
+        for (int widx = tid; widx < WINc; widx += NTHR) {
+            const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
+            if ((widx < H || widx >= H + OWN) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
                 rw[widx] = v;
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         // ---- beta, p over the whole window, stop test   (TSL:851-853, 841)
         const double beta = gamma_new / gamma;
-        for (int idx = tid; idx < WIN; idx += NTHR) {
+        for (int idx = tid; idx < WINc; idx += NTHR) {
             const double zj = PRE ? dw[idx] * rw[idx] : rw[idx];   // z = M r (TSL:849), formed again: same operands, same bits
             const double m = beta * pw[idx];
             pw[idx] = zj + m;

@@ -62,6 +62,124 @@ static __global__ __launch_bounds__(256) void hipk_mid_reach_kernel(const int *_
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
+// ---- window plan: which columns a row block's window holds -------------------------------------------------------------------
+// The LDS window of a workgroup is a list of 256-column TILES, ascending: every tile its rows reference plus its own.  For a 2-D
+// stencil that is the contiguous range [base - nx, base + rows + nx); for a 3-D one three bands (own rows +- a grid line, and
+// the planes below and above), a third of the contiguous range -- what makes 64^3 .. 80^3 grids fit.  Per row block b of
+// `own` rows: tlo[b] (first tile of its range), nslot[b], tiles[b][s] (slot -> tile), map[b][tile - tlo] (tile -> slot or -1);
+// needed[tile] = 1 when a block other than the owner holds the tile (its rows of r are published).  Computed once per handle.
+static constexpr int kMidPlanRange = 512;   // tiles between the first and the last one a block references (131072 columns)
+static constexpr int kMidPlanSlots = 64;    // tiles a window may hold (the LDS a kernel needs decides before this does)
+struct hipk_mid_plan {
+    const int *tlo, *nslot, *tiles;
+    const short *map;
+    const unsigned char *needed;
+    int max_slots;
+};
+static __global__ __launch_bounds__(256) void hipk_mid_plan_kernel(const int *__restrict__ crow, const int *__restrict__ col, int64_t n,
+                                                                   int own, int *__restrict__ tlo, int *__restrict__ nslot,
+                                                                   int *__restrict__ tiles, short *__restrict__ map,
+                                                                   unsigned char *__restrict__ needed, int *__restrict__ status) {
+    __shared__ int tmin_s, tmax_s, flags[kMidPlanRange];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int64_t r0 = (int64_t)b * own, r1 = (r0 + own < n) ? r0 + own : n;
+    const int own_lo = (int)(r0 >> 8), own_hi = (int)((r0 + own - 1) >> 8);   // the block's own tiles, all of them (also beyond n)
+    if (t == 0) {
+        tmin_s = own_lo;
+        tmax_s = own_hi;
+    }
+    __syncthreads();
+    int mn = own_lo, mx = own_hi;
+    for (int64_t i = r0 + t; i < r1; i += 256)
+        for (int e = crow[i]; e < crow[i + 1]; ++e) {
+            const int tt = col[e] >> 8;
+            mn = tt < mn ? tt : mn;
+            mx = tt > mx ? tt : mx;
+        }
+    atomicMin(&tmin_s, mn);
+    atomicMax(&tmax_s, mx);
+    __syncthreads();
+    const int tmin = tmin_s, L = tmax_s - tmin + 1;
+    if (L > kMidPlanRange) {
+        if (t == 0) {
+            atomicOr(status, 1);
+            nslot[b] = 0;
+            tlo[b] = tmin;
+        }
+        return;
+    }
+    for (int i = t; i < kMidPlanRange; i += 256) flags[i] = (i + tmin >= own_lo && i + tmin <= own_hi) ? 1 : 0;
+    __syncthreads();
+    for (int64_t i = r0 + t; i < r1; i += 256)
+        for (int e = crow[i]; e < crow[i + 1]; ++e) flags[(col[e] >> 8) - tmin] = 1;
+    __syncthreads();
+    if (t == 0) {
+        int s = 0;
+        for (int i = 0; i < L; ++i) {
+            if (flags[i]) {
+                if (s < kMidPlanSlots) tiles[b * kMidPlanSlots + s] = tmin + i;
+                map[b * kMidPlanRange + i] = (short)s;
+                ++s;
+            } else {
+                map[b * kMidPlanRange + i] = -1;
+            }
+        }
+        nslot[b] = s;
+        tlo[b] = tmin;
+        if (s > kMidPlanSlots) atomicOr(status, 2);
+        atomicMax(status + 1, s);
+    }
+    for (int i = t; i < L; i += 256)
+        if (flags[i] && (i + tmin < own_lo || i + tmin > own_hi)) needed[i + tmin] = 1;
+}
+// the plan of handle A for row blocks of nch chunks (computed on first use; false: the matrix does not fit the scheme)
+static inline bool hipk_mid_plan_get(hipk_csr_s *A, int nch, hipStream_t stream, hipk_mid_plan *out) {
+    const int own = nch * HIPK_BASE_CHUNK;
+    const int nblk = (int)((A->n_rows + own - 1) / own);
+    const size_t ntiles_all = (size_t)nblk * (own / 256) + kMidPlanRange;
+    const size_t o_tlo = 0, o_nslot = o_tlo + (size_t)nblk * 4, o_tiles = o_nslot + (size_t)nblk * 4,
+                 o_map = o_tiles + (size_t)nblk * kMidPlanSlots * 4, o_needed = o_map + (size_t)nblk * kMidPlanRange * 2,
+                 o_status = (o_needed + ntiles_all + 15) / 16 * 16, total = o_status + 16;
+    if (A->mid_plan_state != 0 && A->mid_plan_nch != nch) {   // (a handle's chunk count never changes: one nch per handle)
+        if (A->mid_plan_mem) (void)hipFree(A->mid_plan_mem);
+        A->mid_plan_mem = nullptr;
+        A->mid_plan_state = 0;
+    }
+    if (A->mid_plan_state == 0) {
+        A->mid_plan_nch = nch;
+        A->mid_plan_nblk = nblk;
+        A->mid_plan_state = -1;
+        int st[2] = {0, 0};
+        if (hipMalloc(&A->mid_plan_mem, total) != hipSuccess) {
+            A->mid_plan_mem = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        char *m = (char *)A->mid_plan_mem;
+        bool ok = hipMemsetAsync(m, 0, total, stream) == hipSuccess;
+        if (ok) {
+            hipk_mid_plan_kernel<<<nblk, 256, 0, stream>>>(A->crow, A->col, A->n_rows, own, (int *)(m + o_tlo), (int *)(m + o_nslot),
+                                                           (int *)(m + o_tiles), (short *)(m + o_map), (unsigned char *)(m + o_needed),
+                                                           (int *)(m + o_status));
+            ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(st, m + o_status, sizeof(st), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
+        }
+        if (ok && st[0] == 0) {
+            A->mid_plan_state = 1;
+            A->mid_plan_max_slots = st[1];
+        }
+    }
+    if (A->mid_plan_state != 1) return false;
+    char *m = (char *)A->mid_plan_mem;
+    out->tlo = (const int *)(m + o_tlo);
+    out->nslot = (const int *)(m + o_nslot);
+    out->tiles = (const int *)(m + o_tiles);
+    out->map = (const short *)(m + o_map);
+    out->needed = (const unsigned char *)(m + o_needed);
+    out->max_slots = A->mid_plan_max_slots;
+    return true;
+}
+
 // thread t's share of the G flagged chunk partials in the spec's order (hipk_reduce_parts: t, t + 256; the tree follows);
 // *fail set when a partial never arrived
 template <int NK = kMidMaxChunks / 256>
