@@ -29,7 +29,8 @@ static constexpr size_t kGmMidSlotBytes = (size_t)kGmMidKinds * kGmMidMaxChunks 
 
 struct hipk_gm_mid_args {
     int64_t n;
-    int g, H, m;
+    int g, win, m;                 // chunks; doubles of the window in LDS (256 x the most tiles any workgroup's window holds); restart
+    hipk_mid_plan plan;            // which tiles (hipk_mid.h)
     const int *crow, *col;
     const double *val;
     double *V;                     // the basis, column j at V + j ldv
@@ -40,8 +41,8 @@ struct hipk_gm_mid_args {
     double eps;
     int test_not_resident, slot_stride, xcd_aware;
 };
-static inline size_t hipk_gm_mid_lds_bytes(int H) {
-    return (size_t)((HIPK_BASE_CHUNK + 2 * H) + 8 + HIPK_BASE_CHUNK + kGmMidCols * 256 + 6 * 40 + 32 + 8) * sizeof(double);
+static inline size_t hipk_gm_mid_lds_bytes(int win) {
+    return (size_t)(win + 8 + HIPK_BASE_CHUNK + kGmMidCols * 256 + 6 * 40 + 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the steps of a launch, the constant 100 MHz clock between
@@ -65,7 +66,7 @@ template <int W>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_gm_mid_kernel(hipk_gm_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
     extern __shared__ double mid_lds[];
-    const int g = a.g, H_ = a.H, WIN_ = CH + 2 * a.H, m = a.m;
+    const int g = a.g, WIN_ = a.win, m = a.m;
     const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, g) : ((int)blockIdx.x < g ? (int)blockIdx.x : -1);
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tw = wave & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
@@ -80,7 +81,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     double *bvs = gvs + 80;                  // [40] beta_vec under the rotations (TSL:595-623)
     double *ts = bvs + 40;                   // [32] wavefront sums of w .* w
     int *flags = (int *)(ts + 32);           // [0] a hand-off failed, [1] stop after this step
-    const int64_t n = a.n, base = (int64_t)wg * CH, w0 = base - H_;
+    int *stile = flags + 16;                 // the window's tiles: slot s holds columns 256 stile[s] .. + 255
+    const int64_t n = a.n, base = (int64_t)wg * CH;
+    const int tlo = a.plan.tlo[wg], WINc = a.plan.nslot[wg] * HIPK_TILE;   // this workgroup's window
+    const short *tmap = a.plan.map + (size_t)wg * kMidPlanRange;
+    const int H_ = __builtin_amdgcn_readfirstlane((int)tmap[(int)(base >> 8) - tlo] * HIPK_TILE);   // where the own tiles sit in the window
+    if (tid < kMidPlanSlots) stile[tid] = (tid * HIPK_TILE < WINc) ? a.plan.tiles[wg * kMidPlanSlots + tid] : 0;
+    __syncthreads();
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_gm_scal *scal = a.scal;
     const hipk_gm_view gv_ = scal->v;        // the header block's arrays (workgroup 0 mirrors its private copies there)
@@ -107,14 +114,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int j = 0; j < W; ++j) {   // short rows padded with (+0.0, the zero slot WIN): see hipk_cg_mid.h
             const bool has = j < len;
-            cj[k][j] = has ? (int)(a.col[lo + j] - w0) : WIN_;
+            const int cc = has ? a.col[lo + j] : 0;
+            cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN_;
             vj[k][j] = has ? a.val[lo + j] : 0.0;
         }
     }
     if (tid < 8) vw[WIN_ + tid] = 0.0;
-    for (int idx = tid; idx < WIN_; idx += NTHR) {
-        const int64_t gc = w0 + idx;
-        vw[idx] = (gc >= 0 && gc < n) ? a.V[gc] : 0.0;
+    for (int idx = tid; idx < WINc; idx += NTHR) {
+        const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
+        vw[idx] = gc < n ? a.V[gc] : 0.0;
     }
     if (tid < 40) {
         hs[tid] = 0.0;
@@ -125,7 +133,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (tid < 80) gvs[tid] = (tid < 2 * ldh && tid < 64) ? gv_.gv[tid] : 0.0;
     const int incremental = scal->incremental;
     const double ptol = scal->ptol, eps = a.eps;
-    const int pub_lo = H_, pub_hi = CH - H_;   // rows whose v another workgroup's window holds
+    // rows whose v another workgroup's window holds (their tile is in that window's list): element i = 2t + 512 q4 (+1) of the chunk
+    const bool pub = a.plan.needed[(int)(base >> 8) + ((2 * t + 512 * q4) >> 8)] != 0;
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the cycle to the launches
     int epoch = 0;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 vw[H + i + e] = v;
                 if (base + i + e < n) {
                     Vn[i + e] = v;
-                    if (i + e < pub_lo || i + e >= pub_hi) hipk_ll_put(ll, (unsigned)(base + i + e), v, seq_v);
+                    if (pub) hipk_ll_put(ll, (unsigned)(base + i + e), v, seq_v);
                 }
             }
         }
@@ -404,10 +413,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         HIPK_MSTAMP(9);
         if (flags[1] || k + 1 >= m) break;
         // hand-off: v_{k+1} at the window's halo columns
-        for (int idx = tid; idx < 2 * H; idx += NTHR) {
-            const int widx = idx < H ? idx : idx + CH;
-            const int64_t gc = w0 + widx;
-            if (gc >= 0 && gc < n) {
+        for (int widx = tid; widx < WINc; widx += NTHR) {
+            const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
+            if ((widx < H || widx >= H + CH) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq_v, hipk_ll_load(ll, (unsigned)gc), v)) flags[0] = 1;
                 vw[widx] = v;

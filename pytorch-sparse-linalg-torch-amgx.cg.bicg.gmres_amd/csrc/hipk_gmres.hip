@@ -2299,7 +2299,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     // Arnoldi steps of a cycle in ONE launch, one workgroup per chunk (hipk_gm_mid.h); HIPK_GMRES_MID=0 keeps the launches
     static bool mid_failed = false;
     bool mid_cycle = false;
-    int mid_H = 0;
+    hipk_mid_plan mid_plan;
+    memset(&mid_plan, 0, sizeof(mid_plan));
     size_t mid_lds = 0;
     void (*mid_kern)(hipk_gm_mid_args) = nullptr;
     if constexpr (sizeof(T) == 8) {
@@ -2311,21 +2312,10 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
         mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7>
                    : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9> : hipk_gm_mid_kernel<12>;
         if (mid_cycle) {
-            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
-                int *out = (int *)part_spare, reach = 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
-                int rgrid = (int)((n + 255) / 256);
-                if (rgrid > 2048) rgrid = 2048;
-                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                A->mid_reach1 = reach + 1;
-            }
-            mid_H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            mid_lds = hipk_gm_mid_lds_bytes(mid_H);
+            mid_cycle = hipk_mid_plan_get(A, 1, stream, &mid_plan);   // the tiles each workgroup's window holds (hipk_mid.h)
+            mid_lds = mid_cycle ? hipk_gm_mid_lds_bytes(mid_plan.max_slots * HIPK_TILE) : 0;
             int occ = 0;
-            mid_cycle = mid_lds <= (size_t)160 * 1024 &&
+            mid_cycle = mid_cycle && mid_plan.max_slots <= kMidPlanSlots && mid_lds <= (size_t)160 * 1024 &&
                         hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) == hipSuccess &&
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, mid_lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
             (void)hipGetLastError();
@@ -2406,7 +2396,8 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                 memset(&ca, 0, sizeof(ca));
                 ca.n = n;
                 ca.g = gm.g;
-                ca.H = mid_H;
+                ca.win = mid_plan.max_slots * HIPK_TILE;
+                ca.plan = mid_plan;
                 ca.m = m;
                 ca.crow = A->crow;
                 ca.col = A->col;

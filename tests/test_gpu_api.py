@@ -1064,6 +1064,12 @@ def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
     and second cycle); and, on one system, as the CPU oracle."""
     from pytorch_sparse_solver.utils.matrix_utils import (create_convdiff_2d_csr, create_poisson_2d_csr,
                                                           create_variable_diffusion_2d_csr)
+    def grid3d(m_):   # nonsymmetric 7-point stencil on an m^3 grid
+        import scipy.sparse as sp
+        T = sp.diags([-1.3, 2.0, -0.7], [-1, 0, 1], shape=(m_, m_))
+        I = sp.identity(m_)
+        return _scipy_to_csr_dev(sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T))
+
     cases = [(create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=4), {}),          # 44 chunks
              (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=4, solve_method="incremental"), {}),
              (create_poisson_2d_csr(500, 500, device=DEV), dict(tol=1e-6, restart=20, maxiter=3), {}),            # 123 chunks
@@ -1076,7 +1082,9 @@ def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
              (create_poisson_2d_csr(300, 300, device=DEV), dict(tol=1e-3, restart=30, maxiter=50), {}),
              (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=30, maxiter=0), {}),
              (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=15, maxiter=4), {"HIPK_TEST_LDS_NOT_RESIDENT": "1"}),
-             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=15, maxiter=4), {"HIPK_TEST_LDS_NOT_RESIDENT": "2"})]
+             (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8, restart=15, maxiter=4), {"HIPK_TEST_LDS_NOT_RESIDENT": "2"}),
+             (grid3d(64), dict(tol=1e-8, restart=25, maxiter=3), {}),                                             # 128 chunks, three bands of tiles
+             (grid3d(45), dict(tol=1e-8, restart=30, maxiter=2, solve_method="incremental"), {})]               # ragged planes
     for idx, (A, kw, env) in enumerate(cases):
         h = hipk.handle_for(A)
         n = A.shape[0]
