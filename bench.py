@@ -484,22 +484,35 @@ def main():
     if not use_dist and nx == NX and not strong and not args.no_n64m:
         launch_bound = []
         from pytorch_sparse_solver.utils.matrix_utils import create_convdiff_2d_csr
-        for solver, mk, side, its in (("cg", create_poisson_2d_csr, 500, 1000), ("cg", create_poisson_2d_csr, 1000, 1000),
-                                      ("bicgstab", create_convdiff_2d_csr, 500, 60)):
-            Am = mk(side, side, device=dev)
+        def grid3d(m_):   # 7-point Poisson on an m^3 grid
+            import numpy as np
+            import scipy.sparse as sp
+            T_ = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m_, m_))
+            I_ = sp.identity(m_)
+            M_ = (sp.kron(sp.kron(T_, I_), I_) + sp.kron(sp.kron(I_, T_), I_) + sp.kron(sp.kron(I_, I_), T_)).tocsr()
+            M_.sort_indices()
+            return torch.sparse_csr_tensor(torch.from_numpy(M_.indptr.astype(np.int64)), torch.from_numpy(M_.indices.astype(np.int64)),
+                                           torch.from_numpy(M_.data), size=M_.shape).to(dev)
+
+        for solver, mk, side, its, kw in (("cg", create_poisson_2d_csr, 500, 1000, {}), ("cg", create_poisson_2d_csr, 1000, 1000, {}),
+                                          ("cg", None, 64, 150, {}), ("bicgstab", create_convdiff_2d_csr, 500, 60, {}),
+                                          ("gmres", create_convdiff_2d_csr, 500, 10, {"restart": 30})):
+            Am = mk(side, side, device=dev) if mk is not None else grid3d(side)
             hm = _hipk.handle_for(Am)
-            bm = torch.ones(side * side, dtype=torch.float64, device=dev)
+            nm = Am.shape[0]
+            bm = torch.ones(nm, dtype=torch.float64, device=dev)
             best = None
             for rep in range(3):
                 xm = torch.zeros_like(bm)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                stm = _hipk.solve(solver, hm, bm, xm, tol=1e-12, atol=0.0, maxiter=its)
+                stm = _hipk.solve(solver, hm, bm, xm, tol=1e-12, atol=0.0, maxiter=its, **kw)
                 torch.cuda.synchronize()
                 us = (time.perf_counter() - t0) / max(stm.iterations, 1) * 1e6
                 best = us if best is None or us < best else best
-            launch_bound.append({"solver": solver, "rows": side * side, "reduction_chunks": -(-side * side // 2048),
-                                 "iterations": stm.iterations, "us_per_iteration": round(best, 2)})
+            launch_bound.append({"solver": solver + ("(30)" if solver == "gmres" else ""), "system": f"{side}^2 stencil" if mk is not None else f"{side}^3 7-point",
+                                 "rows": nm, "reduction_chunks": -(-nm // 2048), "iterations_or_cycles": stm.iterations,
+                                 ("us_per_cycle" if solver == "gmres" else "us_per_iteration"): round(best, 2)})
             del Am, hm, bm, xm
         _hipk.clear_cache()
         torch.cuda.empty_cache()
