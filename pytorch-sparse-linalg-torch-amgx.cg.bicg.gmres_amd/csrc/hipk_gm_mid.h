@@ -37,6 +37,7 @@ struct hipk_gm_mid_args {
     int64_t ldv;
     unsigned long long *v_ll;      // [2 n] flagged words of v_{k+1}
     unsigned long long *slots;     // see kGmMidSlotBytes
+    const double *dinv;            // PRE: the Jacobi preconditioner's diagonal, w = dinv .* (A v) (left preconditioning, TSL:351)
     hipk_gm_scal *scal;
     double eps;
     int test_not_resident, slot_stride, xcd_aware;
@@ -62,7 +63,9 @@ __device__ unsigned long long hipk_gm_mid_stamps[kGmMidMaxChunks * HIPK_GMM_NSTA
 #define HIPK_MSTAMP(k)
 #endif
 
-template <int W>
+// PRE: Jacobi-preconditioned GMRES -- the row scaling of the SpMV kernels' epilogue (HIPK_SPMV_SCALE: out = dinv .* out before the
+// fused ||w||^2), which is the whole difference inside a cycle (hipk_pgmres_solve).
+template <int W, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_gm_mid_kernel(hipk_gm_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
     extern __shared__ double mid_lds[];
@@ -101,11 +104,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (tid < 2) flags[tid] = 0;
 
     // ---- the own rows' matrix entries in registers (thread: rows 256 (t0 + 4 k) + tl); v_0 over the window from the basis
-    double vj[R][W];
+    double vj[R][W], dj[R];
     int cj[R][W];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int64_t row = base + (t0 + TSTEP * k) * HIPK_TILE + tl;
+        dj[k] = (PRE && row < n) ? a.dinv[row] : 1.0;
         int lo = 0, len = 0;
         if (row < n) {
             lo = a.crow[row];
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     const double pr = vj[kk][j] * vw[cj[kk][j]];
                     acc = acc + pr;
                 }
+                if (PRE) acc = dj[kk] * acc;   // w = M (A v_k)
                 wq[lrow] = acc;   // rows beyond n: padding only, +0.0
                 d[kk] = (base + lrow < n) ? acc * acc : 0.0;
             }

@@ -2305,12 +2305,16 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     void (*mid_kern)(hipk_gm_mid_args) = nullptr;
     if constexpr (sizeof(T) == 8) {
         const int mid_min = env_int("HIPK_GMRES_MID_MIN", kGmMidMinChunks);   // (A/B against the whole-solve kernel of 9 .. 32 chunks)
-        mid_cycle = !small && !ext && dinv == nullptr && m <= HIPK_GM_MAXM && gm.g > (mid_min < 8 ? 8 : mid_min) && gm.g <= kGmMidMaxChunks &&
+        mid_cycle = !small && !ext && m <= HIPK_GM_MAXM && gm.g > (mid_min < 8 ? 8 : mid_min) && gm.g <= kGmMidMaxChunks &&
                     gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr && A->crow != nullptr && A->max_row_len <= 12 &&
                     prm->profile == 0 && !mid_failed && !(getenv("HIPK_GMRES_MID") && getenv("HIPK_GMRES_MID")[0] == '0') &&
                     !getenv("HIPK_GMRES_NO_CYCLE");
-        mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7>
-                   : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9> : hipk_gm_mid_kernel<12>;
+        if (dinv)
+            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5, true> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7, true>
+                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9, true> : hipk_gm_mid_kernel<12, true>;
+        else
+            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7>
+                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9> : hipk_gm_mid_kernel<12>;
         if (mid_cycle) {
             mid_cycle = hipk_mid_plan_get(A, 1, stream, &mid_plan);   // the tiles each workgroup's window holds (hipk_mid.h)
             mid_lds = mid_cycle ? hipk_gm_mid_lds_bytes(mid_plan.max_slots * HIPK_TILE) : 0;
@@ -2406,6 +2410,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                 ca.ldv = ldv;
                 ca.v_ll = (unsigned long long *)(vbase + (size_t)(m + 2) * vec);      // behind the basis and tmp (hipk_gmres_work_bytes)
                 ca.slots = (unsigned long long *)(vbase + (size_t)(m + 4) * vec);
+                ca.dinv = (const double *)dinv;
                 ca.scal = scal;
                 ca.eps = eps_t;
                 ca.slot_stride = 16;

@@ -1104,6 +1104,29 @@ def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
             st = hipk.solve("gmres", h, b, x, atol=0.0, **kw)
             out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
         assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, out[0][1:], out[1][1:])
+    # the same with M = diag(d) applied after every A (hipk_gm_mid_kernel<W, PRE>: the row scaling of the SpMV epilogue); a diagonal
+    # that is NOT the matrix's own, so that the scaling matters
+    import scipy.sparse as sp
+    for idx, (A, kw, env) in enumerate(cases):
+        if idx in (6, 7, 10):
+            continue
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        g = torch.Generator(device=DEV).manual_seed(200 + idx)
+        dinv = 0.2 + torch.rand(n, dtype=torch.float64, device=DEV, generator=g)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_GMRES_MID", mid)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b)
+            st = hipk.solve_pgmres(h, dinv, b, x, atol=0.0, **kw)
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], ("jacobi", idx, out[0][1:], out[1][1:])
     monkeypatch.delenv("HIPK_GMRES_MID", raising=False)
     A, kw, _ = cases[2]
     b = torch.ones(A.shape[0], dtype=torch.float64, device=DEV)
