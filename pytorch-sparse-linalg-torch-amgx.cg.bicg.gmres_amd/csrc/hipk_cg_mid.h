@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((lane & 7) == 0 && q < NCH && wg * NCH + q < g) hipk_ll_put(pap_ll, (wg * NCH + q) * ss, 0.0 + tp, seq);
         }
         HIPK_MSTAMP(1);
-        if (tid < 256) sb[buf * NSB + tid] = hipk_mid_poll(pap_ll, g, seq, fail, ss);
+        if (tid < 256) sb[buf * NSB + tid] = hipk_mid_poll<kMidMaxChunks / 256, true>(pap_ll, g, seq, fail, ss);
         HIPK_MSTAMP(2);
         __syncthreads();
         const double pAp = hipk_mid_tree(sb + buf * NSB, lane);
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
             if ((widx < H || widx >= H + OWN) && gc < n) {
                 double v = 0.0;
-                if (!hipk_ll_wait(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
+                if (!hipk_ll_wait<true>(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
                 rw[widx] = v;
             }
         }
         HIPK_MSTAMP(7);
         if (tid < 256) {
-            sb[buf * NSB + tid] = hipk_mid_poll(rr_ll, g, seq, fail, ss);
-            if (PRE) sb[buf * NSB + 256 + tid] = hipk_mid_poll(rz_ll, g, seq, fail, ss);
+            sb[buf * NSB + tid] = hipk_mid_poll<kMidMaxChunks / 256, true>(rr_ll, g, seq, fail, ss);
+            if (PRE) sb[buf * NSB + 256 + tid] = hipk_mid_poll<kMidMaxChunks / 256, true>(rz_ll, g, seq, fail, ss);
         }
         HIPK_MSTAMP(8);
         __syncthreads();
