@@ -26,6 +26,7 @@ struct hipk_bi_mid_args {
     const double *val;
     double *x, *r, *p, *q;
     const double *rhat;
+    const double *dinv;                // PRE: Jacobi preconditioning, M = diag(dinv) applied BEFORE A (TSL:908, 922)
     unsigned long long *q_ll, *r_ll;   // [2 n] flagged words of q and r
     unsigned long long *slots;         // kBiMidKinds arrays of g slots, slot_stride 16-byte words apart
     double *part_rr, *part_rhr;        // chunk partials in memory: read by the first iteration of a launch, left by its last
@@ -35,11 +36,13 @@ struct hipk_bi_mid_args {
     int slot_stride;
     int xcd_aware;
 };
-static inline size_t hipk_bi_mid_lds_bytes(int H) {
-    return (size_t)(3 * (HIPK_BASE_CHUNK + 2 * H) + 16 + HIPK_BASE_CHUNK + 2 * 3 * 256 + 3 * 32 + 8) * sizeof(double);
+static inline size_t hipk_bi_mid_lds_bytes(int H, bool pre = false) {   // pre: + the window of dinv
+    return (size_t)((pre ? 4 : 3) * (HIPK_BASE_CHUNK + 2 * H) + 24 + HIPK_BASE_CHUNK + 2 * 3 * 256 + 3 * 32 + 8) * sizeof(double);
 }
 
-template <int W>
+// PRE: phat = dinv .* p and shat = dinv .* s are the products' inputs (formed at the gathered columns from a fourth LDS window, the
+// owners' formulas on the owners' operands) and x advances with them (TSL:908, 922, 942): hipk_bi_*_kernel<T, true> bit for bit.
+template <int W, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_bi_mid_kernel(hipk_bi_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
     constexpr double EPS = HIPK_EPS64;
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     double *sb = hw + CH;            // 2 x [3 x 256]: fold buffers, used alternately
     double *ts = sb + 2 * 3 * 256;   // [3 x 32] wavefront sums of the tiled dots
     int *fail = (int *)(ts + 3 * 32);
+    double *dw = ts + 3 * 32 + 1;    // PRE: dinv at the window's columns; dw[WIN] = 0.0
     const int64_t n = a.n, base = (int64_t)wg * CH, w0 = base - H;
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_bi_scal *scal = a.scal;
@@ -97,7 +101,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         pw[idx] = in ? a.p[gc] : 0.0;
         qw[idx] = in ? a.q[gc] : 0.0;
         rw[idx] = in ? a.r[gc] : 0.0;
+        if (PRE) dw[idx] = in ? a.dinv[gc] : 0.0;
     }
+    if (PRE && tid < 8) dw[WIN + tid] = 0.0;
     if (tid < 8) rw[WIN + tid] = 0.0;   // s at the zero slot (the second product gathers from rw)
     double rho = scal->rho, alpha = scal->alpha, omega = scal->omega;
     const double atol2 = scal->atol2;
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         int H = H_, WIN = WIN_;
         asm volatile("" : "+s"(H), "+s"(WIN));
         double *qw = pw + WIN + 8, *rw = qw + WIN, *hw = rw + WIN + 8;
+        double *dw = hw + CH + 2 * 3 * 256 + 3 * 32 + 1;
         double *sbb = sb + buf * 3 * 256;
         // ---- K1: rs = <r,r>, rho' = <rhat,r> -> tests; beta; p = r + beta (p - omega q) over the window   (TSL:893-907)
         if (tid < 256) {
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 double acc = 0.0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double pr = vj[k][j] * pw[cj[k][j]];
+                    const double pin = PRE ? dw[cj[k][j]] * pw[cj[k][j]] : pw[cj[k][j]];   // phat = M p (TSL:908)
+                    const double pr = vj[k][j] * pin;
                     acc = acc + pr;
                 }
                 qw[H + lrow] = acc;
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 double acc = 0.0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double pr = vj[k][j] * rw[cj[k][j]];
+                    const double sin_ = PRE ? dw[cj[k][j]] * rw[cj[k][j]] : rw[cj[k][j]];   // shat = M s (TSL:922)
+                    const double pr = vj[k][j] * sin_;
                     acc = acc + pr;
                 }
                 to[k] = acc;
@@ -290,7 +299,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-            const double p_own = pw[H + lrow], s_own = rw[H + lrow];
+            const double d_own = PRE ? dw[H + lrow] : 1.0;
+            const double p_own = PRE ? d_own * pw[H + lrow] : pw[H + lrow];   // x advances with phat, shat (TSL:942)
+            const double s_own = rw[H + lrow], sh_own = PRE ? d_own * s_own : s_own;
             double r_new;
             if (exit_early) {  // TSL:942-950 with exit_early true
                 const double m0 = alpha_new * p_own;
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 r_new = s_own;
             } else {
                 const double m0 = alpha_new * p_own;
-                const double m1 = omega_new * s_own;
+                const double m1 = omega_new * sh_own;
                 const double m2 = m0 + m1;
                 xo[k] = xo[k] + m2;
                 const double m3 = omega_new * to[k];

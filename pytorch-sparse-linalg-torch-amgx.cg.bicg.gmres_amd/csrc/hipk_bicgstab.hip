@@ -765,15 +765,15 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     // whole loop in one launch, one workgroup per chunk (hipk_bi_mid.h); HIPK_BICGSTAB_MID=0 leaves them to the paths below
     static bool mid_failed = false;
     bool mid_loop = false;
-    if constexpr (sizeof(T) == 8 && !PRE) {
+    if constexpr (sizeof(T) == 8) {
         mid_loop = !ext && gm.g > kMidMinChunks && gm.g <= kBiMidMaxChunks && gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_BICGSTAB_MID") && getenv("HIPK_BICGSTAB_MID")[0] == '0') && !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") &&
                    !getenv("HIPK_BICGSTAB_NO_SMALL");
-        void (*mid_kern)(hipk_bi_mid_args) = A->max_row_len <= 5   ? hipk_bi_mid_kernel<5>
-                                             : A->max_row_len <= 7 ? hipk_bi_mid_kernel<7>
-                                             : A->max_row_len <= 9 ? hipk_bi_mid_kernel<9>
-                                                                   : hipk_bi_mid_kernel<12>;
+        void (*mid_kern)(hipk_bi_mid_args) = A->max_row_len <= 5   ? hipk_bi_mid_kernel<5, PRE>
+                                             : A->max_row_len <= 7 ? hipk_bi_mid_kernel<7, PRE>
+                                             : A->max_row_len <= 9 ? hipk_bi_mid_kernel<9, PRE>
+                                                                   : hipk_bi_mid_kernel<12, PRE>;
         int H = 0;
         size_t lds = 0;
         if (mid_loop) {
@@ -789,7 +789,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                 A->mid_reach1 = reach + 1;
             }
             H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_bi_mid_lds_bytes(H);
+            lds = hipk_bi_mid_lds_bytes(H, PRE);
             int occ = 0;
             mid_loop = lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -810,6 +810,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             ca.p = (double *)p;
             ca.q = (double *)q;
             ca.rhat = (const double *)rhat;
+            ca.dinv = (const double *)dinv;
             ca.q_ll = (unsigned long long *)s;                      // s + t: 2 x vec >= 16 n bytes (both are scratch of the launch sequence)
             ca.r_ll = (unsigned long long *)(vbase + 8 * vec);      // behind the eight vectors (hipk_bicgstab_work_bytes)
             ca.slots = (unsigned long long *)(vbase + 10 * vec);

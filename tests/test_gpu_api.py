@@ -1040,6 +1040,36 @@ def test_bicgstab_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
             assert out[0][1] == 0
         if idx < 8:
             assert out[0][1] > 10, (idx, out[0][1])
+    # the same with M = diag(A)^-1 applied before A (hipk_bi_mid_kernel<W, PRE>: a fourth LDS window holds dinv; phat and shat formed at
+    # the gathered columns); against hipk_pbicgstab_solve's launch sequence
+    for idx, (A, kw, env) in enumerate(cases):
+        if idx in (6, 7):
+            continue   # windows beyond the LDS with a fourth one: not taken either way
+        h = hipk.handle_for(A)
+        n = A.shape[0]
+        Ac = A.cpu()
+        dinv = (1.0 / torch.from_numpy(sp.csr_matrix((Ac.values().numpy(), Ac.col_indices().numpy(), Ac.crow_indices().numpy()),
+                                                     shape=A.shape).diagonal())).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(300 + idx)
+        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        out = []
+        for mid in ("1", "0"):
+            monkeypatch.setenv("HIPK_BICGSTAB_MID", mid)
+            if mid == "0":
+                monkeypatch.setenv("HIPK_BICGSTAB_NO_LDS_LOOP", "1")
+            else:
+                monkeypatch.delenv("HIPK_BICGSTAB_NO_LDS_LOOP", raising=False)
+            for k, v in env.items():
+                if mid == "1":
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            x = torch.zeros_like(b) if x0 is None else x0.clone()
+            st = hipk.solve_pcg(h, dinv, b, x, atol=0.0, method="bicgstab", **{"maxiter": None, **kw})
+            out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
+        assert torch.equal(torch.nan_to_num(out[0][0], nan=0.5), torch.nan_to_num(out[1][0], nan=0.5)), ("jacobi", idx, out[0][1:], out[1][1:])
+        assert all(a == b_ or (a != a and b_ != b_) for a, b_ in zip(out[0][1:], out[1][1:])), ("jacobi", idx, out[0][1:], out[1][1:])
     monkeypatch.delenv("HIPK_BICGSTAB_MID", raising=False)
     monkeypatch.delenv("HIPK_BICGSTAB_NO_LDS_LOOP", raising=False)
     A, kw, _ = cases[3]   # (the convection-diffusion systems above diverge for b = ones: a bounded run on a diffusion system)
