@@ -932,7 +932,9 @@ extern "C" size_t hipk_cg_work_bytes(int64_t n, int dtype) {
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     // (the one-launch mid-size loop, hipk_cg_mid.h, keeps r as 16-byte flagged words in Ap + that fourth vector)
     const bool mid = gm.g > kMidMinChunks && gm.g <= kMidMaxChunks;   // + the chunk-partial slots of that loop, a line each
-    return 256 + hipk_scratch_bytes() + (size_t)(3 + (mid ? 1 : 0)) * vec + (mid ? kMidSlotBytes : 0);
+    // (r travels as 16-byte flagged words whatever the dtype: 16 n bytes from Ap on -- one more fp64 vector, three more fp32 ones)
+    const size_t ll = hipk_align_up((size_t)(n > 0 ? n : 1) * 16, 256);
+    return 256 + hipk_scratch_bytes() + 3 * vec + (mid ? (ll - vec) + kMidSlotBytes : 0);
 }
 
 template <typename T>
@@ -1018,18 +1020,18 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
     // (At 9 .. 32 chunks it replaces the eight-workgroups-per-chunk kernel below: 5.0 against 10.7 us per iteration at n = 40 000.)
     static bool mid_failed = false;
     bool mid_loop = false;
-    if constexpr (sizeof(T) == 8) {
+    {
         mid_loop = it == 0 && gm.g > kMidMinChunks && gm.g <= kMidMaxChunks && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0') && !getenv("HIPK_CG_NO_LDS_LOOP") && !getenv("HIPK_CG_NO_SMALL");
         // one workgroup of 1024 threads per CU; a chunk each up to n_cu chunks, two each beyond
         const int nch = gm.g <= A->n_cu ? 1 : 2;
         void (*mid_kern)(hipk_cg_mid_args) =
-            nch == 1 ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1>
-                        : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1>
-                        : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1>
-                                              : hipk_cg_mid_kernel<12, 1>)
-                     : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<5, 2> : hipk_cg_mid_kernel<7, 2>);
+            nch == 1 ? (A->max_row_len <= 5   ? hipk_cg_mid_kernel<T, 5, 1>
+                        : A->max_row_len <= 7 ? hipk_cg_mid_kernel<T, 7, 1>
+                        : A->max_row_len <= 9 ? hipk_cg_mid_kernel<T, 9, 1>
+                                              : hipk_cg_mid_kernel<T, 12, 1>)
+                     : (A->max_row_len <= 5 ? hipk_cg_mid_kernel<T, 5, 2> : hipk_cg_mid_kernel<T, 7, 2>);
         const int mid_threads = 1024, mid_grid = (gm.g + nch - 1) / nch;
         if (nch == 2 && A->max_row_len > 7) mid_loop = false;   // four rows per thread: at most 7 entries each in registers
         size_t lds = 0;
@@ -1039,7 +1041,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             // once per handle: the 256-column tiles each workgroup's window holds (hipk_mid.h); not for matrices whose rows reach
             // further than the plan's range, or whose windows do not fit the LDS
             mid_loop = hipk_mid_plan_get(A, nch, stream, &plan);
-            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, nch) : 0;
+            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, nch, false, sizeof(T)) : 0;
             int occ = 0;
             mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -1048,7 +1050,7 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             (void)hipGetLastError();
         }
         if (mid_loop) {
-            const size_t vec8 = hipk_align_up((size_t)n * sizeof(double), 256);
+            const size_t vec8 = hipk_align_up((size_t)n * 16, 256) / 2;   // half of the flagged words' 16 n bytes
             const char *e = getenv("HIPK_CG_LAUNCH_ITS");
             hipk_cg_mid_args ca;
             memset(&ca, 0, sizeof(ca));
@@ -1058,10 +1060,10 @@ static int hipk_cg_solve_t(hipk_csr_s *A, const T *b, T *x, char *work, const hi
             ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
-            ca.val = (const double *)A->val;
-            ca.x = (double *)x;
-            ca.r = (double *)r;
-            ca.p = (double *)p;
+            ca.val = A->val;
+            ca.x = x;
+            ca.r = r;
+            ca.p = p;
             ca.r_ll = (unsigned long long *)Ap;      // Ap + the fourth vector: 2 x vec >= 16 n bytes
             ca.pap_ll = (unsigned long long *)((char *)Ap + 2 * vec8);   // behind the four vectors (hipk_cg_work_bytes)
             ca.rr_ll = ca.pap_ll + kMidSlotBytes / 16;
@@ -1681,7 +1683,8 @@ extern "C" size_t hipk_pcg_work_bytes(int64_t n, int dtype) {
     // mid-size systems (the one-launch loop, hipk_cg_mid.h<.., PRE>): r as 16-byte flagged words in Ap + a fourth vector, three slot arrays
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     const bool mid = gm.g > kMidMinChunks && gm.g <= kPcgMidMaxChunks;
-    return 256 + 6 * HIPK_MAX_PARTS * sizeof(double) + (size_t)(3 + (mid ? 1 : 0)) * vec + (mid ? kPcgMidSlotBytes : 0);  // scalars | six partial slots | r, p, Ap
+    const size_t ll = hipk_align_up((size_t)(n > 0 ? n : 1) * 16, 256);   // r as 16-byte flagged words, from Ap on
+    return 256 + 6 * HIPK_MAX_PARTS * sizeof(double) + 3 * vec + (mid ? (ll - vec) + kPcgMidSlotBytes : 0);  // scalars | six partial slots | r, p, Ap
 }
 
 template <typename T>
@@ -1749,20 +1752,20 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
     // launch, one workgroup per chunk (hipk_cg_mid_kernel<W, 1, PRE = true>); HIPK_CG_MID=0 leaves them to the paths below
     static bool mid_failed = false;
     bool mid_loop = false;
-    if constexpr (sizeof(T) == 8) {
+    {
         mid_loop = gm.g > kMidMinChunks && gm.g <= kPcgMidMaxChunks && gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_CG_MID") && getenv("HIPK_CG_MID")[0] == '0') && !getenv("HIPK_CG_NO_LDS_LOOP") && !getenv("HIPK_CG_NO_SMALL");
-        void (*mid_kern)(hipk_cg_mid_args) = A->max_row_len <= 5   ? hipk_cg_mid_kernel<5, 1, true>
-                                             : A->max_row_len <= 7 ? hipk_cg_mid_kernel<7, 1, true>
-                                             : A->max_row_len <= 9 ? hipk_cg_mid_kernel<9, 1, true>
-                                                                   : hipk_cg_mid_kernel<12, 1, true>;
+        void (*mid_kern)(hipk_cg_mid_args) = A->max_row_len <= 5   ? hipk_cg_mid_kernel<T, 5, 1, true>
+                                             : A->max_row_len <= 7 ? hipk_cg_mid_kernel<T, 7, 1, true>
+                                             : A->max_row_len <= 9 ? hipk_cg_mid_kernel<T, 9, 1, true>
+                                                                   : hipk_cg_mid_kernel<T, 12, 1, true>;
         size_t lds = 0;
         hipk_mid_plan plan;
         memset(&plan, 0, sizeof(plan));
         if (mid_loop) {
             mid_loop = hipk_mid_plan_get(A, 1, stream, &plan);   // the tiles each workgroup's window holds (hipk_mid.h)
-            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, 1, true) : 0;
+            lds = mid_loop ? hipk_cg_mid_lds_bytes(plan.max_slots * HIPK_TILE, 1, true, sizeof(T)) : 0;
             int occ = 0;
             mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -1779,15 +1782,16 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
             ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
-            ca.val = (const double *)A->val;
-            ca.x = (double *)x;
-            ca.r = (double *)r;
-            ca.p = (double *)p;
+            ca.val = A->val;
+            ca.x = x;
+            ca.r = r;
+            ca.p = p;
             ca.r_ll = (unsigned long long *)Ap;                          // Ap + the fourth vector: 2 x vec >= 16 n bytes
-            ca.pap_ll = (unsigned long long *)((char *)Ap + 2 * vec);    // behind the four vectors (hipk_pcg_work_bytes)
+            const size_t ll_bytes = hipk_align_up((size_t)n * 16, 256);
+            ca.pap_ll = (unsigned long long *)((char *)Ap + ll_bytes);    // behind the flagged words of r (hipk_pcg_work_bytes)
             ca.rr_ll = ca.pap_ll + (size_t)kMidMaxChunks * 256 / 8;
             ca.rz_ll = ca.rr_ll + (size_t)kMidMaxChunks * 256 / 8;
-            ca.dinv = (const double *)dinv;
+            ca.dinv = dinv;
             ca.rz0_parts = part_z[0];
             ca.slot_stride = gm.g <= 32 ? 1 : 16;
             ca.xcd_aware = 1;
@@ -1804,7 +1808,7 @@ static int hipk_pcg_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, char
             for (;;) {
                 ca.it0 = it;
                 ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, ll_bytes, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.pap_ll, 0, kPcgMidSlotBytes, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(&scal->ctl, 0, sizeof(hipk_lds_ctl), stream));
                 mid_kern<<<hipk_xcd_grid(gm.g), 1024, lds, stream>>>(ca);

@@ -28,13 +28,13 @@ struct hipk_cg_mid_args {
     int g, win;                   // chunks; doubles of a window in LDS = 256 x the most tiles any workgroup's window holds
     hipk_mid_plan plan;           // which tiles (hipk_mid.h)
     const int *crow, *col;
-    const double *val;
-    double *x, *r, *p;
+    const void *val;              // values, x, r, p, dinv: of the handle's dtype (the kernel's T)
+    void *x, *r, *p;
     unsigned long long *r_ll;     // [2 n] flagged words of r
     unsigned long long *pap_ll;   // [2 g] chunk partials of <p,Ap>
     unsigned long long *rr_ll;    // [2 g] chunk partials of <r,r>
     unsigned long long *rz_ll;    // PRE: chunk partials of <r, M r>
-    const double *dinv;           // PRE: the Jacobi preconditioner's diagonal, M = diag(dinv) (TSL:849)
+    const void *dinv;             // PRE: the Jacobi preconditioner's diagonal, M = diag(dinv) (TSL:849)
     const double *rz0_parts;      // PRE, it0 = 0: chunk partials of gamma0 = <r0, M r0> (hipk_pcg_start_kernel)
     hipk_lds_ctl *ctl;
     double *gamma;
@@ -47,8 +47,8 @@ struct hipk_cg_mid_args {
 };
 // LDS of a workgroup that owns `nch` chunks, windows of `win` doubles: p window + 8 zero slots | r window | 2 fold buffers | tile sums |
 // flag | (pre: the window of dinv; two sums per fold) | the window's tile list
-static inline size_t hipk_cg_mid_lds_bytes(int win, int nch, bool pre = false) {
-    return (size_t)((pre ? 3 : 2) * win + 8 + 2 * 256 * nch * (pre ? 2 : 1) + 32 * nch + 8 + kMidPlanSlots / 2) * sizeof(double);
+static inline size_t hipk_cg_mid_lds_bytes(int win, int nch, bool pre = false, size_t sv = 8) {   // sv: bytes of a vector element
+    return (size_t)((pre ? 3 : 2) * win + 8) * sv + (size_t)(2 * 256 * nch * (pre ? 2 : 1) + 32 * nch + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the iterations of a launch, the constant 100 MHz clock
@@ -70,7 +70,9 @@ __device__ unsigned long long hipk_mid_stamps[kMidMaxChunks * HIPK_MID_NSTAMP];
 // rows then sit inside a workgroup's own window and are not published).  1024 threads, 2 NCH rows each, one workgroup per CU.
 // PRE (NCH = 1 only): Jacobi-preconditioned CG -- z = dinv .* r is formed where it is used (never stored), gamma = <r,z> steers
 // alpha and beta, <r,r> the stop test (TSL:835-841, 849-852; hipk_pcg_update_kernel / hipk_pcg_direction_kernel bit for bit).
-template <int W, int NCH, bool PRE = false>
+// T: the handle's dtype -- vectors, windows and the element-wise arithmetic in T (fp32 storage: the launch kernels' extension), dots
+// and scalars in double as everywhere.
+template <typename T, int W, int NCH, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_cg_mid_kernel(hipk_cg_mid_args a) {
     static_assert(!PRE || NCH == 1, "the preconditioned form owns one chunk per workgroup");
     constexpr int NSB = 256 * NCH * (PRE ? 2 : 1);   // doubles of one fold buffer
@@ -84,12 +86,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, nwg) : ((int)blockIdx.x < nwg ? (int)blockIdx.x : -1);
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, tw = (tid >> 6) & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
-    double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
-    double *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows (H: where the own tiles sit in the window)
-    double *sb = rw + WIN;           // 2 x [NSB]: fold buffers, used alternately (one barrier per fold)
+    T *pw = (T *)mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
+    T *rw = pw + WIN + 8;       // r at the window's columns; [H, H + OWN) are the own rows (H: where the own tiles sit in the window)
+    double *sb = (double *)(rw + WIN);   // 2 x [NSB]: fold buffers, used alternately (one barrier per fold)
     double *ts = sb + 2 * NSB;       // [32 NCH] wavefront sums of <p,Ap>, 4 per tile
     int *fail = (int *)(ts + 32 * NCH);
-    double *dw = (double *)(fail + 2);   // PRE: dinv at the window's columns
+    T *dw = (T *)(fail + 2);         // PRE: dinv at the window's columns
     int *stile = (int *)(dw + (PRE ? WIN : 0));   // the window's tiles: slot s holds columns 256 stile[s] .. + 255
     const int64_t n = a.n, base = (int64_t)wg * OWN;
     const int tlo = a.plan.tlo[wg], WINc = a.plan.nslot[wg] * HIPK_TILE;   // this workgroup's window
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int ss = a.slot_stride;
 
     // ---- the own rows: x, r, matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); the p window in LDS
-    double xo[R], ro[R], vj[R][W];
+    T xo[R], ro[R], vj[R][W];
     int cj[R][W];
     // short rows are padded with (value +0.0, column slot WIN holding +0.0): acc + (0.0 * 0.0) leaves every acc as it is (acc
     // starts at +0.0 and can never become -0.0), so the sum has the bits of the row's own entries added in CSR order -- and no
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (int k = 0; k < R; ++k) {
         const int64_t row = base + (t0 + TSTEP * k) * HIPK_TILE + tl;
         const bool live = row < n;
-        xo[k] = live ? a.x[row] : 0.0;
-        ro[k] = live ? a.r[row] : 0.0;
+        xo[k] = live ? ((const T *)a.x)[row] : (T)0;
+        ro[k] = live ? ((const T *)a.r)[row] : (T)0;
         int lo = 0, len = 0;
         if (live) {
             lo = a.crow[row];
@@ -127,15 +129,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const bool has = j < len;
             const int cc = has ? a.col[lo + j] : 0;
             cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN;
-            vj[k][j] = has ? a.val[lo + j] : 0.0;
+            vj[k][j] = has ? ((const T *)a.val)[lo + j] : (T)0;
         }
     }
-    if (tid < 8) pw[WIN + tid] = 0.0;
+    if (tid < 8) pw[WIN + tid] = (T)0;
     for (int idx = tid; idx < WINc; idx += NTHR) {
         const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
-        pw[idx] = gc < n ? a.p[gc] : 0.0;
-        rw[idx] = 0.0;
-        if (PRE) dw[idx] = gc < n ? a.dinv[gc] : 0.0;
+        pw[idx] = gc < n ? ((const T *)a.p)[gc] : (T)0;
+        rw[idx] = (T)0;
+        if (PRE) dw[idx] = gc < n ? ((const T *)a.dinv)[gc] : (T)0;
     }
     double gamma = a.gamma[a.it0 & 1];
     const double atol2 = *a.atol2;
@@ -178,25 +180,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // kept in a register (hipk_bi_mid.h: 25 spilled VGPRs became 1)
         int H = H_, WIN = WIN_;
         asm volatile("" : "+s"(H), "+s"(WIN));
-        double *rw = pw + WIN + 8;
-        double *dw = (double *)((int *)(rw + WIN + 2 * NSB + 32 * NCH) + 2);
+        T *rw = pw + WIN + 8;
+        T *dw = (T *)((int *)((double *)(rw + WIN) + 2 * NSB + 32 * NCH) + 2);
         // ---- A p of the own rows (products rounded, added in CSR order), wavefront sums of p .* (A p)   (TSL:845-846)
-        double Ap[R];
+        T Ap[R];
 #pragma unroll
         for (int k = 0; k < R; k += 2) {
             double d[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lrow = (t0 + TSTEP * (k + h)) * HIPK_TILE + tl;
-                double acc = 0.0;
+                T acc = (T)0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double pr = vj[k + h][j] * pw[cj[k + h][j]];
+                    const T pr = vj[k + h][j] * pw[cj[k + h][j]];
                     acc = acc + pr;
                 }
                 Ap[k + h] = acc;   // rows beyond n: padding only, +0.0
                 if (R > 2) rw[H + lrow] = acc;   // four rows per thread: A p waits in the (idle) own slot of the r window
-                d[h] = (base + lrow < n) ? pw[H + lrow] * acc : 0.0;
+                d[h] = (base + lrow < n) ? (double)pw[H + lrow] * (double)acc : 0.0;
             }
             const double s2 = hipk_wave_sum_pair(d[0], d[1]);
             if ((lane & 31) == 0) ts[(t0 + TSTEP * (k + (lane >> 5))) * 4 + tw] = s2;
@@ -224,33 +226,35 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             return;
         }
         // ---- alpha, r, x; r to the neighbours; the chunks' partials of <r,r>   (TSL:846-850)
-        const double alpha = gamma / pAp;
+        const T alpha = (T)(gamma / pAp);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-            const double Ap_k = (R > 2) ? rw[H + lrow] : Ap[k];
-            const double m1 = alpha * Ap_k;
+            const T Ap_k = (R > 2) ? rw[H + lrow] : Ap[k];
+            const T m1 = alpha * Ap_k;
             ro[k] = ro[k] - m1;
-            const double m0 = alpha * pw[H + lrow];
+            const T m0 = alpha * pw[H + lrow];
             xo[k] = xo[k] + m0;
             rw[H + lrow] = ro[k];
-            if (base + lrow < n && pub[k]) hipk_ll_put(r_ll, (unsigned)(base + lrow), ro[k], seq);
+            if (base + lrow < n && pub[k]) hipk_ll_put(r_ll, (unsigned)(base + lrow), (double)ro[k], seq);   // (a float travels as the double it equals)
         }
         __syncthreads();
         HIPK_MSTAMP(4);
         if (tid < 256 * NCH) {
             const int q = tid >> 8, t = tid & 255;
-            double acc = 0.0, acc1 = 0.0;   // virtual thread t of chunk q: elements {2t, 2t+1} + 512 j ascending (the plain dot of the spec)
+            constexpr int VEC = hipk_vec<T>::VEC;
+            double acc = 0.0, acc1 = 0.0;   // virtual thread t of chunk q: elements {VEC t .. VEC t + VEC - 1} + 256 VEC j ascending (the plain dot of the spec)
 #pragma unroll
-            for (int j = 0; j < CH / 512; ++j)
+            for (int j = 0; j < CH / (256 * VEC); ++j)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = q * CH + 2 * t + 512 * j + k;
-                    const double v = rw[H + i];
+                for (int k = 0; k < VEC; ++k) {
+                    const int i = q * CH + VEC * t + 256 * VEC * j + k;
+                    const T rv = rw[H + i];
+                    const double v = (double)rv;
                     if (base + i < n) acc = fma(v, v, acc);
                     if (PRE) {
-                        const double z = dw[H + i] * v;   // TSL:849
-                        if (base + i < n) acc1 = fma(v, z, acc1);   // TSL:850
+                        const T z = dw[H + i] * rv;   // TSL:849
+                        if (base + i < n) acc1 = fma(v, (double)z, acc1);   // TSL:850
                     }
                 }
             sb[buf * NSB + tid] = acc;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((widx < H || widx >= H + OWN) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait<true>(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
-                rw[widx] = v;
+                rw[widx] = (T)v;
             }
         }
         HIPK_MSTAMP(7);
@@ -295,10 +299,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             return;
         }
         // ---- beta, p over the whole window, stop test   (TSL:851-853, 841)
-        const double beta = gamma_new / gamma;
+        const T beta = (T)(gamma_new / gamma);
         for (int idx = tid; idx < WINc; idx += NTHR) {
-            const double zj = PRE ? dw[idx] * rw[idx] : rw[idx];   // z = M r (TSL:849), formed again: same operands, same bits
-            const double m = beta * pw[idx];
+            const T zj = PRE ? dw[idx] * rw[idx] : rw[idx];   // z = M r (TSL:849), formed again: same operands, same bits
+            const T m = beta * pw[idx];
             pw[idx] = zj + m;
         }
         __syncthreads();
@@ -313,9 +317,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (int k = 0; k < R; ++k) {
         const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
         if (base + lrow < n) {
-            a.x[base + lrow] = xo[k];
-            a.r[base + lrow] = ro[k];
-            a.p[base + lrow] = pw[H + lrow];
+            ((T *)a.x)[base + lrow] = xo[k];
+            ((T *)a.r)[base + lrow] = ro[k];
+            ((T *)a.p)[base + lrow] = pw[H + lrow];
         }
     }
 #ifdef HIPK_GM_STAMPS

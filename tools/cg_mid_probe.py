@@ -10,10 +10,13 @@ from pytorch_sparse_solver import _hipk
 from pytorch_sparse_solver.utils.matrix_utils import create_poisson_2d_csr
 dev = torch.device("cuda", 0)
 VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ("mid", "mid-noxcd", "1", "0")
+DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.float64   # fp32 storage
 for nx in (200, 300, 400, 500, 600, 720, 1000):
     A = create_poisson_2d_csr(nx, nx, device=dev)
+    if DT == torch.float32:
+        A = torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
     h = _hipk.handle_for(A)
-    b = torch.ones(nx * nx, dtype=torch.float64, device=dev)
+    b = torch.ones(nx * nx, dtype=DT, device=dev)
     for rep in range(2):
         for two in VARIANTS:
             os.environ["HIPK_CG_MID"] = "1" if two.startswith("mid") else "0"
