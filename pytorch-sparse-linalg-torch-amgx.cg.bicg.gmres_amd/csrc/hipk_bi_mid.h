@@ -21,7 +21,8 @@ static constexpr size_t kBiMidSlotBytes = (size_t)kBiMidKinds * kMidMaxChunks * 
 
 struct hipk_bi_mid_args {
     int64_t n;
-    int g, H;
+    int g, win;                        // chunks; doubles of a window in LDS = 256 x the most tiles any workgroup's window holds
+    hipk_mid_plan plan;                // which tiles (hipk_mid.h)
     const int *crow, *col;
     const double *val;
     double *x, *r, *p, *q;
@@ -36,8 +37,8 @@ struct hipk_bi_mid_args {
     int slot_stride;
     int xcd_aware;
 };
-static inline size_t hipk_bi_mid_lds_bytes(int H, bool pre = false) {   // pre: + the window of dinv
-    return (size_t)((pre ? 4 : 3) * (HIPK_BASE_CHUNK + 2 * H) + 24 + HIPK_BASE_CHUNK + 2 * 3 * 256 + 3 * 32 + 8) * sizeof(double);
+static inline size_t hipk_bi_mid_lds_bytes(int win, bool pre = false) {   // pre: + the window of dinv
+    return (size_t)((pre ? 4 : 3) * win + 24 + HIPK_BASE_CHUNK + 2 * 3 * 256 + 3 * 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // PRE: phat = dinv .* p and shat = dinv .* s are the products' inputs (formed at the gathered columns from a fourth LDS window, the
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
     constexpr double EPS = HIPK_EPS64;
     extern __shared__ double mid_lds[];
-    const int g = a.g, H = a.H, WIN = CH + 2 * H;
+    const int g = a.g, WIN = a.win;
     const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, g) : ((int)blockIdx.x < g ? (int)blockIdx.x : -1);
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tw = wave & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
@@ -59,7 +60,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     double *ts = sb + 2 * 3 * 256;   // [3 x 32] wavefront sums of the tiled dots
     int *fail = (int *)(ts + 3 * 32);
     double *dw = ts + 3 * 32 + 1;    // PRE: dinv at the window's columns; dw[WIN] = 0.0
-    const int64_t n = a.n, base = (int64_t)wg * CH, w0 = base - H;
+    int *stile = (int *)(dw + (PRE ? WIN + 8 : 0));   // the window's tiles: slot s holds columns 256 stile[s] .. + 255
+    const int64_t n = a.n, base = (int64_t)wg * CH;
+    const int tlo = a.plan.tlo[wg], WINc = a.plan.nslot[wg] * HIPK_TILE;   // this workgroup's window
+    const short *tmap = a.plan.map + (size_t)wg * kMidPlanRange;
+    const int H = __builtin_amdgcn_readfirstlane((int)tmap[(int)(base >> 8) - tlo] * HIPK_TILE);   // where the own tiles sit in the window
+    if (tid < kMidPlanSlots) stile[tid] = (tid * HIPK_TILE < WINc) ? a.plan.tiles[wg * kMidPlanSlots + tid] : 0;
+    __syncthreads();
     const int ntiles = (int)((n + HIPK_TILE - 1) / HIPK_TILE);
     hipk_bi_scal *scal = a.scal;
     if (tid == 0) *fail = 0;
@@ -90,14 +97,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int j = 0; j < W; ++j) {   // short rows padded with (+0.0, the zero slot WIN): see hipk_cg_mid.h
             const bool has = j < len;
-            cj[k][j] = has ? (int)(a.col[lo + j] - w0) : WIN;
+            const int cc = has ? a.col[lo + j] : 0;
+            cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN;
             vj[k][j] = has ? a.val[lo + j] : 0.0;
         }
     }
     if (tid < 8) pw[WIN + tid] = 0.0;
-    for (int idx = tid; idx < WIN; idx += NTHR) {
-        const int64_t gc = w0 + idx;
-        const bool in = gc >= 0 && gc < n;
+    for (int idx = tid; idx < WINc; idx += NTHR) {
+        const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
+        const bool in = gc < n;
         pw[idx] = in ? a.p[gc] : 0.0;
         qw[idx] = in ? a.q[gc] : 0.0;
         rw[idx] = in ? a.r[gc] : 0.0;
@@ -109,7 +117,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const double atol2 = scal->atol2;
     const int64_t stop0 = scal->stop_it;
     double rs_last = scal->rs_last;
-    const int pub_lo = H, pub_hi = CH - H;   // rows whose q / r another workgroup's window holds
+    bool pub[R];   // rows whose q / r another workgroup's window holds (their tile is in that window's list)
+#pragma unroll
+    for (int k = 0; k < R; ++k) pub[k] = a.plan.needed[(int)(base >> 8) + t0 + TSTEP * k] != 0;
 
     // every workgroup resident?  Nothing has been modified yet: a failure leaves the solve to the launch sequence
     int epoch = 0;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             break;
         }
         const double beta = rho_new / rho * alpha / omega;  // TSL:906, left to right
-        for (int idx = tid; idx < WIN; idx += NTHR) {       // TSL:907
+        for (int idx = tid; idx < WINc; idx += NTHR) {       // TSL:907
             const double t1 = omega * qw[idx];
             const double t2 = pw[idx] - t1;
             const double t3 = beta * t2;
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 }
                 qw[H + lrow] = acc;
                 d[k] = (base + lrow < n) ? hw[lrow] * acc : 0.0;
-                if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(ll, (unsigned)(base + lrow), acc, seq);
+                if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), acc, seq);
             }
             const double s2 = hipk_wave_sum_pair(d[0], d[1]);
             if ((lane & 31) == 0) ts[(t0 + TSTEP * (lane >> 5)) * 4 + tw] = s2;
@@ -200,10 +210,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (lane == 0) hipk_ll_put(ll, wg * ss, part, seq, rq_o);
         }
         // hand-off 1: q at the window's halo columns, the partials of <rhat,q>
-        for (int idx = tid; idx < 2 * H; idx += NTHR) {
-            const int widx = idx < H ? idx : idx + CH;
-            const int64_t gc = w0 + widx;
-            if (gc >= 0 && gc < n) {
+        for (int widx = tid; widx < WINc; widx += NTHR) {
+            const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
+            if ((widx < H || widx >= H + CH) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc), v)) *fail = 1;
                 qw[widx] = v;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             extra_mv = 1;
             break;
         }
-        for (int idx = tid; idx < WIN; idx += NTHR) {   // TSL:917
+        for (int idx = tid; idx < WINc; idx += NTHR) {   // TSL:917
             const double m = alpha_new * qw[idx];
             rw[idx] = rw[idx] - m;
         }
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 r_new = s_own - m3;
             }
             rw[H + lrow] = r_new;
-            if (base + lrow < n && (lrow < pub_lo || lrow >= pub_hi)) hipk_ll_put(ll, (unsigned)(base + lrow), r_new, seq, r_off);
+            if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), r_new, seq, r_off);
         }
         __syncthreads();
         sbb = sb + buf * 3 * 256;
@@ -355,10 +364,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             break;
         }
         // hand-off 3: r at the window's halo columns (the partials are polled by K1 of the next iteration)
-        for (int idx = tid; idx < 2 * H; idx += NTHR) {
-            const int widx = idx < H ? idx : idx + CH;
-            const int64_t gc = w0 + widx;
-            if (gc >= 0 && gc < n) {
+        for (int widx = tid; widx < WINc; widx += NTHR) {
+            const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
+            if ((widx < H || widx >= H + CH) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc, r_off), v, r_off)) *fail = 1;
                 rw[widx] = v;

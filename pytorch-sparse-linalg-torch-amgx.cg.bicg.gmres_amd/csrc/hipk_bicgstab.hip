@@ -774,24 +774,14 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
                                              : A->max_row_len <= 7 ? hipk_bi_mid_kernel<7, PRE>
                                              : A->max_row_len <= 9 ? hipk_bi_mid_kernel<9, PRE>
                                                                    : hipk_bi_mid_kernel<12, PRE>;
-        int H = 0;
         size_t lds = 0;
+        hipk_mid_plan plan;
+        memset(&plan, 0, sizeof(plan));
         if (mid_loop) {
-            if (A->mid_reach1 == 0) {   // once per handle: how far the rows of a chunk reach beyond it
-                int *out = (int *)part_spare, reach = 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
-                int rgrid = (int)((n + 255) / 256);
-                if (rgrid > 2048) rgrid = 2048;
-                hipk_mid_reach_kernel<<<rgrid, 256, 0, stream>>>(A->crow, A->col, n, gm.ch, out);
-                HIPK_CHECK_HIP(hipGetLastError());
-                HIPK_CHECK_HIP(hipMemcpyAsync(&reach, out, sizeof(int), hipMemcpyDeviceToHost, stream));
-                HIPK_CHECK_HIP(hipStreamSynchronize(stream));
-                A->mid_reach1 = reach + 1;
-            }
-            H = ((A->mid_reach1 - 1 + 127) / 128) * 128;
-            lds = hipk_bi_mid_lds_bytes(H, PRE);
+            mid_loop = hipk_mid_plan_get(A, 1, stream, &plan);   // the tiles each workgroup's window holds (hipk_mid.h)
+            lds = mid_loop ? hipk_bi_mid_lds_bytes(plan.max_slots * HIPK_TILE, PRE) : 0;
             int occ = 0;
-            mid_loop = lds <= (size_t)160 * 1024 &&
+            mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mid_kern, 1024, lds) == hipSuccess && (int64_t)occ * A->n_cu >= gm.g;
             (void)hipGetLastError();
@@ -801,7 +791,8 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             hipk_bi_mid_args ca;
             ca.n = n;
             ca.g = gm.g;
-            ca.H = H;
+            ca.win = plan.max_slots * HIPK_TILE;
+            ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
             ca.val = (const double *)A->val;

@@ -6,8 +6,8 @@
 //   * x and r of its 2048 rows in registers (thread t owns rows base + 256 tt + t, tt = 0..7: the SpMV's tile layout, so the
 //     <p,Ap> tile sums are wavefront sums over 64 contiguous rows as in the SpMV epilogue),
 //   * its matrix rows (values + window-relative column indices) in registers,
-//   * p at every column its rows reference in LDS: a window [base - H, base + 2048 + H) of the vector, H = the matrix's reach
-//     beyond a chunk (hipk_mid_reach_kernel, once per handle).  After <r,r> the workgroup advances the WHOLE window,
+//   * p at every column its rows reference in LDS: a window of 256-column tiles -- the own ones and every tile the rows reference
+//     (hipk_mid_plan_get, once per handle; contiguous for a 2-D stencil, three bands for a 3-D one).  After <r,r> the workgroup advances the WHOLE window,
 //     p_j = r_j + beta p_j -- the owner's formula on the owner's operands, the same bits -- so p itself is never exchanged
 //     (the trick of hipk_cg_solve_lds_kernel / hipk_cg2_spmv_kernel).
 // What crosses workgroups per iteration: one chunk partial of <p,Ap>, one of <r,r>, and r (for the neighbours' windows).  All

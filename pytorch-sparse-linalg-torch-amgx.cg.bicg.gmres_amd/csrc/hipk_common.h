@@ -100,7 +100,6 @@ struct hipk_csr_s {
     int n_huge;          //   row-per-wavefront pre-pass when the matrix as a whole is short-rowed
     int max_row_len;     // structure analysis at creation
     int max_tile_nnz;    //   (tile = 256 consecutive rows)
-    int mid_reach1;      // 1 + the largest distance of a column from its row's reduction chunk (0: not computed yet; hipk_cg_mid.h)
     // window plan of the one-launch CG loop (hipk_mid.h: hipk_mid_plan_get): per row block, the 256-column tiles its rows reference
     void *mid_plan_mem;  // device, owned: tlo | nslot | tiles | map | needed | status
     int mid_plan_state;  // 0 not computed, 1 usable, -1 the matrix does not fit (range or tile count)

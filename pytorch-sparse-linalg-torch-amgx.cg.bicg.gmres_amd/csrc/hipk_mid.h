@@ -64,25 +64,6 @@ __device__ __forceinline__ bool hipk_ll_wait(hipk_ll_rsrc rs, unsigned slot, uns
     return true;
 }
 
-// reach of the matrix beyond the reduction chunk of each row: max over entries of the distance of the column from [lo, lo + ch)
-static __global__ __launch_bounds__(256) void hipk_mid_reach_kernel(const int *__restrict__ crow, const int *__restrict__ col, int64_t n,
-                                                             int ch, int *__restrict__ out) {
-    int m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t lo = (i / ch) * ch, hi = lo + ch - 1;
-        for (int e = crow[i]; e < crow[i + 1]; ++e) {
-            const int64_t cc = col[e];
-            const int64_t d = cc < lo ? lo - cc : (cc > hi ? cc - hi : 0);
-            m = d > m ? (int)d : m;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(m, off);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
-}
-
 // ---- window plan: which columns a row block's window holds -------------------------------------------------------------------
 // The LDS window of a workgroup is a list of 256-column TILES, ascending: every tile its rows reference plus its own.  For a 2-D
 // stencil that is the contiguous range [base - nx, base + rows + nx); for a 3-D one three bands (own rows +- a grid line, and
