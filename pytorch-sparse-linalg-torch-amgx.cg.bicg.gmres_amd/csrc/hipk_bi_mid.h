@@ -24,10 +24,10 @@ struct hipk_bi_mid_args {
     int g, win;                        // chunks; doubles of a window in LDS = 256 x the most tiles any workgroup's window holds
     hipk_mid_plan plan;                // which tiles (hipk_mid.h)
     const int *crow, *col;
-    const double *val;
-    double *x, *r, *p, *q;
-    const double *rhat;
-    const double *dinv;                // PRE: Jacobi preconditioning, M = diag(dinv) applied BEFORE A (TSL:908, 922)
+    const void *val;                   // values, x, r, p, q, rhat, dinv: of the handle's dtype (the kernel's T)
+    void *x, *r, *p, *q;
+    const void *rhat;
+    const void *dinv;                // PRE: Jacobi preconditioning, M = diag(dinv) applied BEFORE A (TSL:908, 922)
     unsigned long long *q_ll, *r_ll;   // [2 n] flagged words of q and r
     unsigned long long *slots;         // kBiMidKinds arrays of g slots, slot_stride 16-byte words apart
     double *part_rr, *part_rhr;        // chunk partials in memory: read by the first iteration of a launch, left by its last
@@ -37,29 +37,31 @@ struct hipk_bi_mid_args {
     int slot_stride;
     int xcd_aware;
 };
-static inline size_t hipk_bi_mid_lds_bytes(int win, bool pre = false) {   // pre: + the window of dinv
-    return (size_t)((pre ? 4 : 3) * win + 24 + HIPK_BASE_CHUNK + 2 * 3 * 256 + 3 * 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
+static inline size_t hipk_bi_mid_lds_bytes(int win, bool pre = false, size_t sv = 8) {   // pre: + the window of dinv; sv: bytes of a vector element
+    return (size_t)((pre ? 4 : 3) * win + 24 + HIPK_BASE_CHUNK) * sv + (size_t)(2 * 3 * 256 + 3 * 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // PRE: phat = dinv .* p and shat = dinv .* s are the products' inputs (formed at the gathered columns from a fourth LDS window, the
 // owners' formulas on the owners' operands) and x advances with them (TSL:908, 922, 942): hipk_bi_*_kernel<T, true> bit for bit.
-template <int W, bool PRE = false>
+// T: the handle's dtype (vectors, windows, element-wise arithmetic in T; dots and scalars in double).
+template <typename T, int W, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_bi_mid_kernel(hipk_bi_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
-    constexpr double EPS = HIPK_EPS64;
+    constexpr double EPS = hipk_eps<T>::v;
+    constexpr int VEC = hipk_vec<T>::VEC;
     extern __shared__ double mid_lds[];
     const int g = a.g, WIN = a.win;
     const int wg = a.xcd_aware ? hipk_xcd_chunk(blockIdx.x, g) : ((int)blockIdx.x < g ? (int)blockIdx.x : -1);
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tw = wave & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
-    double *pw = mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
-    double *qw = pw + WIN + 8;       // q at the window's columns
-    double *rw = qw + WIN;           // r, between K3 and K5 s, at the window's columns; rw[WIN] = 0.0 as in pw
-    double *hw = rw + WIN + 8;           // rhat of the own rows (the <rhat,r> chains read it in the spec's virtual-thread layout)
-    double *sb = hw + CH;            // 2 x [3 x 256]: fold buffers, used alternately
+    T *pw = (T *)mid_lds;            // p at the window's columns; pw[WIN] = 0.0 for the padding entries of short rows
+    T *qw = pw + WIN + 8;            // q at the window's columns
+    T *rw = qw + WIN;                // r, between K3 and K5 s, at the window's columns; rw[WIN] = 0.0 as in pw
+    T *hw = rw + WIN + 8;            // rhat of the own rows (the <rhat,r> chains read it in the spec's virtual-thread layout)
+    double *sb = (double *)(hw + CH);   // 2 x [3 x 256]: fold buffers, used alternately
     double *ts = sb + 2 * 3 * 256;   // [3 x 32] wavefront sums of the tiled dots
     int *fail = (int *)(ts + 3 * 32);
-    double *dw = ts + 3 * 32 + 1;    // PRE: dinv at the window's columns; dw[WIN] = 0.0
+    T *dw = (T *)(ts + 3 * 32 + 1);  // PRE: dinv at the window's columns; dw[WIN] = 0.0
     int *stile = (int *)(dw + (PRE ? WIN + 8 : 0));   // the window's tiles: slot s holds columns 256 stile[s] .. + 255
     const int64_t n = a.n, base = (int64_t)wg * CH;
     const int tlo = a.plan.tlo[wg], WINc = a.plan.nslot[wg] * HIPK_TILE;   // this workgroup's window
@@ -80,15 +82,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     // ---- the own rows: x and the matrix entries in registers (thread t: rows 256 (t0 + 4 k) + tl); r (s), q, p of the own rows are
     // the [H, H + CH) parts of the LDS windows, rhat sits in hw -- the register file is spent on the matrix (128 VGPRs at 4 waves per SIMD)
-    double xo[R], vj[R][W];
+    T xo[R], vj[R][W];
     int cj[R][W];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
         const int64_t row = base + lrow;
         const bool live = row < n;
-        xo[k] = live ? a.x[row] : 0.0;
-        hw[lrow] = live ? a.rhat[row] : 0.0;
+        xo[k] = live ? ((const T *)a.x)[row] : (T)0;
+        hw[lrow] = live ? ((const T *)a.rhat)[row] : (T)0;
         int lo = 0, len = 0;
         if (live) {
             lo = a.crow[row];
@@ -99,20 +101,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const bool has = j < len;
             const int cc = has ? a.col[lo + j] : 0;
             cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN;
-            vj[k][j] = has ? a.val[lo + j] : 0.0;
+            vj[k][j] = has ? ((const T *)a.val)[lo + j] : (T)0;
         }
     }
-    if (tid < 8) pw[WIN + tid] = 0.0;
+    if (tid < 8) pw[WIN + tid] = (T)0;
     for (int idx = tid; idx < WINc; idx += NTHR) {
         const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
         const bool in = gc < n;
-        pw[idx] = in ? a.p[gc] : 0.0;
-        qw[idx] = in ? a.q[gc] : 0.0;
-        rw[idx] = in ? a.r[gc] : 0.0;
-        if (PRE) dw[idx] = in ? a.dinv[gc] : 0.0;
+        pw[idx] = in ? ((const T *)a.p)[gc] : (T)0;
+        qw[idx] = in ? ((const T *)a.q)[gc] : (T)0;
+        rw[idx] = in ? ((const T *)a.r)[gc] : (T)0;
+        if (PRE) dw[idx] = in ? ((const T *)a.dinv)[gc] : (T)0;
     }
-    if (PRE && tid < 8) dw[WIN + tid] = 0.0;
-    if (tid < 8) rw[WIN + tid] = 0.0;   // s at the zero slot (the second product gathers from rw)
+    if (PRE && tid < 8) dw[WIN + tid] = (T)0;
+    if (tid < 8) rw[WIN + tid] = (T)0;   // s at the zero slot (the second product gathers from rw)
     double rho = scal->rho, alpha = scal->alpha, omega = scal->omega;
     const double atol2 = scal->atol2;
     const int64_t stop0 = scal->stop_it;
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // columns, own rows, passes) is formed ahead of it and kept in a register -- 25 VGPRs spilled at W = 5 with that
         int H = H_, WIN = WIN_;
         asm volatile("" : "+s"(H), "+s"(WIN));
-        double *qw = pw + WIN + 8, *rw = qw + WIN, *hw = rw + WIN + 8;
-        double *dw = hw + CH + 2 * 3 * 256 + 3 * 32 + 1;
+        T *qw = pw + WIN + 8, *rw = qw + WIN, *hw = rw + WIN + 8;
+        T *dw = (T *)((double *)(hw + CH) + 2 * 3 * 256 + 3 * 32 + 1);
         double *sbb = sb + buf * 3 * 256;
         // ---- K1: rs = <r,r>, rho' = <rhat,r> -> tests; beta; p = r + beta (p - omega q) over the window   (TSL:893-907)
         if (tid < 256) {
@@ -176,11 +178,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             code = -10;
             break;
         }
-        const double beta = rho_new / rho * alpha / omega;  // TSL:906, left to right
+        const T beta = (T)(rho_new / rho * alpha / omega);  // TSL:906, left to right
+        const T om = (T)omega;
         for (int idx = tid; idx < WINc; idx += NTHR) {       // TSL:907
-            const double t1 = omega * qw[idx];
-            const double t2 = pw[idx] - t1;
-            const double t3 = beta * t2;
+            const T t1 = om * qw[idx];
+            const T t2 = pw[idx] - t1;
+            const T t3 = beta * t2;
             pw[idx] = rw[idx] + t3;
         }
         __syncthreads();
@@ -190,16 +193,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-                double acc = 0.0;
+                T acc = (T)0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double pin = PRE ? dw[cj[k][j]] * pw[cj[k][j]] : pw[cj[k][j]];   // phat = M p (TSL:908)
-                    const double pr = vj[k][j] * pin;
+                    const T pin = PRE ? dw[cj[k][j]] * pw[cj[k][j]] : pw[cj[k][j]];   // phat = M p (TSL:908)
+                    const T pr = vj[k][j] * pin;
                     acc = acc + pr;
                 }
                 qw[H + lrow] = acc;
-                d[k] = (base + lrow < n) ? hw[lrow] * acc : 0.0;
-                if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), acc, seq);
+                d[k] = (base + lrow < n) ? (double)hw[lrow] * (double)acc : 0.0;
+                if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), (double)acc, seq);   // (a float travels as the double it equals)
             }
             const double s2 = hipk_wave_sum_pair(d[0], d[1]);
             if ((lane & 31) == 0) ts[(t0 + TSTEP * (lane >> 5)) * 4 + tw] = s2;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((widx < H || widx >= H + CH) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc), v)) *fail = 1;
-                qw[widx] = v;
+                qw[widx] = (T)v;
             }
         }
         sbb = sb + buf * 3 * 256;
@@ -232,42 +235,43 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             extra_mv = 1;
             break;
         }
+        const T al = (T)alpha_new;
         for (int idx = tid; idx < WINc; idx += NTHR) {   // TSL:917
-            const double m = alpha_new * qw[idx];
+            const T m = al * qw[idx];
             rw[idx] = rw[idx] - m;
         }
         __syncthreads();
         sbb = sb + buf * 3 * 256;
         if (tid < 256) {
-            double acc = 0.0;   // virtual thread t of the chunk: elements {2t, 2t+1} + 512 j ascending
+            double acc = 0.0;   // virtual thread t of the chunk: elements {VEC t .. VEC t + VEC - 1} + 256 VEC j ascending
 #pragma unroll
-            for (int j = 0; j < CH / 512; ++j)
+            for (int j = 0; j < CH / (256 * VEC); ++j)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = 2 * tid + 512 * j + k;
-                    const double v = rw[H + i];
+                for (int k = 0; k < VEC; ++k) {
+                    const int i = VEC * tid + 256 * VEC * j + k;
+                    const double v = (double)rw[H + i];
                     if (base + i < n) acc = fma(v, v, acc);
                 }
             sbb[tid] = acc;
         }
         // ---- K4: t = A s (own rows), wavefront sums of s .* t and t .* t   (TSL:923-930)
-        double to[R];
+        T to[R];
         {
             double d0[R], d1[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-                double acc = 0.0;
+                T acc = (T)0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double sin_ = PRE ? dw[cj[k][j]] * rw[cj[k][j]] : rw[cj[k][j]];   // shat = M s (TSL:922)
-                    const double pr = vj[k][j] * sin_;
+                    const T sin_ = PRE ? dw[cj[k][j]] * rw[cj[k][j]] : rw[cj[k][j]];   // shat = M s (TSL:922)
+                    const T pr = vj[k][j] * sin_;
                     acc = acc + pr;
                 }
                 to[k] = acc;
                 const bool live = base + lrow < n;
-                d0[k] = live ? rw[H + lrow] * acc : 0.0;   // s of the own row (K3's pass over the window)
-                d1[k] = live ? acc * acc : 0.0;
+                d0[k] = live ? (double)rw[H + lrow] * (double)acc : 0.0;   // s of the own row (K3's pass over the window)
+                d1[k] = live ? (double)acc * (double)acc : 0.0;
             }
             const double s0 = hipk_wave_sum_pair(d0[0], d0[1]), s1 = hipk_wave_sum_pair(d1[0], d1[1]);
             if ((lane & 31) == 0) {
@@ -305,38 +309,39 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             extra_mv = 2;
             break;
         }
+        const T omn = (T)omega_new;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
-            const double d_own = PRE ? dw[H + lrow] : 1.0;
-            const double p_own = PRE ? d_own * pw[H + lrow] : pw[H + lrow];   // x advances with phat, shat (TSL:942)
-            const double s_own = rw[H + lrow], sh_own = PRE ? d_own * s_own : s_own;
-            double r_new;
+            const T d_own = PRE ? dw[H + lrow] : (T)1;
+            const T p_own = PRE ? d_own * pw[H + lrow] : pw[H + lrow];   // x advances with phat, shat (TSL:942)
+            const T s_own = rw[H + lrow], sh_own = PRE ? d_own * s_own : s_own;
+            T r_new;
             if (exit_early) {  // TSL:942-950 with exit_early true
-                const double m0 = alpha_new * p_own;
+                const T m0 = al * p_own;
                 xo[k] = xo[k] + m0;
                 r_new = s_own;
             } else {
-                const double m0 = alpha_new * p_own;
-                const double m1 = omega_new * sh_own;
-                const double m2 = m0 + m1;
+                const T m0 = al * p_own;
+                const T m1 = omn * sh_own;
+                const T m2 = m0 + m1;
                 xo[k] = xo[k] + m2;
-                const double m3 = omega_new * to[k];
+                const T m3 = omn * to[k];
                 r_new = s_own - m3;
             }
             rw[H + lrow] = r_new;
-            if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), r_new, seq, r_off);
+            if (base + lrow < n && pub[k]) hipk_ll_put(ll, (unsigned)(base + lrow), (double)r_new, seq, r_off);
         }
         __syncthreads();
         sbb = sb + buf * 3 * 256;
         if (tid < 256) {
             double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < CH / 512; ++j)
+            for (int j = 0; j < CH / (256 * VEC); ++j)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = 2 * tid + 512 * j + k;
-                    const double rv = rw[H + i], hv = hw[i];
+                for (int k = 0; k < VEC; ++k) {
+                    const int i = VEC * tid + 256 * VEC * j + k;
+                    const double rv = (double)rw[H + i], hv = (double)hw[i];
                     if (base + i < n) {
                         acc0 = fma(rv, rv, acc0);
                         acc1 = fma(hv, rv, acc1);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if ((widx < H || widx >= H + CH) && gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc, r_off), v, r_off)) *fail = 1;
-                rw[widx] = v;
+                rw[widx] = (T)v;
             }
         }
     }
@@ -379,10 +384,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (int k = 0; k < R; ++k) {
         const int lrow = (t0 + TSTEP * k) * HIPK_TILE + tl;
         if (base + lrow < n) {
-            a.x[base + lrow] = xo[k];
-            a.r[base + lrow] = rw[H + lrow];   // (after an omega breakdown this is s: the solve has ended, r is not an output)
-            a.p[base + lrow] = pw[H + lrow];
-            a.q[base + lrow] = qw[H + lrow];
+            ((T *)a.x)[base + lrow] = xo[k];
+            ((T *)a.r)[base + lrow] = rw[H + lrow];   // (after an omega breakdown this is s: the solve has ended, r is not an output)
+            ((T *)a.p)[base + lrow] = pw[H + lrow];
+            ((T *)a.q)[base + lrow] = qw[H + lrow];
         }
     }
     if (have_parts && lane == 0) {

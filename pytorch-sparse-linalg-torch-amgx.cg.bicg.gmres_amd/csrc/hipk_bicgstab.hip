@@ -673,7 +673,8 @@ extern "C" size_t hipk_bicgstab_work_bytes(int64_t n, int dtype) {
     // mid-size systems (hipk_bi_mid.h): q and r travel as 16-byte flagged words (q in s + t, r in two more vectors) + the partial slots
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     const bool mid = gm.g > kMidMinChunks && gm.g <= kBiMidMaxChunks;
-    return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec + (mid ? 4 * vec + kBiMidSlotBytes : 0);
+    const size_t ll = hipk_align_up((size_t)(n > 0 ? n : 1) * 16, 256);   // q and r as 16-byte flagged words whatever the dtype
+    return 256 + (size_t)kBiSlots * HIPK_MAX_PARTS * sizeof(double) + 6 * vec + (mid ? 2 * vec + 2 * ll + kBiMidSlotBytes : 0);
 }
 extern "C" size_t hipk_pbicgstab_work_bytes(int64_t n, int dtype) {
     const size_t sv = (dtype == HIPK_F64) ? 8 : 4;
@@ -765,21 +766,21 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
     // whole loop in one launch, one workgroup per chunk (hipk_bi_mid.h); HIPK_BICGSTAB_MID=0 leaves them to the paths below
     static bool mid_failed = false;
     bool mid_loop = false;
-    if constexpr (sizeof(T) == 8) {
+    {
         mid_loop = !ext && gm.g > kMidMinChunks && gm.g <= kBiMidMaxChunks && gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr &&
                    A->crow != nullptr && A->max_row_len <= 12 && prm->profile == 0 && maxiter > 0 && !mid_failed &&
                    !(getenv("HIPK_BICGSTAB_MID") && getenv("HIPK_BICGSTAB_MID")[0] == '0') && !getenv("HIPK_BICGSTAB_NO_LDS_LOOP") &&
                    !getenv("HIPK_BICGSTAB_NO_SMALL");
-        void (*mid_kern)(hipk_bi_mid_args) = A->max_row_len <= 5   ? hipk_bi_mid_kernel<5, PRE>
-                                             : A->max_row_len <= 7 ? hipk_bi_mid_kernel<7, PRE>
-                                             : A->max_row_len <= 9 ? hipk_bi_mid_kernel<9, PRE>
-                                                                   : hipk_bi_mid_kernel<12, PRE>;
+        void (*mid_kern)(hipk_bi_mid_args) = A->max_row_len <= 5   ? hipk_bi_mid_kernel<T, 5, PRE>
+                                             : A->max_row_len <= 7 ? hipk_bi_mid_kernel<T, 7, PRE>
+                                             : A->max_row_len <= 9 ? hipk_bi_mid_kernel<T, 9, PRE>
+                                                                   : hipk_bi_mid_kernel<T, 12, PRE>;
         size_t lds = 0;
         hipk_mid_plan plan;
         memset(&plan, 0, sizeof(plan));
         if (mid_loop) {
             mid_loop = hipk_mid_plan_get(A, 1, stream, &plan);   // the tiles each workgroup's window holds (hipk_mid.h)
-            lds = mid_loop ? hipk_bi_mid_lds_bytes(plan.max_slots * HIPK_TILE, PRE) : 0;
+            lds = mid_loop ? hipk_bi_mid_lds_bytes(plan.max_slots * HIPK_TILE, PRE, sizeof(T)) : 0;
             int occ = 0;
             mid_loop = mid_loop && plan.max_slots <= kMidPlanSlots && lds <= (size_t)160 * 1024 &&
                        hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
@@ -795,16 +796,17 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             ca.plan = plan;
             ca.crow = A->crow;
             ca.col = A->col;
-            ca.val = (const double *)A->val;
-            ca.x = (double *)x;
-            ca.r = (double *)r;
-            ca.p = (double *)p;
-            ca.q = (double *)q;
-            ca.rhat = (const double *)rhat;
-            ca.dinv = (const double *)dinv;
-            ca.q_ll = (unsigned long long *)s;                      // s + t: 2 x vec >= 16 n bytes (both are scratch of the launch sequence)
-            ca.r_ll = (unsigned long long *)(vbase + 8 * vec);      // behind the eight vectors (hipk_bicgstab_work_bytes)
-            ca.slots = (unsigned long long *)(vbase + 10 * vec);
+            const size_t ll_bytes = hipk_align_up((size_t)n * 16, 256);
+            ca.val = A->val;
+            ca.x = x;
+            ca.r = r;
+            ca.p = p;
+            ca.q = q;
+            ca.rhat = rhat;
+            ca.dinv = dinv;
+            ca.q_ll = (unsigned long long *)(vbase + 8 * vec);      // behind the eight vectors (hipk_bicgstab_work_bytes)
+            ca.r_ll = (unsigned long long *)(vbase + 8 * vec + ll_bytes);
+            ca.slots = (unsigned long long *)(vbase + 8 * vec + 2 * ll_bytes);
             ca.part_rr = part_rr;
             ca.part_rhr = part_rhr;
             ca.scal = scal;
@@ -819,8 +821,7 @@ static int hipk_bicgstab_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x,
             for (;;) {
                 ca.it0 = it;
                 ca.test_not_resident = (++launch_no == fail_launch) ? 1 : 0;
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.q_ll, 0, 2 * vec, stream));
-                HIPK_CHECK_HIP(hipMemsetAsync(ca.r_ll, 0, 2 * vec, stream));
+                HIPK_CHECK_HIP(hipMemsetAsync(ca.q_ll, 0, 2 * ll_bytes, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(ca.slots, 0, kBiMidSlotBytes, stream));
                 HIPK_CHECK_HIP(hipMemsetAsync(&scal->it_done, 0, sizeof(hipk_bi_scal) - offsetof(hipk_bi_scal, it_done), stream));
                 mid_kern<<<hipk_xcd_grid(gm.g), 1024, lds, stream>>>(ca);

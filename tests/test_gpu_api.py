@@ -1016,13 +1016,16 @@ def test_bicgstab_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
              (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-8), {"HIPK_BICGSTAB_LAUNCH_ITS": "5", "HIPK_TEST_LDS_NOT_RESIDENT": "2"}),
              (create_convdiff_2d_csr(300, 300, device=DEV), dict(tol=1e-30, maxiter=400), {})]       # runs into the iteration bound (or a breakdown)
     for idx, (A, kw, env) in enumerate(cases):
-        h = hipk.handle_for(A)
+      for dt in (torch.float64, torch.float32):   # fp32 storage: the kernel's T = float (tolerances it can reach, bounded iterations)
+        Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
+        kw = kw if dt == torch.float64 else {**kw, "tol": max(kw["tol"], 1e-4), "maxiter": min(kw.get("maxiter", 200) or 200, 200)}
+        h = hipk.handle_for(Ad)
         n = A.shape[0]
         g = torch.Generator(device=DEV).manual_seed(idx)
-        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
-        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        b = torch.randn(n, dtype=dt, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=dt, device=DEV, generator=g) if idx % 2 else None
         if idx == 11:
-            x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+            x0 = torch.randn(n, dtype=dt, device=DEV, generator=g)
             b = hipk.spmv(h, x0)
         out = []
         for mid in ("1", "0"):
@@ -1040,11 +1043,11 @@ def test_bicgstab_mid_one_launch_is_bit_identical(hipk, oracle, monkeypatch):
             print("bicgstab mid case", idx, "mid" if mid == "1" else "launch sequence", flush=True)   # (-s: which case a hang is in)
             st = hipk.solve("bicgstab", h, b, x, atol=0.0, **{"maxiter": None, **kw})
             out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
-        assert torch.equal(torch.nan_to_num(out[0][0], nan=0.5), torch.nan_to_num(out[1][0], nan=0.5)), (idx, out[0][1:], out[1][1:])
-        assert all(a == b_ or (a != a and b_ != b_) for a, b_ in zip(out[0][1:], out[1][1:])), (idx, out[0][1:], out[1][1:])
+        assert torch.equal(torch.nan_to_num(out[0][0], nan=0.5), torch.nan_to_num(out[1][0], nan=0.5)), (idx, dt, out[0][1:], out[1][1:])
+        assert all(a == b_ or (a != a and b_ != b_) for a, b_ in zip(out[0][1:], out[1][1:])), (idx, dt, out[0][1:], out[1][1:])
         if idx == 11:
             assert out[0][1] == 0
-        if idx < 8:
+        if idx < 8 and dt == torch.float64:
             assert out[0][1] > 10, (idx, out[0][1])
     # the same with M = diag(A)^-1 applied before A (hipk_bi_mid_kernel<W, PRE>: a fourth LDS window holds dinv; phat and shat formed at
     # the gathered columns); against hipk_pbicgstab_solve's launch sequence
