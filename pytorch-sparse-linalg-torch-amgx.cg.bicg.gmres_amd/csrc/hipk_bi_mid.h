@@ -213,9 +213,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (lane == 0) hipk_ll_put(ll, wg * ss, part, seq, rq_o);
         }
         // hand-off 1: q at the window's halo columns, the partials of <rhat,q>
-        for (int widx = tid; widx < WINc; widx += NTHR) {
+        for (int idx = tid; idx < WINc - CH; idx += NTHR) {   // the window without the own tiles (contiguous at H)
+            const int widx = idx < H ? idx : idx + CH;
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
-            if ((widx < H || widx >= H + CH) && gc < n) {
+            if (gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc), v)) *fail = 1;
                 qw[widx] = (T)v;
@@ -369,9 +370,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             break;
         }
         // hand-off 3: r at the window's halo columns (the partials are polled by K1 of the next iteration)
-        for (int widx = tid; widx < WINc; widx += NTHR) {
+        for (int idx = tid; idx < WINc - CH; idx += NTHR) {   // the window without the own tiles (contiguous at H)
+            const int widx = idx < H ? idx : idx + CH;
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
-            if ((widx < H || widx >= H + CH) && gc < n) {
+            if (gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq, hipk_ll_load(ll, (unsigned)gc, r_off), v, r_off)) *fail = 1;
                 rw[widx] = (T)v;

@@ -275,9 +275,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs).
         // (Issuing these loads earlier and examining them after the fold measured slower: a poll is a 0.5 us trip, the early
         // ones mostly came back empty and the partials' polls queued behind them -- 7.1 vs 5.8 us per iteration at n = 250 k.)
-        for (int widx = tid; widx < WINc; widx += NTHR) {
+        for (int idx = tid; idx < WINc - OWN; idx += NTHR) {   // the window without the own tiles (contiguous at H)
+            const int widx = idx < H ? idx : idx + OWN;
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
-            if ((widx < H || widx >= H + OWN) && gc < n) {
+            if (gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait<true>(r_ll, (unsigned)gc, seq, hipk_ll_load(r_ll, (unsigned)gc), v)) *fail = 1;
                 rw[widx] = (T)v;

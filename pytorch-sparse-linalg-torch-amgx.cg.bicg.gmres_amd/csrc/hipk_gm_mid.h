@@ -418,9 +418,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         HIPK_MSTAMP(9);
         if (flags[1] || k + 1 >= m) break;
         // hand-off: v_{k+1} at the window's halo columns
-        for (int widx = tid; widx < WINc; widx += NTHR) {
+        for (int idx = tid; idx < WINc - CH; idx += NTHR) {   // the window without the own tiles (contiguous at H)
+            const int widx = idx < H ? idx : idx + CH;
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
-            if ((widx < H || widx >= H + CH) && gc < n) {
+            if (gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq_v, hipk_ll_load(ll, (unsigned)gc), v)) flags[0] = 1;
                 vw[widx] = v;
