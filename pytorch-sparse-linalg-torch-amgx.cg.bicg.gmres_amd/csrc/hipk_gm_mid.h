@@ -32,18 +32,18 @@ struct hipk_gm_mid_args {
     int g, win, m;                 // chunks; doubles of the window in LDS (256 x the most tiles any workgroup's window holds); restart
     hipk_mid_plan plan;            // which tiles (hipk_mid.h)
     const int *crow, *col;
-    const double *val;
-    double *V;                     // the basis, column j at V + j ldv
+    const void *val;               // values, basis, dinv: of the handle's dtype (the kernel's T)
+    void *V;                       // the basis, column j at V + j ldv
     int64_t ldv;
     unsigned long long *v_ll;      // [2 n] flagged words of v_{k+1}
     unsigned long long *slots;     // see kGmMidSlotBytes
-    const double *dinv;            // PRE: the Jacobi preconditioner's diagonal, w = dinv .* (A v) (left preconditioning, TSL:351)
+    const void *dinv;              // PRE: the Jacobi preconditioner's diagonal, w = dinv .* (A v) (left preconditioning, TSL:351)
     hipk_gm_scal *scal;
     double eps;
     int test_not_resident, slot_stride, xcd_aware;
 };
-static inline size_t hipk_gm_mid_lds_bytes(int win) {
-    return (size_t)(win + 8 + HIPK_BASE_CHUNK + kGmMidCols * 256 + 6 * 40 + 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
+static inline size_t hipk_gm_mid_lds_bytes(int win, size_t sv = 8) {   // sv: bytes of a vector element
+    return (size_t)(win + 8 + HIPK_BASE_CHUNK) * sv + (size_t)(kGmMidCols * 256 + 6 * 40 + 32 + 8 + kMidPlanSlots / 2) * sizeof(double);
 }
 
 // Diagnostic twin (make stamps): thread 0 of every workgroup sums, over the steps of a launch, the constant 100 MHz clock between
@@ -65,7 +65,8 @@ __device__ unsigned long long hipk_gm_mid_stamps[kGmMidMaxChunks * HIPK_GMM_NSTA
 
 // PRE: Jacobi-preconditioned GMRES -- the row scaling of the SpMV kernels' epilogue (HIPK_SPMV_SCALE: out = dinv .* out before the
 // fused ||w||^2), which is the whole difference inside a cycle (hipk_pgmres_solve).
-template <int W, bool PRE = false>
+// T: the handle's dtype (basis, window, w / q and the element-wise arithmetic in T; dots, h and the small arrays in double).
+template <typename T, int W, bool PRE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipk_gm_mid_kernel(hipk_gm_mid_args a) {
     constexpr int NTHR = 1024, CH = HIPK_BASE_CHUNK, R = CH / NTHR, TSTEP = NTHR / HIPK_TILE;
     extern __shared__ double mid_lds[];
@@ -74,9 +75,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (wg < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tw = wave & 3, tl = tid & (HIPK_TILE - 1), t0 = tid >> 8;
     const int q4 = tid >> 8, t = tid & 255;   // column group / virtual thread of the vector phases
-    double *vw = mid_lds;                    // v_k at the window's columns; vw[WIN] = 0.0 for the padding entries of short rows
-    double *wq = vw + WIN_ + 8;              // w, then q, of the own rows
-    double *sbm = wq + CH;                   // [32][256] per-column fold buffers
+    constexpr int VEC = hipk_vec<T>::VEC;
+    T *vw = (T *)mid_lds;                    // v_k at the window's columns; vw[WIN] = 0.0 for the padding entries of short rows
+    T *wq = vw + WIN_ + 8;                   // w, then q, of the own rows
+    double *sbm = (double *)(wq + CH);       // [32][256] per-column fold buffers
     double *hs = sbm + kGmMidCols * 256;     // [40] h of the pass
     double *rvec = hs + 40;                  // [40] h accumulated over the passes (TSL:302-305)
     double *hc = rvec + 40;                  // [40] column k of H under the Givens rotations
@@ -104,12 +106,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (tid < 2) flags[tid] = 0;
 
     // ---- the own rows' matrix entries in registers (thread: rows 256 (t0 + 4 k) + tl); v_0 over the window from the basis
-    double vj[R][W], dj[R];
+    T vj[R][W], dj[R];
+    T *const Vb = (T *)a.V;
     int cj[R][W];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int64_t row = base + (t0 + TSTEP * k) * HIPK_TILE + tl;
-        dj[k] = (PRE && row < n) ? a.dinv[row] : 1.0;
+        dj[k] = (PRE && row < n) ? ((const T *)a.dinv)[row] : (T)1;
         int lo = 0, len = 0;
         if (row < n) {
             lo = a.crow[row];
@@ -120,13 +123,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const bool has = j < len;
             const int cc = has ? a.col[lo + j] : 0;
             cj[k][j] = has ? (int)tmap[(cc >> 8) - tlo] * HIPK_TILE + (cc & (HIPK_TILE - 1)) : WIN_;
-            vj[k][j] = has ? a.val[lo + j] : 0.0;
+            vj[k][j] = has ? ((const T *)a.val)[lo + j] : (T)0;
         }
     }
-    if (tid < 8) vw[WIN_ + tid] = 0.0;
+    if (tid < 8) vw[WIN_ + tid] = (T)0;
     for (int idx = tid; idx < WINc; idx += NTHR) {
         const int64_t gc = (int64_t)stile[idx >> 8] * HIPK_TILE + (idx & (HIPK_TILE - 1));
-        vw[idx] = gc < n ? a.V[gc] : 0.0;
+        vw[idx] = gc < n ? Vb[gc] : (T)0;
     }
     if (tid < 40) {
         hs[tid] = 0.0;
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // the window geometry is made opaque once per step (hipk_bi_mid.h: LDS addresses formed ahead of the loop cost registers)
         int H = H_, WIN = WIN_;
         asm volatile("" : "+s"(H), "+s"(WIN));
-        double *wq = vw + WIN + 8;
-        double *sbm = wq + CH;
+        T *wq = vw + WIN + 8;
+        double *sbm = (double *)(wq + CH);
         const unsigned seq_k = (unsigned)k + 1u;
         const unsigned ww_o = ww_o0 + (unsigned)(k & 1) * col_bytes;
         // ---- w = A v_k (own rows; products rounded, added in CSR order), wavefront sums of w .* w   (TSL:351-352)
@@ -168,15 +171,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int kk = 0; kk < R; ++kk) {
                 const int lrow = (t0 + TSTEP * kk) * HIPK_TILE + tl;
-                double acc = 0.0;
+                T acc = (T)0;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    const double pr = vj[kk][j] * vw[cj[kk][j]];
+                    const T pr = vj[kk][j] * vw[cj[kk][j]];
                     acc = acc + pr;
                 }
                 if (PRE) acc = dj[kk] * acc;   // w = M (A v_k)
                 wq[lrow] = acc;   // rows beyond n: padding only, +0.0
-                d[kk] = (base + lrow < n) ? acc * acc : 0.0;
+                d[kk] = (base + lrow < n) ? (double)acc * (double)acc : 0.0;
             }
             const double s2 = hipk_wave_sum_pair(d[0], d[1]);
             if ((lane & 31) == 0) ts[(t0 + TSTEP * (lane >> 5)) * 4 + tw] = s2;
@@ -208,27 +211,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // ---- h_j = <V_j, w>, j <= k: chains of the own chunk (column group q4 takes j = q4, q4 + 4, ...; virtual thread t
             // the elements {2t, 2t+1} + 512 jj ascending), chunk trees, partials out   (hipk_gm_multidot_stream_kernel)
             {
-                double wv[CH / 256];
+                // virtual thread t: elements {VEC t .. VEC t + VEC - 1} + 256 VEC jj ascending
+                constexpr int NJ = CH / (256 * VEC);
+                double wv[NJ][VEC];
 #pragma unroll
-                for (int jj = 0; jj < CH / 512; ++jj) {
-                    wv[2 * jj] = wq[2 * t + 512 * jj];
-                    wv[2 * jj + 1] = wq[2 * t + 512 * jj + 1];
-                }
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) wv[jj][e] = (double)wq[VEC * t + 256 * VEC * jj + e];
                 for (int j = q4; j <= k; j += 4) {
-                    const double *Vj = a.V + (int64_t)j * a.ldv + base;
-                    double2 vv[CH / 512];
+                    const T *Vj = Vb + (int64_t)j * a.ldv;
+                    T vv[NJ][VEC];
 #pragma unroll
-                    for (int jj = 0; jj < CH / 512; ++jj) {
-                        const int i = 2 * t + 512 * jj;
-                        if (base + i + 1 < n) vv[jj] = *(const double2 *)(Vj + i);
-                        else vv[jj] = make_double2(base + i < n ? Vj[i] : 0.0, 0.0);
+                    for (int jj = 0; jj < NJ; ++jj) {
+                        const int64_t i = base + VEC * t + 256 * VEC * jj;
+                        const int64_t left = n - i;
+                        hipk_ld<T>(Vj, i, left >= VEC ? VEC : (left > 0 ? (int)left : 0), vv[jj]);
                     }
                     double acc = 0.0;
 #pragma unroll
-                    for (int jj = 0; jj < CH / 512; ++jj) {
-                        const int i = 2 * t + 512 * jj;
-                        if (base + i < n) acc = fma(vv[jj].x, wv[2 * jj], acc);
-                        if (base + i + 1 < n) acc = fma(vv[jj].y, wv[2 * jj + 1], acc);
+                    for (int jj = 0; jj < NJ; ++jj) {
+                        const int64_t i = base + VEC * t + 256 * VEC * jj;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (i + e < n) acc = fma((double)vv[jj][e], wv[jj][e], acc);
                     }
                     sbm[j * 256 + t] = acc;
                 }
@@ -276,16 +281,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 const int i = 2 * t + 512 * q4;
                 double s0 = 0.0, s1 = 0.0;
                 for (int j = 0; j <= k; ++j) {
-                    const double *Vj = a.V + (int64_t)j * a.ldv + base;
-                    double2 vv;
-                    if (base + i + 1 < n) vv = *(const double2 *)(Vj + i);
-                    else vv = make_double2(base + i < n ? Vj[i] : 0.0, 0.0);
+                    const T *Vj = Vb + (int64_t)j * a.ldv + base;
+                    T v0 = (T)0, v1 = (T)0;
+                    if (base + i + 1 < n) {
+                        if constexpr (sizeof(T) == 8) {
+                            const double2 vv = *(const double2 *)(Vj + i);
+                            v0 = vv.x;
+                            v1 = vv.y;
+                        } else {
+                            const float2 vv = *(const float2 *)(Vj + i);
+                            v0 = vv.x;
+                            v1 = vv.y;
+                        }
+                    } else if (base + i < n) {
+                        v0 = Vj[i];
+                    }
                     const double hj = hs[j];
-                    s0 = fma(vv.x, hj, s0);
-                    s1 = fma(vv.y, hj, s1);
+                    s0 = fma((double)v0, hj, s0);
+                    s1 = fma((double)v1, hj, s1);
                 }
-                wq[i] = wq[i] - s0;
-                wq[i + 1] = wq[i + 1] - s1;
+                wq[i] = (T)((double)wq[i] - s0);
+                wq[i + 1] = (T)((double)wq[i + 1] - s1);
                 if (tid <= k) rvec[tid] = ((pass == 0) ? 0.0 : rvec[tid]) + hs[tid];
             }
             __syncthreads();
@@ -293,11 +309,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (tid < 256) {
                 double acc = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < CH / 512; ++jj)
+                for (int jj = 0; jj < CH / (256 * VEC); ++jj)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int i = 2 * tid + 512 * jj + e;
-                        const double v = wq[i];
+                    for (int e = 0; e < VEC; ++e) {
+                        const int i = VEC * tid + 256 * VEC * jj + e;
+                        const double v = (double)wq[i];
                         if (base + i < n) acc = fma(v, v, acc);
                     }
                 sbm[tid] = acc;
@@ -340,18 +356,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (!(norm0 > eps)) norm0 = 0.0;
         const double thr = eps * norm0;
         const bool use = norm1 > thr;
-        const double nrm = norm1;
+        const T nrm = (T)norm1;
         const unsigned seq_v = (unsigned)k + 1u;
         {
             const int i = 2 * t + 512 * q4;
-            double *Vn = a.V + (int64_t)(k + 1) * a.ldv + base;
+            T *Vn = Vb + (int64_t)(k + 1) * a.ldv + base;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const double v = use ? wq[i + e] / nrm : 0.0;
+                const T v = use ? wq[i + e] / nrm : (T)0;
                 vw[H + i + e] = v;
                 if (base + i + e < n) {
                     Vn[i + e] = v;
-                    if (pub) hipk_ll_put(ll, (unsigned)(base + i + e), v, seq_v);
+                    if (pub) hipk_ll_put(ll, (unsigned)(base + i + e), (double)v, seq_v);   // (a float travels as the double it equals)
                 }
             }
         }
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (gc < n) {
                 double v = 0.0;
                 if (!hipk_ll_wait(ll, (unsigned)gc, seq_v, hipk_ll_load(ll, (unsigned)gc), v)) flags[0] = 1;
-                vw[widx] = v;
+                vw[widx] = (T)v;
             }
         }
         __syncthreads();

@@ -2132,7 +2132,7 @@ extern "C" size_t hipk_gmres_work_bytes(int64_t n, int restart, int dtype) {
     const hipk_geom gm = hipk_make_geom(n > 0 ? n : 1);
     const bool mid = gm.g > 8 && gm.g <= kGmMidMaxChunks && m <= HIPK_GM_MAXM;
     return kGmHeader + hipk_gm_big_doubles(m) * sizeof(double) + (size_t)(kGmSlots + m + 1) * HIPK_MAX_PARTS * sizeof(double) +
-           (size_t)(m + 2) * vec + (mid ? 2 * vec + kGmMidSlotBytes : 0);
+           (size_t)(m + 2) * vec + (mid ? hipk_align_up((size_t)(n > 0 ? n : 1) * 16, 256) + kGmMidSlotBytes : 0);   // v_{k+1} as 16-byte flagged words
 }
 
 // partials of || d .* v ||^2 (||M b|| of the preconditioned solver, TSL:750)
@@ -2303,21 +2303,21 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
     memset(&mid_plan, 0, sizeof(mid_plan));
     size_t mid_lds = 0;
     void (*mid_kern)(hipk_gm_mid_args) = nullptr;
-    if constexpr (sizeof(T) == 8) {
+    {
         const int mid_min = env_int("HIPK_GMRES_MID_MIN", kGmMidMinChunks);   // (A/B against the whole-solve kernel of 9 .. 32 chunks)
         mid_cycle = !small && !ext && m <= HIPK_GM_MAXM && gm.g > (mid_min < 8 ? 8 : mid_min) && gm.g <= kGmMidMaxChunks &&
                     gm.g <= A->n_cu && gm.ch == HIPK_BASE_CHUNK && A->op_cb == nullptr && A->crow != nullptr && A->max_row_len <= 12 &&
                     prm->profile == 0 && !mid_failed && !(getenv("HIPK_GMRES_MID") && getenv("HIPK_GMRES_MID")[0] == '0') &&
                     !getenv("HIPK_GMRES_NO_CYCLE");
         if (dinv)
-            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5, true> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7, true>
-                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9, true> : hipk_gm_mid_kernel<12, true>;
+            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<T, 5, true> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<T, 7, true>
+                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<T, 9, true> : hipk_gm_mid_kernel<T, 12, true>;
         else
-            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<7>
-                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<9> : hipk_gm_mid_kernel<12>;
+            mid_kern = A->max_row_len <= 5 ? hipk_gm_mid_kernel<T, 5> : A->max_row_len <= 7 ? hipk_gm_mid_kernel<T, 7>
+                       : A->max_row_len <= 9 ? hipk_gm_mid_kernel<T, 9> : hipk_gm_mid_kernel<T, 12>;
         if (mid_cycle) {
             mid_cycle = hipk_mid_plan_get(A, 1, stream, &mid_plan);   // the tiles each workgroup's window holds (hipk_mid.h)
-            mid_lds = mid_cycle ? hipk_gm_mid_lds_bytes(mid_plan.max_slots * HIPK_TILE) : 0;
+            mid_lds = mid_cycle ? hipk_gm_mid_lds_bytes(mid_plan.max_slots * HIPK_TILE, sizeof(T)) : 0;
             int occ = 0;
             mid_cycle = mid_cycle && mid_plan.max_slots <= kMidPlanSlots && mid_lds <= (size_t)160 * 1024 &&
                         hipFuncSetAttribute((const void *)mid_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) == hipSuccess &&
@@ -2394,7 +2394,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
             else
                 hipk_gm_cycle_small_kernel<T><<<8 * gm.g, HIPK_BASE_CHUNK / hipk_vec<T>::VEC, 0, stream>>>(ca);
         }
-        if constexpr (sizeof(T) == 8) {
+        {
             if (mid_cycle) {
                 hipk_gm_mid_args ca;
                 memset(&ca, 0, sizeof(ca));
@@ -2405,12 +2405,12 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                 ca.m = m;
                 ca.crow = A->crow;
                 ca.col = A->col;
-                ca.val = (const double *)A->val;
-                ca.V = (double *)V;
+                ca.val = A->val;
+                ca.V = V;
                 ca.ldv = ldv;
                 ca.v_ll = (unsigned long long *)(vbase + (size_t)(m + 2) * vec);      // behind the basis and tmp (hipk_gmres_work_bytes)
-                ca.slots = (unsigned long long *)(vbase + (size_t)(m + 4) * vec);
-                ca.dinv = (const double *)dinv;
+                ca.slots = (unsigned long long *)(vbase + (size_t)(m + 2) * vec + hipk_align_up((size_t)n * 16, 256));
+                ca.dinv = dinv;
                 ca.scal = scal;
                 ca.eps = eps_t;
                 ca.slot_stride = 16;
@@ -2420,7 +2420,7 @@ static int hipk_gmres_solve_t(hipk_csr_s *A, const T *dinv, const T *b, T *x, ch
                     const int fail_launch = fe ? (atoi(fe) > 1 ? atoi(fe) : 1) : 0;
                     ca.test_not_resident = (++lds_launch_no == fail_launch) ? 1 : 0;
                 }
-                (void)hipMemsetAsync(ca.v_ll, 0, 2 * vec, stream);
+                (void)hipMemsetAsync(ca.v_ll, 0, hipk_align_up((size_t)n * 16, 256), stream);
                 (void)hipMemsetAsync(ca.slots, 0, (size_t)kGmMidKinds * gm.g * ca.slot_stride * 16, stream);
                 mid_kern<<<hipk_xcd_grid(gm.g), 1024, mid_lds, stream>>>(ca);
             }

@@ -1125,11 +1125,14 @@ def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
              (grid3d(64), dict(tol=1e-8, restart=25, maxiter=3), {}),                                             # 128 chunks, three bands of tiles
              (grid3d(45), dict(tol=1e-8, restart=30, maxiter=2, solve_method="incremental"), {})]               # ragged planes
     for idx, (A, kw, env) in enumerate(cases):
-        h = hipk.handle_for(A)
+      for dt in (torch.float64, torch.float32):   # fp32 storage: the kernel's T = float
+        Ad = A if dt == torch.float64 else torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), A.values().float(), size=A.shape)
+        kwd = kw if dt == torch.float64 else {**kw, "tol": max(kw["tol"], 1e-4)}
+        h = hipk.handle_for(Ad)
         n = A.shape[0]
         g = torch.Generator(device=DEV).manual_seed(idx)
-        b = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
-        x0 = torch.randn(n, dtype=torch.float64, device=DEV, generator=g) if idx % 2 else None
+        b = torch.randn(n, dtype=dt, device=DEV, generator=g)
+        x0 = torch.randn(n, dtype=dt, device=DEV, generator=g) if idx % 2 else None
         out = []
         for mid in ("1", "0"):
             monkeypatch.setenv("HIPK_GMRES_MID", mid)
@@ -1139,10 +1142,10 @@ def test_gmres_mid_one_launch_cycle_is_bit_identical(hipk, oracle, monkeypatch):
                 else:
                     monkeypatch.delenv(k, raising=False)
             x = torch.zeros_like(b) if x0 is None else x0.clone()
-            print("gmres mid case", idx, "mid" if mid == "1" else "launch sequence", flush=True)
-            st = hipk.solve("gmres", h, b, x, atol=0.0, **kw)
+            print("gmres mid case", idx, dt, "mid" if mid == "1" else "launch sequence", flush=True)
+            st = hipk.solve("gmres", h, b, x, atol=0.0, **kwd)
             out.append((x.clone(), st.iterations, st.matvecs, st.info, st.residual_norm, st.recurrence_rs, st.breakdown))
-        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, out[0][1:], out[1][1:])
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:], (idx, dt, out[0][1:], out[1][1:])
     # the same with M = diag(d) applied after every A (hipk_gm_mid_kernel<W, PRE>: the row scaling of the SpMV epilogue); a diagonal
     # that is NOT the matrix's own, so that the scaling matters
     import scipy.sparse as sp

@@ -84,7 +84,8 @@ MID = {
                     "void hipk_cg_mid_kernel<float, 12, 1, false>": 0},
     "hipk_bicgstab.hip": {"void hipk_bi_mid_kernel<double, 5, false>": 8, "void hipk_bi_mid_kernel<double, 7, false>": 48, "void hipk_bi_mid_kernel<double, 5, true>": 8,
                           "void hipk_bi_mid_kernel<float, 5, false>": 0},
-    "hipk_gmres.hip": {"void hipk_gm_mid_kernel<5, false>": 0, "void hipk_gm_mid_kernel<7, false>": 32, "void hipk_gm_mid_kernel<5, true>": 16},
+    "hipk_gmres.hip": {"void hipk_gm_mid_kernel<double, 5, false>": 0, "void hipk_gm_mid_kernel<double, 7, false>": 32, "void hipk_gm_mid_kernel<double, 5, true>": 16,
+                       "void hipk_gm_mid_kernel<float, 5, false>": 0},
 }
 
 
