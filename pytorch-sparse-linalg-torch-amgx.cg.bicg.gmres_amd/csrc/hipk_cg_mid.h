@@ -275,9 +275,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // r at the window's halo columns (polled before the partials of <r,r>: the neighbours published r before theirs).
         // (Issuing these loads earlier and examining them after the fold measured slower: a poll is a 0.5 us trip, the early
         // ones mostly came back empty and the partials' polls queued behind them -- 7.1 vs 5.8 us per iteration at n = 250 k.)
-        // (So did giving the halo to the twelve wavefronts that have no chains to run, at once, with the chain wavefronts meeting at an
-        // LDS arrival counter instead of the barrier: 5.7 vs 5.2 us at 250 k rows, 8.1 vs 6.9 at 518 k, 10.8 vs 8.2-9.0 at 1 M -- polls
-        // that start before the words can have arrived only load the fabric the words travel on.)
         for (int idx = tid; idx < WINc - OWN; idx += NTHR) {   // the window without the own tiles (contiguous at H)
             const int widx = idx < H ? idx : idx + OWN;
             const int64_t gc = (int64_t)stile[widx >> 8] * HIPK_TILE + (widx & (HIPK_TILE - 1));
